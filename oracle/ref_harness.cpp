@@ -1,0 +1,243 @@
+// TEST INFRASTRUCTURE -- see ref_harness.h.  This translation unit is the only new code
+// in oracle/_ref/libunc_ref.so; everything it drives is the reference's own object code.
+// It reaches Mapper's private state (prev_paths_, seed_tracker_, map_next) by re-labelling
+// `private` for THIS TU only; the reference TUs are compiled untouched, and access
+// specifiers do not change the Itanium-ABI layout, so both views of the classes agree.
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#define private public
+#define protected public
+#include "mapper.hpp"
+#undef private
+#undef protected
+
+#include "ref_harness.h"
+
+namespace {
+
+void fill_read(ReadBuffer &r, const float *signal, uint32_t n, uint32_t number) {
+    r.id_ = "read" + std::to_string(number);
+    r.channel_idx_ = 0;
+    r.number_ = number;
+    r.start_sample_ = 0;
+    r.full_signal_.assign(signal, signal + n);
+    r.chunk_.clear();
+    r.chunk_count_ = 0;
+    r.chunk_processed_ = false;
+    r.loc_ = Paf(r.id_, r.get_channel(), r.start_sample_);
+    r.set_raw_len(n);
+}
+
+void fill_hit(Mapper *m, const Paf &p, ref_hit_t *h) {
+    std::memset(h, 0, sizeof *h);
+    h->mapped = p.is_mapped_;
+    h->fwd = p.fwd_;
+    h->rd_st = p.rd_st_; h->rd_en = p.rd_en_; h->rd_len = p.rd_len_;
+    h->rf_st = p.rf_st_; h->rf_en = p.rf_en_; h->rf_len = p.rf_len_;
+    h->matches = p.matches_;
+    h->event_i = m->event_i_;
+    h->n_events = m->norm_.n_;
+    h->mean_event_len = m->evdt_.mean_event_len();
+    std::strncpy(h->rf_name, p.rf_name_.c_str(), sizeof h->rf_name - 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events) {
+    Mapper::PRMS.bwa_prefix = bwa_prefix;
+    Mapper::PRMS.idx_preset = idx_preset ? idx_preset : "default";
+    if (max_events) Mapper::PRMS.max_events = max_events;
+    Mapper m;  // load_static(): aborts on a bad index exactly as the reference does
+    return Mapper::fmi.is_loaded() ? 0 : 1;
+}
+
+void *ref_mapper_new(void) { return new Mapper(); }
+void ref_mapper_free(void *m) { delete static_cast<Mapper *>(m); }
+
+void ref_calibrate(const int16_t *raw, uint64_t n, float range, float offset, float digitisation, float *out) {
+    // read_buffer.cpp:239-241: `for (u16 raw : int_data) cal_range * (raw + cal_offset) / cal_digit`
+    for (uint64_t i = 0; i < n; ++i) {
+        u16 r = (u16)raw[i];
+        float calibrated = range * (r + offset) / digitisation;
+        out[i] = calibrated;
+    }
+}
+
+int ref_map_read(void *mp, const float *signal, uint32_t n, ref_hit_t *out) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    ReadBuffer r;
+    fill_read(r, signal, n, 0);
+    minibwa_counters_reset();
+    auto t0 = std::chrono::steady_clock::now();
+    m->new_read(r);
+    Paf p = m->map_read();
+    auto t1 = std::chrono::steady_clock::now();
+    fill_hit(m, p, out);
+    minibwa_counters_t c;
+    minibwa_counters_get(&c);
+    out->n_nbr = c.n_2occ; out->n_sa = c.n_sa; out->n_lf = c.n_lf;
+    out->map_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return 0;
+}
+
+double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out) {
+    if (n_threads < 1) n_threads = 1;
+    std::vector<Mapper *> mappers;
+    for (int t = 0; t < n_threads; ++t) mappers.push_back(new Mapper());
+    std::atomic<uint32_t> next(0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        th.emplace_back([&, t]() {
+            for (;;) {
+                uint32_t i = next.fetch_add(1);
+                if (i >= n_reads) break;
+                ref_map_read(mappers[t], signals + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), out + i);
+            }
+        });
+    }
+    for (auto &x : th) x.join();
+    auto t1 = std::chrono::steady_clock::now();
+    for (auto *m : mappers) delete m;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events) {
+    EventDetector ed(Mapper::PRMS.event_prms);
+    std::vector<float> raw(signal, signal + n);
+    std::vector<Event> ev = ed.get_events(raw);
+    for (uint32_t i = 0; i < ev.size() && i < cap; ++i) {
+        out[i].mean = ev[i].mean; out[i].stdv = ev[i].stdv;
+        out[i].start = ev[i].start; out[i].length = ev[i].length;
+    }
+    if (mean_event_len) *mean_event_len = ed.mean_event_len();
+    if (total_events) *total_events = ed.total_events_;
+    return (uint32_t)ev.size();
+}
+
+void ref_norm_levels(const float *means, uint32_t m, float *levels, float *scale, float *shift) {
+    Normalizer norm(Mapper::PRMS.norm_prms);
+    norm.set_target(Mapper::model.get_means_mean(), Mapper::model.get_means_stdv());
+    std::vector<float> sig(means, means + m);
+    norm.set_signal(sig);
+    if (scale) *scale = norm.get_scale();
+    if (shift) *shift = norm.get_shift();
+    for (uint32_t i = 0; i < m; ++i) levels[i] = norm.pop();
+}
+
+void ref_match_probs(float level, float *out1024) {
+    for (u16 k = 0; k < 1024; ++k) out1024[k] = Mapper::model.match_prob(level, k);
+}
+
+void ref_model_tables(float *means, float *vars_x2, float *lognorm, float *model_mean, float *model_stdv) {
+    for (u16 k = 0; k < 1024; ++k) {
+        means[k] = Mapper::model.lv_means_[k];
+        vars_x2[k] = Mapper::model.lv_vars_x2_[k];
+        lognorm[k] = Mapper::model.lognorm_denoms_[k];
+    }
+    *model_mean = Mapper::model.get_means_mean();
+    *model_stdv = Mapper::model.get_means_stdv();
+}
+
+void ref_kmer_ranges(uint64_t *out2048) {
+    for (u16 k = 0; k < 1024; ++k) {
+        Range r = Mapper::fmi.get_kmer_range(k);
+        out2048[2 * k] = r.start_;
+        out2048[2 * k + 1] = r.end_;
+    }
+}
+
+void ref_thresholds(float *out64) {
+    for (int i = 0; i < 64; ++i) out64[i] = Mapper::prob_threshes_[i];
+}
+
+void ref_get_neighbor(uint64_t s, uint64_t e, int base, uint64_t *os, uint64_t *oe) {
+    Range r = Mapper::fmi.get_neighbor(Range(s, e), (u8)base);
+    *os = r.start_; *oe = r.end_;
+}
+
+uint64_t ref_sa(uint64_t k) { return Mapper::fmi.sa(k); }
+uint64_t ref_fm_size(void) { return Mapper::fmi.size(); }
+
+void ref_trace_begin(void *mp, const float *signal, uint32_t n) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    ReadBuffer r;
+    fill_read(r, signal, n, 0);
+    minibwa_counters_reset();
+    m->new_read(r);
+    // mapper.cpp:191-193
+    m->map_timer_.reset();
+    m->norm_.set_signal(m->evdt_.get_means(m->read_.full_signal_));
+}
+
+int ref_trace_step(void *mp) { return static_cast<Mapper *>(mp)->map_next() ? 1 : 0; }
+
+uint32_t ref_trace_paths(void *mp, ref_path_t *out, uint32_t cap) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    uint32_t n = m->prev_size_;
+    for (uint32_t i = 0; i < n && i < cap; ++i) {
+        const Mapper::PathBuffer &p = m->prev_paths_[i];
+        ref_path_t &o = out[i];
+        std::memset(&o, 0, sizeof o);
+        o.fm_start = p.fm_range_.start_; o.fm_end = p.fm_range_.end_;
+        o.event_moves = p.event_moves_; o.seed_prob = p.seed_prob_; o.kmer = p.kmer_;
+        o.length = p.length_; o.consec_stays = p.consec_stays_; o.sa_checked = p.sa_checked_;
+        for (int j = 0; j <= (int)p.length_ && j < 23; ++j) o.prob_sums[j] = p.prob_sums_[j];
+    }
+    return n;
+}
+
+uint32_t ref_trace_clusters(void *mp, ref_cluster_t *out, uint32_t cap, ref_cluster_t *max_map, float *len_sum, uint32_t *n_lens) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    SeedTracker &st = m->seed_tracker_;
+    uint32_t i = 0;
+    for (const SeedCluster &c : st.seed_clusters_) {
+        if (i < cap) {
+            out[i].ref_st = c.ref_st_; out[i].ref_en_start = c.ref_en_.start_; out[i].ref_en_end = c.ref_en_.end_;
+            out[i].evt_st = c.evt_st_; out[i].evt_en = c.evt_en_; out[i].total_len = c.total_len_; out[i].pad = 0;
+        }
+        ++i;
+    }
+    if (max_map) {
+        const SeedCluster &c = st.max_map_;
+        max_map->ref_st = c.total_len_ ? c.ref_st_ : 0;
+        max_map->ref_en_start = c.ref_en_.start_; max_map->ref_en_end = c.ref_en_.end_;
+        max_map->evt_st = c.evt_st_; max_map->evt_en = c.evt_en_; max_map->total_len = c.total_len_; max_map->pad = 0;
+    }
+    if (len_sum) *len_sum = st.len_sum_;
+    if (n_lens) *n_lens = (uint32_t)st.all_lens_.size();
+    return i;
+}
+
+uint32_t ref_trace_event_i(void *mp) { return static_cast<Mapper *>(mp)->event_i_; }
+
+void ref_trace_finish(void *mp, ref_hit_t *out) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    fill_hit(m, m->read_.loc_, out);
+    minibwa_counters_t c;
+    minibwa_counters_get(&c);
+    out->n_nbr = c.n_2occ; out->n_sa = c.n_sa; out->n_lf = c.n_lf;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+/* TEST INFRASTRUCTURE -- C ABI of oracle/_ref/libunc_ref.so: the reference's own hot-path
+ * sources (/root/reference/src/{mapper,event_detector,normalizer,event_profiler,
+ * seed_tracker,range,read_buffer,chunk}.cpp) compiled IN PLACE, unmodified, with the
+ * reference's flags (-std=c++11 -O3, setup.py:121) against oracle/shim + oracle/minibwa.c.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it. */
+#ifndef UNC_REF_HARNESS_H
+#define UNC_REF_HARNESS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t mapped, fwd;
+    uint64_t rd_st, rd_en, rd_len;      /* PAF cols 3,4,2 */
+    uint64_t rf_st, rf_en, rf_len;      /* PAF cols 8,9,7 */
+    uint32_t matches;                   /* PAF col 10; col 11 = rf_en - rf_st + 1 */
+    uint32_t n_events;                  /* events kept by the detector over the whole read */
+    uint32_t event_i;                   /* Mapper::event_i_ when map_read returned */
+    float mean_event_len;
+    uint64_t n_nbr, n_sa, n_lf;         /* minibwa work counters for this read */
+    double map_ms;
+    char rf_name[128];
+} ref_hit_t;
+
+typedef struct { float mean, stdv; uint32_t start, length; } ref_event_t;
+
+typedef struct {
+    uint64_t fm_start, fm_end;
+    uint32_t event_moves;
+    float seed_prob;
+    uint16_t kmer;
+    uint8_t length, consec_stays, sa_checked, pad[3];
+    float prob_sums[23];
+} ref_path_t;
+
+typedef struct {
+    uint64_t ref_st, ref_en_start, ref_en_end;
+    uint32_t evt_st, evt_en, total_len, pad;
+} ref_cluster_t;
+
+/* Sets Mapper::PRMS.{bwa_prefix,idx_preset}; first Mapper construction loads the statics.
+ * max_events==0 keeps the reference default (30000).  Returns 0 on success. */
+int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events);
+void *ref_mapper_new(void);
+void ref_mapper_free(void *m);
+
+/* read_buffer.cpp:239-241 (u16 reinterpretation quirk included). */
+void ref_calibrate(const int16_t *raw, uint64_t n, float range, float offset, float digitisation, float *out);
+
+int ref_map_read(void *m, const float *signal, uint32_t n, ref_hit_t *out);
+/* N threads, one Mapper each, tight new_read->map_read loop over an interleaved shard
+ * (BASELINE.md "B1").  Returns wall seconds of the mapping loop. */
+double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out);
+
+/* stage taps */
+uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events);
+void ref_norm_levels(const float *means, uint32_t m, float *levels, float *scale, float *shift);
+void ref_match_probs(float level, float *out1024);
+void ref_model_tables(float *means1024, float *vars_x2_1024, float *lognorm1024, float *model_mean, float *model_stdv);
+void ref_kmer_ranges(uint64_t *out2048);
+void ref_thresholds(float *out64);
+void ref_get_neighbor(uint64_t s, uint64_t e, int base, uint64_t *os, uint64_t *oe);
+uint64_t ref_sa(uint64_t k);
+uint64_t ref_fm_size(void);
+
+/* step-wise trace of Mapper::map_read (mapper.cpp:188-200) */
+void ref_trace_begin(void *m, const float *signal, uint32_t n);
+int ref_trace_step(void *m);                                   /* one map_next(); 1 when done */
+uint32_t ref_trace_paths(void *m, ref_path_t *out, uint32_t cap);  /* prev_paths_[0..prev_size_) */
+uint32_t ref_trace_clusters(void *m, ref_cluster_t *out, uint32_t cap, ref_cluster_t *max_map, float *len_sum, uint32_t *n_lens);
+uint32_t ref_trace_event_i(void *m);
+void ref_trace_finish(void *m, ref_hit_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
