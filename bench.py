@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- reads mapped/sec of the MI355X hot path (BASELINE.json metric) on the E. coli configuration.
+
+One step = one pass of the whole hot path (event detection -> normalisation -> match -> FM path forest -> seed
+clustering -> PAF coordinates) over one batch of synthetic r9.4.1 reads that is already resident in HBM.
+`--gpus N` is launched by the driver as N ranks (torch.distributed.run); reads shard across ranks (index
+replicated per GPU, no data-path collective), per-GPU work fixed => weak scaling.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how roofline / cpu_baseline are derived).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def ensure_index(cache, rank, world, barrier):
+    """SURVEY 8(d) `ecoli_syn`: 1 contig, 4 641 652 bp, i.i.d. ACGT, GC 0.508, seed 1 -> BWA-format index."""
+    from tools.build_index import build_from_codes, synthetic_genome
+    prefix = cache / "ecoli_syn"
+    names, lens, codes = synthetic_genome(1, 4641652, seed=1)
+    if rank == 0 and not (Path(str(prefix) + ".sa").exists() and Path(str(prefix) + ".uncl").exists()):
+        cache.mkdir(parents=True, exist_ok=True)
+        build_from_codes(prefix, names, [""] * len(names), lens, codes)
+    barrier()
+    return prefix, codes, lens
+
+
+def algorithmic_bytes(hits, offsets):
+    """per read 2*S + 128*N_nbr + 64*N_lf + 8*N_sa + 64; split per kernel in DESIGN.md."""
+    S = (offsets[1:] - offsets[:-1]).astype(np.float64)
+    ev_bytes = 2.0 * S + 4.0 * hits["n_events"] + 24.0
+    map_bytes = 4.0 * hits["event_i"] + 128.0 * hits["n_nbr"] + 64.0 * hits["n_lf"] + 8.0 * hits["n_sa"] + 64.0
+    return float(ev_bytes.sum()), float(map_bytes.sum())
+
+
+def cpu_baseline(prefix, sim_signal_host, offsets, calib, hits_gpu, seconds_target=20.0):
+    """Times the CPU path on the host cores over a bounded sample of the same reads (rank 0, N=1 only) and checks
+    the GPU's PAF columns against it.  Prefers oracle/_ref (the reference's own object code) when it travelled."""
+    from oracle import pyoracle as po
+    from oracle import pyref
+    cores = os.cpu_count() or 1
+    kind = "reference" if pyref.available() else "port"
+    n_avail = offsets.size - 1
+    # ~0.1 s per read per core on this class of host: size the sample for about seconds_target of wall time
+    n = int(min(n_avail, max(cores * 8, seconds_target * cores / 0.12)))
+    off = offsets[:n + 1]
+    raw = sim_signal_host[:int(off[-1])]
+    sig = po.calibrate(raw, float(calib["range"][0]), float(calib["offset"][0]), float(calib["digitisation"][0]))
+    oix = po.Index(prefix)
+    names = oix.ref_names()
+    if kind == "reference":
+        pyref.init(prefix)
+        hits, secs = pyref.map_batch(sig, off, cores)
+        cpu_cols = [h.paf_cols() for h in hits]
+    else:
+        hits, secs = po.map_batch(oix, sig, off, cores)
+        cpu_cols = [po.hit_paf_cols(h, names) for h in hits]
+    from uncalled_amd import capi
+    mism = sum(1 for i in range(n) if capi.hit_paf_cols(hits_gpu[i], names) != cpu_cols[i])
+    return dict(value=n / secs, unit="reads/s", cores=cores, kind=kind,
+                sample=f"first {n} reads of the batch, {cores} threads, tight new_read->map_read loop (BASELINE.md B1)",
+                seconds=secs, paf_mismatches_vs_gpu=mism)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("UNC_BENCH_READS", 50000)),
+                    help="reads per GPU per step (config: E. coli 4.6 Mb ref, 50k synthetic r9.4.1 reads)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
+    from tools.simulate_reads_torch import simulate_reads_torch
+    from uncalled_amd import capi
+
+    cache = Path(os.environ.get("UNC_BENCH_CACHE", "/tmp/uncalled_amd_bench"))
+    prefix, codes, lens = ensure_index(cache, rank, world, barrier)
+    ix = capi.Index(prefix, device=local_rank)
+    mapper = capi.Mapper(ix)
+    # this rank's shard of the read set: reads are independent units, sharded by rank with distinct seeds
+    sim = simulate_reads_torch(codes, lens, a.reads, seed=42 + rank, device=f"cuda:{local_rank}")
+    offsets = sim["offsets"]
+    calib = capi.make_calib(a.reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    raw_ptr = sim["signal"].data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    hits = None
+    for _ in range(a.warmup):
+        hits = mapper.map_batch_device(raw_ptr, offsets, calib, stream=stream)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    ms_ev, ms_map = [], []
+    for _ in range(a.steps):
+        hits = mapper.map_batch_device(raw_ptr, offsets, calib, stream=stream)
+        e, m = mapper.last_timing()
+        ms_ev.append(e)
+        ms_map.append(m)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_reads = a.reads * world * a.steps
+        ev_bytes, map_bytes = algorithmic_bytes(hits, offsets)
+        map_ms = float(np.mean(ms_map))
+        achieved = map_bytes / (map_ms * 1e-3) / 1e9
+        out = {
+            "metric": "reads_mapped_per_sec", "value": total_reads / dt, "unit": "reads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32/f64",
+            "data": "synthetic",
+            "config": {"workload": "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1), synthetic r9.4.1 reads "
+                                   "(3600 bases ~ 32k samples, 10% off-target), all reference defaults",
+                       "reads_per_gpu_per_step": a.reads, "parallelism": f"reads sharded over {world} GPU(s), index replicated",
+                       "mean_ms_per_read_amortised": 1e3 * dt / (a.reads * a.steps),
+                       "mapped_fraction": float(hits["mapped"].mean()),
+                       "mean_events_per_read": float(hits["event_i"].mean()),
+                       "kernel_ms": {"k_events": float(np.mean(ms_ev)), "k_map": map_ms}},
+            "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms,
+                         "whole_path_bytes_per_step": ev_bytes + map_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            host_sig = sim["signal"][:int(offsets[min(a.reads, 4096)])].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(prefix, host_sig, offsets[:min(a.reads, 4096) + 1], calib, hits)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

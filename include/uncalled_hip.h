@@ -1,0 +1,181 @@
+/* uncalled_hip.h -- C ABI of libuncalled_hip.so: the MI355X (gfx950) implementation of UNCALLED's
+ * per-read Mapper hot path (event detection -> normalisation -> r9.4 5-mer match -> FM-index path
+ * forest -> seed clustering -> PAF coordinates), batched over reads, one wavefront per read.
+ *
+ * Every entry point names the reference interface it stands in for (skovaka/UNCALLED v2.3.0,
+ * paths relative to the reference root).  No exceptions cross this boundary: functions return
+ * UNC_OK (0) or a negative unc_status_t; unc_last_error() gives the message for the calling thread.
+ * Plain pointers and sizes only -- no C++/torch types.
+ */
+#ifndef UNCALLED_HIP_H
+#define UNCALLED_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    UNC_OK = 0,
+    UNC_ERR_ARG = -1,        /* bad argument / unsupported parameter value */
+    UNC_ERR_IO = -2,         /* index file missing or malformed (reference: abort(), mapper.cpp:118-127) */
+    UNC_ERR_HIP = -3,        /* HIP runtime error */
+    UNC_ERR_NOMEM = -4,
+    UNC_ERR_OVERFLOW = -5    /* a per-read device scratch area overflowed (see unc_hit_t.status) */
+} unc_status_t;
+
+/* Compile-time shape of the kernels (the reference's defaults; mapper.cpp:30, event_detector.cpp:18-19) */
+#define UNC_SEED_LEN 22
+#define UNC_KLEN 5
+#define UNC_NKMER 1024
+#define UNC_WINDOW1 3
+#define UNC_WINDOW2 6
+
+/* Mapper::PRMS (mapper.cpp:29-52) + EventDetector::PRMS_DEF (event_detector.cpp:17-26) +
+ * SeedTracker::PRMS_DEF (seed_tracker.cpp:28-32) + ReadBuffer::PRMS (read_buffer.cpp:26-32);
+ * the subset Conf exposes for the map path (conf.hpp:296-340). */
+typedef struct {
+    uint32_t seed_len;          /* must be 22 */
+    uint32_t min_rep_len;
+    uint32_t max_rep_copy;      /* <= 64 */
+    uint32_t max_paths;         /* <= 65535 */
+    uint32_t max_consec_stay;
+    uint32_t max_events;
+    float max_stay_frac;
+    float min_seed_prob;
+    uint32_t window_length1;    /* must be 3 */
+    uint32_t window_length2;    /* must be 6 */
+    float threshold1, threshold2, peak_height, min_mean, max_mean;
+    uint32_t min_map_len;
+    float min_mean_conf, min_top_conf;
+    float bp_per_sec, sample_rate;
+    float chunk_time;
+    uint32_t max_chunks;
+} unc_params_t;
+
+/* fast5 channel calibration, read_buffer.cpp:212-222,239-241 */
+typedef struct { float range, offset, digitisation; } unc_calib_t;
+
+/* per-read status bits */
+#define UNC_READ_OK 0u
+#define UNC_READ_CLUSTER_OVERFLOW 1u   /* seed-cluster scratch exhausted: result for this read is invalid */
+#define UNC_READ_SEED_OVERFLOW 2u      /* per-event seed list exhausted: result for this read is invalid */
+
+/* One PAF record's worth of coordinates (Paf, read_buffer.hpp:42-126; set by Mapper::set_ref_loc,
+ * mapper.cpp:708-728) plus the work counters of SURVEY.md section 8(d). */
+typedef struct {
+    int32_t mapped, fwd, rid;
+    uint32_t status;
+    uint64_t rd_st, rd_en, rd_len;      /* PAF cols 3,4,2 */
+    uint64_t rf_st, rf_en, rf_len;      /* PAF cols 8,9,7 */
+    uint32_t matches;                   /* PAF col 10; col 11 = rf_en - rf_st + 1 */
+    uint32_t n_events;                  /* events kept by the detector over the whole read */
+    uint32_t event_i;                   /* Mapper::event_i_ at the end of map_read */
+    float mean_event_len;
+    uint64_t n_nbr, n_sa, n_lf;         /* get_neighbor calls, SA lookups, LF steps inside them */
+    /* winning SeedCluster (seed_tracker.hpp:40-66), zero when unmapped */
+    uint64_t cl_ref_st, cl_ref_en_start, cl_ref_en_end;
+    uint32_t cl_evt_st, cl_evt_en, cl_total_len, pad;
+} unc_hit_t;
+
+/* stage tap: per-read result of the event/normalisation kernel */
+typedef struct {
+    uint32_t n_events;       /* events with mean in [min_mean, max_mean] */
+    uint32_t total_events;   /* all events (EventDetector::total_events_) */
+    float len_sum;           /* EventDetector::len_sum_ */
+    float scale, shift;      /* Normalizer::at, normalizer.cpp:114-118 */
+    uint32_t pad;
+} unc_evt_info_t;
+
+typedef struct {
+    uint64_t fm_start, fm_end;
+    uint32_t event_moves;
+    float seed_prob;
+    uint16_t kmer;
+    uint8_t length, consec_stays, sa_checked, pad[3];
+    float prob_sums[UNC_SEED_LEN + 1];
+} unc_path_t;
+
+typedef struct {
+    uint64_t ref_st, ref_en_start, ref_en_end;
+    uint32_t evt_st, evt_en, total_len, pad;
+} unc_cluster_t;
+
+typedef struct unc_index unc_index_t;
+typedef struct unc_mapper unc_mapper_t;
+
+const char *unc_last_error(void);
+const char *unc_version(void);
+
+/* Conf defaults: compiled-in PRMS of the reference (SURVEY.md section 5 "Config / flags") */
+void unc_params_default(unc_params_t *p);
+
+/* ---- index: replaces Mapper::load_static (mapper.cpp:109-159) = BwaIndex::load_index
+ * (bwa_index.hpp:116-135: bwt_restore_bwt / bwt_restore_sa / bns_restore + the 1024 k-mer ranges)
+ * + the .uncl threshold parser (mapper.cpp:123-157) + PoreModel tables (pore_model.hpp:58-103).
+ * Parses <prefix>.{bwt,sa,ann,amb,uncl} on the host and uploads BWT/Occ blocks, sampled SA, k-mer
+ * ranges, thresholds and the 1024x3 model table to HBM of `device`. */
+int unc_index_load(const char *bwa_prefix, const char *idx_preset, int device, unc_index_t **out);
+void unc_index_free(unc_index_t *ix);
+uint64_t unc_index_size(const unc_index_t *ix);                      /* BwaIndex::size, bwa_index.hpp:180-182 */
+int32_t unc_index_n_seqs(const unc_index_t *ix);
+const char *unc_index_seq_name(const unc_index_t *ix, int32_t rid);  /* BwaIndex::get_ref_name, :197-199 */
+uint64_t unc_index_seq_len(const unc_index_t *ix, int32_t rid);      /* BwaIndex::get_ref_len, :201-203 */
+/* BwaIndex::translate_loc, bwa_index.hpp:213-220 (bns_pos2rid): returns the sequence length, 0 if none */
+uint64_t unc_index_translate_loc(const unc_index_t *ix, uint64_t sa_loc, int32_t *rid, uint64_t *ref_loc);
+uint64_t unc_index_device_bytes(const unc_index_t *ix);
+/* host copies of the derived tables (parity taps) */
+void unc_index_kmer_ranges(const unc_index_t *ix, uint64_t *out2048);       /* BwaIndex::get_kmer_range */
+void unc_index_thresholds(const unc_index_t *ix, float *out64);             /* Mapper::prob_threshes_ */
+void unc_index_model_tables(const unc_index_t *ix, float *means1024, float *vars_x2_1024, float *lognorm1024,
+                            float *model_mean, float *model_stdv);
+/* device FM primitives run over arrays (parity taps for bwa_index.hpp:158-162 and :176-178) */
+int unc_fm_get_neighbor(const unc_index_t *ix, uint32_t n, const uint64_t *starts, const uint64_t *ends,
+                        const uint8_t *bases, uint64_t *out_starts, uint64_t *out_ends);
+int unc_fm_sa(const unc_index_t *ix, uint32_t n, const uint64_t *rows, uint64_t *out);
+/* device PoreModel::match_prob over all 1024 k-mers (pore_model.hpp:163-165; mapper.cpp:443-445) */
+int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *levels, float *out /* n x 1024 */);
+
+/* ---- mapper: replaces N x (Mapper::new_read + Mapper::map_read) (mapper.cpp:188-207), i.e. the
+ * body of MapPool::MapperThread::run (map_pool.cpp:130-158), for a whole batch of reads. */
+typedef struct {
+    uint32_t n_slots;        /* resident wavefronts (0 = 8 per CU) */
+    uint32_t max_clusters;   /* seed clusters per read (0 = 16384) */
+    uint32_t max_seed_paths; /* seed-valid paths per event (0 = max_paths) */
+    uint32_t reserved;
+} unc_mapper_opts_t;
+
+int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out);
+void unc_mapper_free(unc_mapper_t *m);
+uint64_t unc_mapper_device_bytes(const unc_mapper_t *m);
+
+/* Map a batch.  raw = concatenated int16 samples, read i = raw[offsets[i] .. offsets[i+1]);
+ * calib[i] per read.  When on_device != 0 the three input pointers are device pointers (inputs
+ * already resident in HBM); otherwise they are host pointers and are copied first.  `stream` is a
+ * hipStream_t (NULL = the mapper's own stream).  hits (host, n_reads) receives one record per read. */
+int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                  const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits);
+/* wall-clock of the kernels of the last unc_map_batch, from HIP events on the launch stream */
+int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map);
+
+/* ---- stage taps (parity tests) */
+/* event detection + whole-read normalisation only (EventDetector::get_means, event_detector.cpp:133-145;
+ * Normalizer::set_signal, normalizer.cpp:31-44).  means (host) receives the kept event means of read i
+ * at means[means_offsets[i] ..]; means_offsets (host, n_reads+1) is filled by the call. */
+int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                      const unc_calib_t *calib, float *means, uint64_t means_cap, uint64_t *means_offsets,
+                      unc_evt_info_t *info);
+/* step-wise trace of ONE read (Mapper::map_next, mapper.cpp:433-663): begin, then step until it
+ * returns 1; after each step the live path buffer and seed clusters can be read back. */
+int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, const unc_calib_t *calib);
+int unc_trace_step(unc_mapper_t *m, uint32_t n_events /* map_next calls to run */, int *done);
+int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, uint32_t *n_out);
+int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t cap, uint32_t *n_out, unc_cluster_t *max_map,
+                       float *len_sum, uint32_t *n_lens);
+int unc_trace_finish(unc_mapper_t *m, unc_hit_t *hit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

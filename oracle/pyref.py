@@ -92,6 +92,11 @@ def init(prefix, preset="default", max_events=0):
     _prefix = prefix
 
 
+def set_max_paths(n):
+    lib().ref_set_max_paths.argtypes = [C.c_uint32]
+    lib().ref_set_max_paths(n)
+
+
 def calibrate(raw_i16, rng, offset, digitisation):
     raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
     out = np.empty(raw.size, dtype=np.float32)

@@ -72,6 +72,7 @@ int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events
     return Mapper::fmi.is_loaded() ? 0 : 1;
 }
 
+void ref_set_max_paths(uint32_t max_paths) { Mapper::PRMS.max_paths = max_paths; }
 void *ref_mapper_new(void) { return new Mapper(); }
 void ref_mapper_free(void *m) { delete static_cast<Mapper *>(m); }
 

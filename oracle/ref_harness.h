@@ -42,6 +42,8 @@ typedef struct {
 /* Sets Mapper::PRMS.{bwa_prefix,idx_preset}; first Mapper construction loads the statics.
  * max_events==0 keeps the reference default (30000).  Returns 0 on success. */
 int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events);
+/* Mapper::PRMS.max_paths for Mappers constructed afterwards (mapper.cpp:33,83-86) */
+void ref_set_max_paths(uint32_t max_paths);
 void *ref_mapper_new(void);
 void ref_mapper_free(void *m);
 

@@ -1,0 +1,149 @@
+"""Parity cases shared by the lanesim (CPU emulator, container) and gpu (real MI355X) test modules: the HIP path
+-- through the C ABI -- against the oracle restatement and the committed reference goldens."""
+import numpy as np
+
+from tests.helpers import assert_hits_equal, oracle_hits, to_oracle_params
+from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
+from uncalled_amd import capi
+
+_cache = {}
+
+
+def _index(lib, example):
+    key = (id(lib), str(example["prefix"]))
+    if key not in _cache:
+        _cache[key] = capi.Index(example["prefix"], lib=lib)
+    return _cache[key]
+
+
+def case_index_tables(lib, oracle_lib, example, goldens):
+    dev_index = _index(lib, example)
+    oix = oracle_lib.Index(example["prefix"])
+    assert np.array_equal(dev_index.kmer_ranges(), oix.kmer_ranges())
+    assert np.array_equal(dev_index.thresholds(), oix.thresholds())
+    for a, b in zip(dev_index.model_tables(), oracle_lib.model_tables()):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def case_fm_primitives(lib, oracle_lib, example, goldens):
+    dev_index = _index(lib, example)
+    oix = oracle_lib.Index(example["prefix"])
+    rng = np.random.default_rng(1)
+    kr = oix.kmer_ranges()
+    s, e, b = [], [], []
+    for k in rng.integers(0, 1024, 300):
+        if kr[k, 0] <= kr[k, 1]:
+            lo = int(rng.integers(kr[k, 0], kr[k, 1] + 1))
+            hi = int(rng.integers(lo, kr[k, 1] + 1))
+            s.append(lo); e.append(hi); b.append(int(rng.integers(0, 4)))
+    # edge rows: first row, the sentinel row's neighbours, last row
+    for row in (1, 2, int(oix.size) - 1, int(oix.size)):
+        s.append(row); e.append(row); b.append(int(rng.integers(0, 4)))
+    os_, oe = dev_index.get_neighbor(s, e, b)
+    for x, y, z, p, q in zip(s, e, b, os_, oe):
+        assert oix.get_neighbor(x, y, z) == (int(p), int(q))
+    rows = np.concatenate((rng.integers(0, oix.size + 1, 400), [0, 1, oix.size]))
+    assert np.array_equal(dev_index.sa(rows), np.array([oix.sa(int(r)) for r in rows], dtype=np.uint64))
+
+
+def case_events_and_normaliser(lib, oracle_lib, example, goldens):
+    dev_index = _index(lib, example)
+    m = capi.Mapper(dev_index, n_slots=1)
+    raw = example["signal"]
+    off = np.array([0, raw.size], dtype=np.uint64)
+    cal = capi.make_calib(1, example["range"], example["offset"], example["digitisation"])
+    means, moff, info = m.detect_events(raw, off, cal)
+    assert np.array_equal(means, goldens["ex_events"]["mean"])          # north star: 1e-5; achieved: bit-exact
+    assert info["total_events"][0] == int(goldens["ex_total_events"])
+    assert np.float32(info["len_sum"][0] / info["total_events"][0]) == goldens["ex_mean_event_len"]
+    assert info["scale"][0] == goldens["ex_scale"] and info["shift"][0] == goldens["ex_shift"]
+    lv = goldens["ex_levels"]
+    assert np.array_equal(dev_index.match_probs(lv[:64]), goldens["ex_probs"])
+
+
+def case_events_edge_cases(lib, oracle_lib, example, goldens):
+    """empty read, reads shorter than the detector windows, a flat (zero-variance) read, negative samples."""
+    dev_index = _index(lib, example)
+    po = oracle_lib
+    rng = np.random.default_rng(5)
+    reads = [np.zeros(0, np.int16), np.array([500], np.int16), rng.integers(300, 700, 12).astype(np.int16),
+             np.full(400, 512, np.int16), rng.integers(-200, 900, 700).astype(np.int16),
+             np.repeat(rng.integers(350, 650, 60), 9).astype(np.int16)]
+    raw = np.concatenate(reads)
+    off = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint64)
+    cal = capi.make_calib(len(reads), CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    m = capi.Mapper(dev_index, n_slots=1)
+    means, moff, info = m.detect_events(raw, off, cal)
+    for i, r in enumerate(reads):
+        ev, mel, tot = po.detect_events(po.calibrate(r, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION))
+        assert info["n_events"][i] == len(ev) and info["total_events"][i] == tot, i
+        assert np.array_equal(means[int(moff[i]):int(moff[i + 1])], ev["mean"]), i
+        if len(ev):
+            lv, sc, sh = po.normalize(ev["mean"])
+            assert (np.float32(sc) == info["scale"][i] or (np.isnan(sc) and np.isnan(info["scale"][i]))), i
+            assert (np.float32(sh) == info["shift"][i] or (np.isnan(sh) and np.isnan(info["shift"][i]))), i
+
+
+def case_example_read_full_path(lib, oracle_lib, example, goldens):
+    dev_index = _index(lib, example)
+    m = capi.Mapper(dev_index, n_slots=2)
+    raw = example["signal"]
+    off = np.array([0, raw.size], dtype=np.uint64)
+    cal = capi.make_calib(1, example["range"], example["offset"], example["digitisation"])
+    hits = m.map_batch(raw, off, cal)
+    oix = oracle_lib.Index(example["prefix"])
+    assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "example")
+    assert capi.hit_paf_cols(hits[0], dev_index.seq_names()) == \
+        (106, 73, 106, "-", "Escherichia_coli_chromosome:2400000-2410000", 10000, 6938, 6976, 38, 39, 255)
+
+
+def case_synthetic_batch(lib, oracle_lib, example, goldens, max_paths, n_reads):
+    """Batch through the persistent read queue (more reads than slots); small max_paths exercises the buffer
+    cut-off semantics of mapper.cpp:480-482,507-509,521-523,544,576,605-624 incl. stale sources_added_ flags."""
+    dev_index = _index(lib, example)
+    p = capi.default_params(dev_index.L)
+    p.max_paths = max_paths
+    m = capi.Mapper(dev_index, params=p, n_slots=3)
+    off_all = goldens["sim_offsets"]
+    raw = goldens["sim_signal"][:int(off_all[n_reads])]
+    off = off_all[:n_reads + 1].copy()
+    cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    hits = m.map_batch(raw, off, cal)
+    oix = oracle_lib.Index(example["prefix"])
+    want = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True)
+    assert_hits_equal(hits, want, f"max_paths={max_paths}")
+    if max_paths == 10000:
+        f = {str(n): j for j, n in enumerate(goldens["hit_fields"])}
+        for i in range(n_reads):   # and against the reference's own answers
+            for name in ("mapped", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_lf"):
+                assert int(hits[i][name]) == int(goldens["sim_hits"][i][f[name]]), (i, name)
+
+
+def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens):
+    """Path buffer (order, ranges, k-mers, prob-sum windows, flags) and the seed-cluster set after every map_next."""
+    dev_index = _index(lib, example)
+    raw = example["signal"][:6000]
+    cal = capi.make_calib(1, example["range"], example["offset"], example["digitisation"])
+    m = capi.Mapper(dev_index, n_slots=1)
+    oix = oracle_lib.Index(example["prefix"])
+    om = oracle_lib.Mapper(oix)
+    sig = oracle_lib.calibrate(raw, example["range"], example["offset"], example["digitisation"])
+    steps = 0
+    for (dd, dpaths, dclus, dmm, dls, dnl), (od, oe, opaths, oclus, omm, ols, onl) in zip(m.trace(raw, cal), om.trace(sig)):
+        assert dd == od, steps
+        v = opaths["length"] > 0          # the device list holds only valid parents, in the same order
+        ov = opaths[v]
+        assert len(dpaths) == len(ov), steps
+        for f in ("fm_start", "fm_end", "kmer", "length", "event_moves", "seed_prob", "consec_stays", "sa_checked"):
+            assert np.array_equal(dpaths[f], ov[f]), (steps, f)
+        for j in range(len(ov)):
+            L = int(ov["length"][j])
+            assert np.array_equal(dpaths["prob_sums"][j][:L + 1], ov["prob_sums"][j][:L + 1]), (steps, j)
+        assert np.array_equal(dclus, oclus), steps
+        assert dls == ols and dnl == onl, steps
+        if omm["total_len"]:
+            assert dmm == omm, steps
+        steps += 1
+    assert steps > 100
+    dh, oh = m.trace_finish(), om.trace_finish()
+    assert_hits_equal([dh], [oh], "trace")

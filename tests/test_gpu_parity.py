@@ -1,0 +1,103 @@
+"""`-m gpu`: the parity tests proper.  The gfx950 library, called through the C ABI on a real MI355X, against the
+oracle restatement on the same seeded inputs, against the committed reference goldens, and -- at the bench's
+index scale -- on a synthetic E. coli-sized reference built on the fly."""
+import time
+
+import numpy as np
+import pytest
+
+from tests import parity_cases as pc
+from tests.helpers import assert_hits_equal, oracle_hits
+from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE, simulate_reads
+from uncalled_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_index_tables(hip_lib, oracle_lib, example, goldens):
+    pc.case_index_tables(hip_lib, oracle_lib, example, goldens)
+
+
+def test_fm_primitives(hip_lib, oracle_lib, example, goldens):
+    pc.case_fm_primitives(hip_lib, oracle_lib, example, goldens)
+
+
+def test_events_and_normaliser(hip_lib, oracle_lib, example, goldens):
+    pc.case_events_and_normaliser(hip_lib, oracle_lib, example, goldens)
+
+
+def test_events_edge_cases(hip_lib, oracle_lib, example, goldens):
+    pc.case_events_edge_cases(hip_lib, oracle_lib, example, goldens)
+
+
+def test_example_read_full_path(hip_lib, oracle_lib, example, goldens):
+    pc.case_example_read_full_path(hip_lib, oracle_lib, example, goldens)
+
+
+@pytest.mark.parametrize("max_paths,n_reads", [(10000, 48), (300, 24), (97, 12)])
+def test_synthetic_batch(hip_lib, oracle_lib, example, goldens, max_paths, n_reads):
+    pc.case_synthetic_batch(hip_lib, oracle_lib, example, goldens, max_paths, n_reads)
+
+
+def test_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens):
+    pc.case_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
+
+
+@pytest.fixture(scope="module")
+def ecoli(tmp_path_factory):
+    """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (tools/build_index.py)."""
+    from tools.build_index import build_from_codes, synthetic_genome
+    d = tmp_path_factory.mktemp("ecoli")
+    names, lens, codes = synthetic_genome(1, 4641652, seed=1)
+    prefix = d / "ecoli_syn"
+    build_from_codes(prefix, names, [""] * len(names), lens, codes)
+    return dict(prefix=prefix, codes=codes, lens=lens)
+
+
+def test_ecoli_scale_batch(hip_lib, oracle_lib, ecoli):
+    """192 full-length (3600-base, about 32 k-sample) reads, mapped + off-target, against the oracle: PAF,
+    winning cluster, event counts and work counters bit-exact."""
+    n = 192
+    sim = simulate_reads(ecoli["codes"], ecoli["lens"], n, seed=42)
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    ix = capi.Index(ecoli["prefix"], lib=hip_lib)
+    m = capi.Mapper(ix)
+    t0 = time.time()
+    hits = m.map_batch(sim["signal"], sim["offsets"], cal)
+    t_gpu = time.time() - t0
+    oix = oracle_lib.Index(ecoli["prefix"])
+    t0 = time.time()
+    want = oracle_hits(oix, sim["signal"], sim["offsets"], cal)
+    t_cpu = time.time() - t0
+    assert_hits_equal(hits, want, "ecoli")
+    mapped = int(hits["mapped"].sum())
+    assert mapped >= 0.7 * n
+    ok = 0
+    for i in np.flatnonzero(hits["mapped"]):
+        if sim["contig"][i] >= 0 and bool(hits["fwd"][i]) == (sim["strand"][i] == 0) and \
+                sim["pos"][i] - 100 <= hits["rf_st"][i] <= sim["pos"][i] + 3700:
+            ok += 1
+    assert ok >= 0.95 * mapped
+    print(f"ecoli batch: {n} reads, {mapped} mapped, gpu {t_gpu:.2f}s, oracle(1 thread) {t_cpu:.2f}s")
+
+
+def test_batch_order_and_slot_independence(hip_lib, oracle_lib, example, goldens):
+    """A read's result does not depend on which slot / in which order it is processed (no state leaks across
+    reads): map the golden batch reversed and with a single slot."""
+    n = 32
+    off = goldens["sim_offsets"]
+    reads = [goldens["sim_signal"][int(off[i]):int(off[i + 1])] for i in range(n)]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    ix = capi.Index(example["prefix"], lib=hip_lib)
+
+    def run(order, n_slots):
+        raw = np.concatenate([reads[i] for i in order])
+        o = np.concatenate(([0], np.cumsum([len(reads[i]) for i in order]))).astype(np.uint64)
+        h = capi.Mapper(ix, n_slots=n_slots).map_batch(raw, o, cal)
+        out = np.zeros_like(h)
+        out[list(order)] = h
+        return out
+    a = run(range(n), 0)
+    b = run(range(n - 1, -1, -1), 1)
+    for f in ("mapped", "rd_st", "rd_en", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_sa", "n_lf"):
+        assert np.array_equal(a[f], b[f]), f

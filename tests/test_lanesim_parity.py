@@ -1,0 +1,37 @@
+"""The product's HIP kernel sources, compiled unmodified against the lanesim CPU SIMT emulator (tests/lanesim),
+checked against the oracle.  Logic tests for the GPU-less build container; the same cases run on a real MI355X
+through the gfx950 library in test_gpu_parity.py."""
+import pytest
+
+from tests import parity_cases as pc
+
+pytestmark = pytest.mark.lanesim
+
+
+def test_index_tables(sim_lib, oracle_lib, example, goldens):
+    pc.case_index_tables(sim_lib, oracle_lib, example, goldens)
+
+
+def test_fm_primitives(sim_lib, oracle_lib, example, goldens):
+    pc.case_fm_primitives(sim_lib, oracle_lib, example, goldens)
+
+
+def test_events_and_normaliser(sim_lib, oracle_lib, example, goldens):
+    pc.case_events_and_normaliser(sim_lib, oracle_lib, example, goldens)
+
+
+def test_events_edge_cases(sim_lib, oracle_lib, example, goldens):
+    pc.case_events_edge_cases(sim_lib, oracle_lib, example, goldens)
+
+
+def test_example_read_full_path(sim_lib, oracle_lib, example, goldens):
+    pc.case_example_read_full_path(sim_lib, oracle_lib, example, goldens)
+
+
+@pytest.mark.parametrize("max_paths,n_reads", [(10000, 10), (300, 8), (97, 6)])
+def test_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads):
+    pc.case_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads)
+
+
+def test_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens):
+    pc.case_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)

@@ -1,0 +1,163 @@
+"""CPU tests of the test oracle itself: the plain-C restatement (oracle/unc_oracle.c) is pinned against
+(a) the committed goldens generated from the reference's own object code (tests/golden/make_goldens.py), and
+(b) that object code live, wherever /root/reference exists (this container)."""
+import numpy as np
+import pytest
+
+from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
+
+
+def _gold_hit(goldens, row):
+    return dict(zip([str(x) for x in goldens["hit_fields"]], [int(v) for v in row]))
+
+
+def test_calibration_and_events_match_golden(oracle_lib, example, goldens):
+    po = oracle_lib
+    sig = po.calibrate(example["signal"], example["range"], example["offset"], example["digitisation"])
+    assert np.array_equal(sig, goldens["ex_calibrated"])
+    ev, mel, tot = po.detect_events(sig)
+    g = goldens["ex_events"]
+    assert len(ev) == len(g) == 6171
+    for f in ("mean", "stdv", "start", "length"):
+        assert np.array_equal(ev[f], g[f]), f
+    assert np.float32(mel) == goldens["ex_mean_event_len"] and tot == int(goldens["ex_total_events"])
+
+
+def test_model_normaliser_matchprob_match_golden(oracle_lib, goldens):
+    po = oracle_lib
+    a, b, c, mm, ms = po.model_tables()
+    assert np.array_equal(a, goldens["model_means"]) and np.array_equal(b, goldens["model_vars_x2"])
+    assert np.array_equal(c, goldens["model_lognorm"])
+    assert np.float32(mm) == goldens["model_mean"] and np.float32(ms) == goldens["model_stdv"]
+    lv, sc, sh = po.normalize(goldens["ex_events"]["mean"])
+    assert np.array_equal(lv, goldens["ex_levels"])      # north star: within 1e-5; achieved: bit-exact
+    assert np.float32(sc) == goldens["ex_scale"] and np.float32(sh) == goldens["ex_shift"]
+    for i in range(64):
+        assert np.array_equal(po.match_probs(lv[i]), goldens["ex_probs"][i])
+
+
+def test_index_tables_match_golden(oracle_lib, example, goldens):
+    ix = oracle_lib.Index(example["prefix"])
+    assert np.array_equal(ix.kmer_ranges(), goldens["kmer_ranges"])
+    assert np.array_equal(ix.thresholds(), goldens["thresholds"])
+    # the .uncl line of the example index: bins 63..58 then copies (mapper.cpp:146-156)
+    thr = ix.thresholds()
+    assert thr[63] == np.float32(-10.07) and thr[57] == thr[0] == np.float32(-2.2677272727272726)
+
+
+def test_fm_index_against_naive_suffix_array(oracle_lib, example):
+    """minibwa pinned on the reference's prebuilt index: SA(k) for every row equals the naive suffix array
+    of fwd+revcomp decoded from .pac; block counts reproduce L2."""
+    ix = oracle_lib.Index(example["prefix"])
+    pac = np.fromfile(str(example["prefix"]) + ".pac", dtype=np.uint8)
+    n = 10000
+    codes = np.array([(pac[i >> 2] >> ((~i & 3) << 1)) & 3 for i in range(n)], dtype=np.uint8)
+    t = np.concatenate((codes, 3 - codes[::-1]))
+    assert ix.size == 2 * n
+    s = bytes(t + 1)   # 1..4 so that the empty suffix sorts first
+    sa = sorted(range(2 * n + 1), key=lambda i: s[i:])
+    got = [ix.sa(k) for k in range(1, 2 * n + 1)]
+    assert got == sa[1:]
+    # backward search of a known 12-mer lands on rows whose SA values are its occurrences
+    q = t[5000:5012]
+    lo, hi = 0, 2 * n   # whole matrix: rows of suffixes starting with q[-1] ...
+    # build the range base by base the way BwaIndex does (bwa_index.hpp:124-132, 158-174)
+    counts = np.bincount(t, minlength=4)
+    L2 = np.concatenate(([0], np.cumsum(counts)))
+    lo, hi = int(L2[q[-1]]), int(L2[q[-1] + 1])
+    for b in q[-2::-1]:
+        lo, hi = ix.get_neighbor(lo, hi, int(b))
+    occ = sorted(ix.sa(k) for k in range(lo, hi + 1))
+    want = [i for i in range(2 * n - 11) if np.array_equal(t[i:i + 12], q)]
+    assert set(want) <= set(occ) and len(occ) - len(want) <= 1   # get_base_range starts one row low (SURVEY a-8)
+
+
+def test_example_read_paf_matches_golden(oracle_lib, example, goldens):
+    po = oracle_lib
+    ix = po.Index(example["prefix"])
+    h = po.Mapper(ix).map_read(goldens["ex_calibrated"])
+    g = _gold_hit(goldens, goldens["ex_hit"])
+    for f, v in g.items():
+        assert int(h[f]) == v, f
+    # the survey's probe of the current reference: 106 73 106 - ... 10000 6938 6976 38 39 255
+    assert po.hit_paf_cols(h, ix.ref_names()) == (106, 73, 106, "-", "Escherichia_coli_chromosome:2400000-2410000",
+                                                   10000, 6938, 6976, 38, 39, 255)
+
+
+def test_synthetic_reads_match_golden(oracle_lib, example, goldens):
+    po = oracle_lib
+    ix = po.Index(example["prefix"])
+    om = po.Mapper(ix)
+    off = goldens["sim_offsets"]
+    for i in range(len(off) - 1):
+        sig = po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+        h = om.map_read(sig)
+        g = _gold_hit(goldens, goldens["sim_hits"][i])
+        for f, v in g.items():
+            assert int(h[f]) == v, (i, f)
+        assert np.float32(h["mean_event_len"]) == goldens["sim_mel"][i]
+    assert int(goldens["sim_hits"][:, 0].sum()) >= 40   # the simulator produces mappable reads
+
+
+def test_simulated_reads_map_to_their_origin(goldens):
+    """Sanity of the data tooling: mapped reads land on the simulated strand and locus."""
+    hits = goldens["sim_hits"]
+    f = {str(n): j for j, n in enumerate(goldens["hit_fields"])}
+    ok = 0
+    for i, row in enumerate(hits):
+        if not row[f["mapped"]] or goldens["sim_contig"][i] < 0:
+            continue
+        pos, strand = int(goldens["sim_pos"][i]), int(goldens["sim_strand"][i])
+        assert bool(row[f["fwd"]]) == (strand == 0)
+        assert pos - 50 <= row[f["rf_st"]] <= pos + 1500 + 50
+        ok += 1
+    assert ok >= 35
+
+
+@pytest.mark.parametrize("max_paths", [10000, 300])
+def test_oracle_equals_live_reference(oracle_lib, ref_lib, example, goldens, max_paths):
+    """Live comparison with the reference's object code, incl. the max_paths cut-off logic (mapper.cpp:480,507,521)
+    exercised with a small buffer.  Skipped where /root/reference is absent."""
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    pr.set_max_paths(max_paths)
+    p = po.default_params()
+    p.max_paths = max_paths
+    ix = po.Index(example["prefix"])
+    om, rm = po.Mapper(ix, p), pr.Mapper()
+    off = goldens["sim_offsets"]
+    sigs = [goldens["ex_calibrated"]] + [
+        po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+        for i in range(16)]
+    for i, sig in enumerate(sigs):
+        h, r = om.map_read(sig), rm.map_read(sig)
+        assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), i
+        assert (int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (r.event_i, r.n_nbr, r.n_sa, r.n_lf), i
+    pr.set_max_paths(10000)
+
+
+def test_oracle_trace_equals_live_reference(oracle_lib, ref_lib, example, goldens):
+    """Per-event path buffers and seed clusters agree with the reference after every map_next."""
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    ix = po.Index(example["prefix"])
+    om, rm = po.Mapper(ix), pr.Mapper()
+    sig = goldens["ex_calibrated"]
+    steps = 0
+    for (od, oe, opaths, oclus, omm, ols, onl), (rd, re_, rpaths, rclus, rmm, rls, rnl) in zip(om.trace(sig), rm.trace(sig)):
+        assert od == rd and oe == re_
+        assert len(opaths) == len(rpaths)
+        for f in ("fm_start", "fm_end", "kmer", "length"):
+            assert np.array_equal(opaths[f], rpaths[f]), (steps, f)
+        v = opaths["length"] > 0
+        for f in ("event_moves", "seed_prob", "consec_stays", "sa_checked"):
+            assert np.array_equal(opaths[f][v], rpaths[f][v]), (steps, f)
+        for j in np.flatnonzero(v)[:50]:
+            L = int(opaths["length"][j])
+            assert np.array_equal(opaths["prob_sums"][j][:L + 1], rpaths["prob_sums"][j][:L + 1])
+        assert np.array_equal(oclus, rclus), steps
+        assert ols == rls and onl == rnl
+        if omm["total_len"] or rmm["total_len"]:
+            assert omm == rmm
+        steps += 1
+    assert steps == 178

@@ -1,0 +1,281 @@
+"""ctypes binding of the C ABI in include/uncalled_hip.h.
+
+`load()` opens uncalled_amd/libuncalled_hip.so -- the gfx950 code object built by
+`__graft_entry__.build()` -- and raises if it is missing: there is no CPU mapping path behind this
+package.  (tests/ may pass an explicit library path to run the same kernel sources under the
+lanesim CPU emulator; the package itself never does.)
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+DEFAULT_LIB = HERE / "libuncalled_hip.so"
+
+UNC_OK = 0
+UNC_ERR_OVERFLOW = -5
+
+
+class Params(C.Structure):
+    """unc_params_t: Mapper::PRMS + EventDetector/SeedTracker/ReadBuffer params (reference defaults)."""
+    _fields_ = [("seed_len", C.c_uint32), ("min_rep_len", C.c_uint32), ("max_rep_copy", C.c_uint32),
+                ("max_paths", C.c_uint32), ("max_consec_stay", C.c_uint32), ("max_events", C.c_uint32),
+                ("max_stay_frac", C.c_float), ("min_seed_prob", C.c_float),
+                ("window_length1", C.c_uint32), ("window_length2", C.c_uint32),
+                ("threshold1", C.c_float), ("threshold2", C.c_float), ("peak_height", C.c_float),
+                ("min_mean", C.c_float), ("max_mean", C.c_float),
+                ("min_map_len", C.c_uint32), ("min_mean_conf", C.c_float), ("min_top_conf", C.c_float),
+                ("bp_per_sec", C.c_float), ("sample_rate", C.c_float), ("chunk_time", C.c_float),
+                ("max_chunks", C.c_uint32)]
+
+
+class MapperOpts(C.Structure):
+    _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+CALIB = np.dtype([("range", "<f4"), ("offset", "<f4"), ("digitisation", "<f4")])
+HIT = np.dtype([("mapped", "<i4"), ("fwd", "<i4"), ("rid", "<i4"), ("status", "<u4"),
+                ("rd_st", "<u8"), ("rd_en", "<u8"), ("rd_len", "<u8"),
+                ("rf_st", "<u8"), ("rf_en", "<u8"), ("rf_len", "<u8"),
+                ("matches", "<u4"), ("n_events", "<u4"), ("event_i", "<u4"), ("mean_event_len", "<f4"),
+                ("n_nbr", "<u8"), ("n_sa", "<u8"), ("n_lf", "<u8"),
+                ("cl_ref_st", "<u8"), ("cl_ref_en_start", "<u8"), ("cl_ref_en_end", "<u8"),
+                ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("pad", "<u4")])
+EVT_INFO = np.dtype([("n_events", "<u4"), ("total_events", "<u4"), ("len_sum", "<f4"), ("scale", "<f4"),
+                     ("shift", "<f4"), ("pad", "<u4")])
+PATH = np.dtype([("fm_start", "<u8"), ("fm_end", "<u8"), ("event_moves", "<u4"), ("seed_prob", "<f4"),
+                 ("kmer", "<u2"), ("length", "u1"), ("consec_stays", "u1"), ("sa_checked", "u1"),
+                 ("pad", "u1", 3), ("prob_sums", "<f4", 23)], align=True)
+CLUSTER = np.dtype([("ref_st", "<u8"), ("ref_en_start", "<u8"), ("ref_en_end", "<u8"),
+                    ("evt_st", "<u4"), ("evt_en", "<u4"), ("total_len", "<u4"), ("pad", "<u4")])
+
+_libs = {}
+
+
+class UncalledHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Open the shared library (default: the in-tree gfx950 build) and declare its prototypes."""
+    path = Path(path) if path else DEFAULT_LIB
+    key = str(path)
+    if key in _libs:
+        return _libs[key]
+    if not path.exists():
+        raise UncalledHipError(
+            f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "uncalled_amd has no CPU fallback.")
+    L = C.CDLL(str(path))
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.unc_last_error.restype = C.c_char_p
+    L.unc_version.restype = C.c_char_p
+    L.unc_params_default.argtypes = [C.POINTER(Params)]
+    L.unc_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.unc_index_free.argtypes = [vp]
+    L.unc_index_size.argtypes = [vp]; L.unc_index_size.restype = u64
+    L.unc_index_n_seqs.argtypes = [vp]; L.unc_index_n_seqs.restype = i32
+    L.unc_index_seq_name.argtypes = [vp, i32]; L.unc_index_seq_name.restype = C.c_char_p
+    L.unc_index_seq_len.argtypes = [vp, i32]; L.unc_index_seq_len.restype = u64
+    L.unc_index_translate_loc.argtypes = [vp, u64, C.POINTER(i32), C.POINTER(u64)]; L.unc_index_translate_loc.restype = u64
+    L.unc_index_device_bytes.argtypes = [vp]; L.unc_index_device_bytes.restype = u64
+    L.unc_index_kmer_ranges.argtypes = [vp, vp]
+    L.unc_index_thresholds.argtypes = [vp, vp]
+    L.unc_index_model_tables.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.unc_fm_get_neighbor.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    L.unc_fm_sa.argtypes = [vp, u32, vp, vp]
+    L.unc_match_probs.argtypes = [vp, u32, vp, vp]
+    L.unc_mapper_create.argtypes = [vp, C.POINTER(Params), C.POINTER(MapperOpts), C.POINTER(vp)]
+    L.unc_mapper_free.argtypes = [vp]
+    L.unc_mapper_device_bytes.argtypes = [vp]; L.unc_mapper_device_bytes.restype = u64
+    L.unc_map_batch.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp, vp]
+    L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.unc_detect_events.argtypes = [vp, u32, vp, vp, vp, vp, u64, vp, vp]
+    L.unc_trace_begin.argtypes = [vp, vp, u32, vp]
+    L.unc_trace_step.argtypes = [vp, u32, C.POINTER(C.c_int)]
+    L.unc_trace_paths.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.unc_trace_clusters.argtypes = [vp, vp, u32, C.POINTER(u32), vp, C.POINTER(C.c_float), C.POINTER(u32)]
+    L.unc_trace_finish.argtypes = [vp, vp]
+    _libs[key] = L
+    return L
+
+
+def _check(L, rc, allow=()):
+    if rc != UNC_OK and rc not in allow:
+        raise UncalledHipError(f"uncalled_hip error {rc}: {L.unc_last_error().decode()}")
+    return rc
+
+
+def default_params(lib=None):
+    p = Params()
+    (lib or load()).unc_params_default(C.byref(p))
+    return p
+
+
+class Index:
+    """Device-resident FM index + thresholds + pore model (Mapper::load_static, mapper.cpp:109-159)."""
+
+    def __init__(self, prefix, preset="default", device=0, lib=None):
+        self.L = lib or load()
+        h = C.c_void_p()
+        _check(self.L, self.L.unc_index_load(str(prefix).encode(), preset.encode(), device, C.byref(h)))
+        self.h = h
+        self.size = self.L.unc_index_size(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.unc_index_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def seq_names(self):
+        return [self.L.unc_index_seq_name(self.h, i).decode() for i in range(self.L.unc_index_n_seqs(self.h))]
+
+    def seq_len(self, rid):
+        return self.L.unc_index_seq_len(self.h, rid)
+
+    def device_bytes(self):
+        return self.L.unc_index_device_bytes(self.h)
+
+    def kmer_ranges(self):
+        out = np.empty((1024, 2), dtype=np.uint64)
+        self.L.unc_index_kmer_ranges(self.h, out.ctypes.data)
+        return out
+
+    def thresholds(self):
+        out = np.empty(64, dtype=np.float32)
+        self.L.unc_index_thresholds(self.h, out.ctypes.data)
+        return out
+
+    def model_tables(self):
+        a, b, c = (np.empty(1024, dtype=np.float32) for _ in range(3))
+        mm, ms = C.c_float(), C.c_float()
+        self.L.unc_index_model_tables(self.h, a.ctypes.data, b.ctypes.data, c.ctypes.data, C.byref(mm), C.byref(ms))
+        return a, b, c, mm.value, ms.value
+
+    def get_neighbor(self, starts, ends, bases):
+        s = np.ascontiguousarray(starts, dtype=np.uint64)
+        e = np.ascontiguousarray(ends, dtype=np.uint64)
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        os_, oe = np.empty_like(s), np.empty_like(s)
+        _check(self.L, self.L.unc_fm_get_neighbor(self.h, s.size, s.ctypes.data, e.ctypes.data, b.ctypes.data,
+                                                  os_.ctypes.data, oe.ctypes.data))
+        return os_, oe
+
+    def sa(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.empty_like(r)
+        _check(self.L, self.L.unc_fm_sa(self.h, r.size, r.ctypes.data, out.ctypes.data))
+        return out
+
+    def match_probs(self, levels):
+        lv = np.ascontiguousarray(levels, dtype=np.float32)
+        out = np.empty((lv.size, 1024), dtype=np.float32)
+        _check(self.L, self.L.unc_match_probs(self.h, lv.size, lv.ctypes.data, out.ctypes.data))
+        return out
+
+
+def make_calib(n, rng, offset, digitisation):
+    c = np.empty(n, dtype=CALIB)
+    c["range"], c["offset"], c["digitisation"] = rng, offset, digitisation
+    return c
+
+
+def hit_paf_cols(h, names):
+    """PAF columns 2-12 (Paf::print_paf, read_buffer.cpp:92-118) of one HIT record."""
+    if not h["mapped"]:
+        return (int(h["rd_len"]), "*")
+    name = names[int(h["rid"])] if h["rid"] >= 0 else ""
+    return (int(h["rd_len"]), int(h["rd_st"]), int(h["rd_en"]), "+" if h["fwd"] else "-", name,
+            int(h["rf_len"]), int(h["rf_st"]), int(h["rf_en"]), int(h["matches"]),
+            int(h["rf_en"] - h["rf_st"] + 1), 255)
+
+
+class Mapper:
+    """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
+
+    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0):
+        self.index = index
+        self.L = index.L
+        self.params = params or default_params(self.L)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, 0)
+        h = C.c_void_p()
+        _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.unc_mapper_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def device_bytes(self):
+        return self.L.unc_mapper_device_bytes(self.h)
+
+    def map_batch(self, raw_i16, offsets_u64, calib, allow_overflow=False):
+        """raw: host int16 array (all reads concatenated); returns HIT[n_reads]."""
+        raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
+        off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        cal = np.ascontiguousarray(calib, dtype=CALIB)
+        n = off.size - 1
+        hits = np.zeros(n, dtype=HIT)
+        _check(self.L, self.L.unc_map_batch(self.h, n, raw.ctypes.data, off.ctypes.data, cal.ctypes.data, 0, None,
+                                            hits.ctypes.data), allow=(UNC_ERR_OVERFLOW,) if allow_overflow else ())
+        return hits
+
+    def map_batch_device(self, raw_ptr, offsets_u64, calib, stream=None, allow_overflow=False):
+        """raw_ptr: integer device address of the int16 samples already resident in HBM."""
+        off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        cal = np.ascontiguousarray(calib, dtype=CALIB)
+        n = off.size - 1
+        hits = np.zeros(n, dtype=HIT)
+        _check(self.L, self.L.unc_map_batch(self.h, n, C.c_void_p(raw_ptr), off.ctypes.data, cal.ctypes.data, 1,
+                                            C.c_void_p(stream or 0), hits.ctypes.data),
+               allow=(UNC_ERR_OVERFLOW,) if allow_overflow else ())
+        return hits
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        self.L.unc_mapper_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def detect_events(self, raw_i16, offsets_u64, calib):
+        raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
+        off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        cal = np.ascontiguousarray(calib, dtype=CALIB)
+        n = off.size - 1
+        means = np.empty(int(off[-1] - off[0]) + 16, dtype=np.float32)
+        moff = np.empty(n + 1, dtype=np.uint64)
+        info = np.zeros(n, dtype=EVT_INFO)
+        _check(self.L, self.L.unc_detect_events(self.h, n, raw.ctypes.data, off.ctypes.data, cal.ctypes.data,
+                                                means.ctypes.data, means.size, moff.ctypes.data, info.ctypes.data))
+        return means[:int(moff[-1])], moff, info
+
+    def trace(self, raw_i16, calib1, events_per_step=1, max_clusters=1 << 15):
+        """Generator over Mapper::map_next steps of one read: (done, paths, clusters, max_map, len_sum, n_lens)."""
+        raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
+        cal = np.ascontiguousarray(calib1, dtype=CALIB)
+        _check(self.L, self.L.unc_trace_begin(self.h, raw.ctypes.data, raw.size, cal.ctypes.data))
+        mp = self.params.max_paths
+        paths = np.zeros(mp, dtype=PATH)
+        clus = np.zeros(max_clusters, dtype=CLUSTER)
+        mm = np.zeros(1, dtype=CLUSTER)
+        while True:
+            done = C.c_int()
+            _check(self.L, self.L.unc_trace_step(self.h, events_per_step, C.byref(done)))
+            n, nc, nl, ls = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_float()
+            _check(self.L, self.L.unc_trace_paths(self.h, paths.ctypes.data, mp, C.byref(n)))
+            _check(self.L, self.L.unc_trace_clusters(self.h, clus.ctypes.data, max_clusters, C.byref(nc), mm.ctypes.data,
+                                                     C.byref(ls), C.byref(nl)))
+            yield bool(done.value), paths[:n.value].copy(), clus[:nc.value].copy(), mm[0].copy(), ls.value, nl.value
+            if done.value:
+                break
+
+    def trace_finish(self):
+        hit = np.zeros(1, dtype=HIT)
+        _check(self.L, self.L.unc_trace_finish(self.h, hit.ctypes.data))
+        return hit[0]

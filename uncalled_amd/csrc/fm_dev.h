@@ -1,0 +1,84 @@
+// Device FM-index arithmetic over the BWA on-disk block layout:
+// one 64-byte block per 128 BWT symbols = 4 x u64 counts-before-block (A,C,G,T) + 8 x u32 of
+// 2-bit symbols, symbol j of a word at bits (~j & 15) << 1.  Replaces the libbwa calls behind
+// BwaIndex::get_neighbor (bwa_index.hpp:158-162 -> bwt_2occ) and BwaIndex::sa (:176-178 -> bwt_sa).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "unc_dev_types.h"
+
+namespace unc {
+
+// occurrences of base c among the 32 symbols of y
+__device__ __forceinline__ uint32_t occ32(uint64_t y, uint32_t c) {
+    uint64_t hi = (c & 2) ? y : ~y, lo = (c & 1) ? y : ~y;
+    return (uint32_t)__popcll((hi >> 1) & lo & 0x5555555555555555ull);
+}
+
+struct FmBlock { uint4 q0, q1, q2, q3; };  // counts A,C | counts G,T | symbols 0..63 | symbols 64..127
+
+__device__ __forceinline__ FmBlock fm_load_block(const DevIndex &ix, uint64_t kk) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.bwt + ((kk >> 7) << 4));
+    FmBlock b;
+    b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3];
+    return b;
+}
+
+__device__ __forceinline__ uint64_t fm_block_count(const FmBlock &b, uint32_t c) {
+    uint64_t cA = ((uint64_t)b.q0.y << 32) | b.q0.x, cC = ((uint64_t)b.q0.w << 32) | b.q0.z;
+    uint64_t cG = ((uint64_t)b.q1.y << 32) | b.q1.x, cT = ((uint64_t)b.q1.w << 32) | b.q1.z;
+    return c == 0 ? cA : c == 1 ? cC : c == 2 ? cG : cT;
+}
+
+// number of c among block symbols [0 .. (kk & 127)] (inclusive), kk already sentinel-adjusted
+__device__ __forceinline__ uint32_t fm_block_rank(const FmBlock &b, uint64_t kk, uint32_t c) {
+    // 32-symbol words, big-endian pairs of u32 (p[0] << 32 | p[1])
+    uint64_t w0 = ((uint64_t)b.q2.x << 32) | b.q2.y, w1 = ((uint64_t)b.q2.z << 32) | b.q2.w;
+    uint64_t w2 = ((uint64_t)b.q3.x << 32) | b.q3.y, w3 = ((uint64_t)b.q3.z << 32) | b.q3.w;
+    uint32_t full = (uint32_t)(kk & 127) >> 5;                     // whole words before the last one
+    uint64_t tailmask = ~((1ull << ((~kk & 31) << 1)) - 1ull);     // keep symbols 0..(kk&31) of the last word
+    uint32_t n = 0;
+    n += full > 0 ? occ32(w0, c) : (full == 0 ? occ32(w0 & tailmask, c) : 0u);
+    n += full > 1 ? occ32(w1, c) : (full == 1 ? occ32(w1 & tailmask, c) : 0u);
+    n += full > 2 ? occ32(w2, c) : (full == 2 ? occ32(w2 & tailmask, c) : 0u);
+    n += full == 3 ? occ32(w3 & tailmask, c) : 0u;
+    if (c == 0) n -= (uint32_t)(~kk & 31);                         // masked-off tail symbols look like A
+    return n;
+}
+
+// bwt_occ: occurrences of c in BWT rows [0..k] of the matrix that includes the sentinel row
+__device__ __forceinline__ uint64_t fm_occ(const DevIndex &ix, uint64_t k, uint32_t c) {
+    if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
+    if (k == ~0ull) return 0;
+    uint64_t kk = k - (k >= ix.primary ? 1 : 0);
+    FmBlock b = fm_load_block(ix, kk);
+    return fm_block_count(b, c) + fm_block_rank(b, kk, c);
+}
+
+// BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c
+__device__ __forceinline__ void fm_get_neighbor(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c,
+                                                uint64_t *os, uint64_t *oe) {
+    uint64_t ok = fm_occ(ix, s - 1, c), ol = fm_occ(ix, e, c);
+    *os = ix.L2[c] + ok + 1;
+    *oe = ix.L2[c] + ol;
+}
+
+// bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps
+__device__ __forceinline__ uint64_t fm_sa(const DevIndex &ix, uint64_t k, uint32_t *steps) {
+    uint32_t n = 0;
+    while (k & 31) {
+        ++n;
+        if (k == ix.primary) { k = 0; continue; }
+        uint64_t kk = k - (k > ix.primary ? 1 : 0);
+        FmBlock b = fm_load_block(ix, kk);
+        uint32_t j = (uint32_t)(kk & 127);
+        uint32_t word = j < 64 ? (j < 32 ? (j < 16 ? b.q2.x : b.q2.y) : (j < 48 ? b.q2.z : b.q2.w))
+                               : (j < 96 ? (j < 80 ? b.q3.x : b.q3.y) : (j < 112 ? b.q3.z : b.q3.w));
+        uint32_t c = (word >> ((~j & 15) << 1)) & 3;
+        k = ix.L2[c] + fm_block_count(b, c) + fm_block_rank(b, kk, c);
+    }
+    *steps = n;
+    return (uint64_t)n + ix.sa[k >> 5];
+}
+
+}  // namespace unc

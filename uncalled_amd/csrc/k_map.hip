@@ -1,0 +1,789 @@
+// k_map: the per-read path-forest search, one WAVEFRONT per read, persistent over a read queue.
+//
+// Replaces Mapper::map_next (mapper.cpp:433-663) + PathBuffer::make_child/make_source (751-807) +
+// Mapper::update_seeds (665-700) + SeedTracker::add_seed/get_final (seed_tracker.cpp:129-232) for a
+// whole batch.  One event of one read is processed as a sequence of wave-cooperative phases:
+//
+//   P  1024 match log-probs of the normalised event (pore_model.hpp:163-165) -> LDS
+//   E  parents, 64 per pass in the reference's visiting order: thresholds -> candidate (parent,base)
+//      pairs compacted through LDS -> FM get_neighbor with every lane busy -> child slots by prefix
+//      sum (honouring the max_paths cut-off) -> one lane per child copies the parent's 128-byte
+//      record, slides the prob-sum window and emits a 16-byte sort key
+//   S  wavefront bitonic sort of the keys in registers (global-memory network beyond 512 children)
+//   W  walk in sorted order: duplicate-range pruning, per-k-mer gap sources from a segmented
+//      prefix-max, survivors -> next parent list, seed-valid survivors -> seed list
+//   F  full-range sources for k-mers not covered (sources_added_ bitmap in LDS)
+//   T  SA look-ups for all seeds in parallel (<=31 dependent LF steps each), then the SeedTracker
+//      update in the reference's order on a sorted 16-byte key array + append-only payload pool
+//   G  confidence test (get_final / check_map_conf) -> SUCCESS, or next event
+//
+// Integer/range results are bit-exact with the reference; float expressions are written one IEEE
+// operation at a time (compile with -ffp-contract=off; the reference is built without FMA).
+#include <hip/hip_runtime.h>
+
+#include "fm_dev.h"
+#include "unc_dev_types.h"
+#include "wave_prims.h"
+
+namespace unc {
+
+constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
+constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
+
+struct MapArgs {
+    DevIndex ix;
+    DevScratch sc;
+    DevReads rd;
+    unc_params_t P;
+    DevResult *results;
+    uint32_t *next_read;    // work-queue head
+    uint32_t max_steps;     // map_next calls per launch (0xFFFFFFFF = run to completion)
+    uint32_t resume;        // 1: continue the read saved in SlotState (trace / chunked mode)
+};
+
+struct Tracker {
+    uint32_t n, n_pay, n_lens, max1, max2, status;
+    float len_sum;
+    ClusterVal mm;
+};
+
+__device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
+    // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
+    return k.rstart > r2 || (k.rstart == r2 && k.evt_en > e2);
+}
+
+// std::multiset<u32> all_lens_ reduced to what get_final reads: its size and its two largest values.
+__device__ __forceinline__ void lens_insert(Tracker &T, uint32_t v) {
+    T.n_lens++;
+    if (v > T.max1) { T.max2 = T.max1; T.max1 = v; }
+    else if (v > T.max2) T.max2 = v;
+}
+// replace one instance of p by q > p (seed_tracker.cpp:201-203)
+__device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q) {
+    if (p == T.max1) { T.max1 = q; }                                   // (q, max2)
+    else if (p == T.max2) { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else T.max2 = q; }
+    else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
+}
+
+// move keys [a,b) one slot up (towards higher indices)
+__device__ __forceinline__ void keys_shift_up(ClusterKey *keys, uint32_t a, uint32_t b, int lane) {
+    for (uint32_t hi = b; hi > a;) {
+        uint32_t lo = hi - a > 64 ? hi - 64 : a;
+        uint32_t idx = lo + lane;
+        ClusterKey k;
+        bool have = idx < hi;
+        if (have) k = keys[idx];
+        wave_sync();
+        if (have) keys[idx + 1] = k;
+        wave_sync();
+        hi = lo;
+    }
+}
+// move keys [a,b) one slot down
+__device__ __forceinline__ void keys_shift_down(ClusterKey *keys, uint32_t a, uint32_t b, int lane) {
+    for (uint32_t lo = a; lo < b; lo += 64) {
+        uint32_t idx = lo + lane;
+        ClusterKey k;
+        bool have = idx < b;
+        if (have) k = keys[idx];
+        wave_sync();
+        if (have) keys[idx - 1] = k;
+        wave_sync();
+    }
+}
+
+// SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
+__device__ void add_seed(Tracker &T, ClusterKey *keys, ClusterPay *pay, uint32_t max_clusters, uint32_t min_map_len,
+                         uint64_t ref_en, uint32_t ref_len, uint32_t evt, int lane) {
+    if (T.status) return;
+    const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
+    const uint32_t e2 = evt;
+
+    // lower_bound(new_seed): 64-ary search
+    uint32_t lo = 0, hi = T.n;
+    while (hi - lo > 64) {
+        uint32_t step = (hi - lo + 63) / 64;
+        uint32_t idx = lo + (uint32_t)lane * step;
+        bool less = false;
+        if (idx < hi) less = key_less(keys[idx], r2, e2);
+        uint32_t c = (uint32_t)__popcll(__ballot(less));
+        uint32_t nlo = c ? lo + (c - 1) * step + 1 : lo;
+        uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    uint32_t lb;
+    {
+        uint32_t idx = lo + (uint32_t)lane;
+        bool less = false;
+        if (idx < hi) less = key_less(keys[idx], r2, e2);
+        lb = lo + (uint32_t)__popcll(__ballot(less));
+    }
+
+    // forward scan for the best-supported cluster this seed can extend (:169-191)
+    uint32_t best_len = 0, match = 0xFFFFFFFFu;
+    bool stop = false;
+    for (uint32_t pos = lb; pos < T.n && !stop; pos += 64) {
+        uint32_t idx = pos + (uint32_t)lane;
+        bool have = idx < T.n;
+        uint64_t r1 = 0;
+        uint32_t e1 = 0, tl = 0;
+        if (have) {
+            ClusterKey k = keys[idx];
+            r1 = k.rstart;
+            e1 = k.evt_en;
+            tl = pay[k.pidx].total_len;
+        }
+        uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
+        bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
+        bool far = have && dr >= (uint64_t)e2;
+        uint32_t tot;
+        uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
+        if (pm < best_len) pm = best_len;
+        bool taken = in_range && tl > pm;
+        bool brk = have && !taken && far;
+        uint64_t bm = __ballot(brk), tm = __ballot(taken);
+        if (bm) {
+            int first = __ffsll((unsigned long long)bm) - 1;
+            tm &= (1ull << first) - 1ull;
+            stop = true;
+        }
+        int last = tm ? 63 - __clzll((long long)tm) : 0;
+        uint32_t tl_last = bcast32(tl, last);
+        if (tm) {
+            match = pos + (uint32_t)last;
+            best_len = tl_last;
+        }
+    }
+
+    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at lb
+    {
+        uint64_t kr = 0; uint32_t ke = 0;
+        if (lb < T.n) { ClusterKey k = keys[lb]; kr = k.rstart; ke = k.evt_en; }
+        exists_at_lb = lb < T.n && kr == r2 && ke == e2;
+    }
+
+    if (match != 0xFFFFFFFFu) {
+        ClusterKey mk = keys[match];
+        ClusterPay mp = pay[mk.pidx];
+        ClusterVal a;
+        a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
+        a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mp.total_len;
+        const uint32_t prev_len = a.total_len;
+        // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
+        uint8_t growth = 0;
+        if (r2 < a.rend) {
+            if (ref_en > a.rend) { growth = (uint8_t)(ref_en - a.rend); a.rend = ref_en; }
+            a.rstart = r2;
+        } else {
+            growth = (uint8_t)ref_len;
+            a.rstart = r2;
+            a.rend = ref_en;
+        }
+        a.evt_en = e2;
+        a.total_len += growth;
+        if (a.total_len != prev_len) {
+            T.len_sum = __fadd_rn(T.len_sum, (float)(a.total_len - prev_len));
+            lens_replace(T, prev_len, a.total_len);
+            if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
+        }
+        // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2)
+        wave_sync();
+        if (lb == match) {
+            if (lane == 0) {
+                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
+                keys[match] = nk;
+            }
+        } else if (exists_at_lb) {
+            keys_shift_down(keys, match + 1, T.n, lane);   // the re-insert collides: cluster dropped
+            T.n--;
+        } else {
+            keys_shift_up(keys, lb, match, lane);
+            if (lane == 0) {
+                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
+                keys[lb] = nk;
+            }
+        }
+        if (lane == 0) {
+            ClusterPay np; np.ref_st = a.ref_st; np.rend = a.rend; np.evt_st = a.evt_st; np.total_len = a.total_len;
+            np.pad[0] = np.pad[1] = 0;
+            pay[mk.pidx] = np;
+        }
+        wave_sync();
+    } else {
+        // new cluster (:218-228): the bookkeeping happens even when the set insert collides
+        lens_insert(T, ref_len);
+        T.len_sum = __fadd_rn(T.len_sum, (float)ref_len);
+        if (ref_len >= min_map_len && ref_len > T.mm.total_len) {
+            T.mm.ref_st = r2; T.mm.rstart = r2; T.mm.rend = ref_en;
+            T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
+        }
+        if (!exists_at_lb) {
+            if (T.n >= max_clusters || T.n_pay >= max_clusters) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            wave_sync();
+            keys_shift_up(keys, lb, T.n, lane);
+            if (lane == 0) {
+                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = T.n_pay;
+                keys[lb] = nk;
+                ClusterPay np; np.ref_st = r2; np.rend = ref_en; np.evt_st = e2; np.total_len = ref_len;
+                np.pad[0] = np.pad[1] = 0;
+                pay[T.n_pay] = np;
+            }
+            T.n++;
+            T.n_pay++;
+            wave_sync();
+        }
+    }
+}
+
+// ---- sorting ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool key_gt(uint64_t a1, uint64_t b1, uint64_t a2, uint64_t b2) {
+    return a1 > a2 || (a1 == a2 && b1 > b2);
+}
+
+// bitonic sort of n <= 64*E keys held E per lane (element p = e*64 + lane)
+template <int E>
+__device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+    uint64_t a[E], b[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t i = (uint32_t)e * 64 + (uint32_t)lane;
+        if (i < n) { SortKey k = in[i]; a[e] = k.a; b[e] = k.b; }
+        else { a[e] = ~0ull; b[e] = ~0ull; }
+    }
+    constexpr uint32_t N = 64u * E;
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const uint32_t je = j >> 6;
+#pragma unroll
+                for (int jj = 1; jj < E; jj <<= 1) {
+                    if (je == (uint32_t)jj) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            if (!(e & jj)) {
+                                const int pe = e | jj;
+                                bool up = (((uint32_t)e * 64u) & k) == 0;
+                                bool gt = key_gt(a[e], b[e], a[pe], b[pe]);
+                                if (up ? gt : !gt) {
+                                    uint64_t ta = a[e], tb = b[e];
+                                    a[e] = a[pe]; b[e] = b[pe];
+                                    a[pe] = ta; b[pe] = tb;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)j);
+                    uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)j);
+                    uint32_t p = (uint32_t)e * 64u + (uint32_t)lane;
+                    bool up = (p & k) == 0, lower = ((uint32_t)lane & j) == 0;
+                    bool want_min = lower == up;
+                    bool gt = key_gt(a[e], b[e], pa, pb);
+                    if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t i = (uint32_t)e * 64 + (uint32_t)lane;
+        if (i < n) { SortKey k; k.a = a[e]; k.b = b[e]; out[i] = k; }
+    }
+}
+
+// bitonic network through global memory for events with more than 512 children
+__device__ void sort_global(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+    uint32_t N = 64;
+    while (N < n) N <<= 1;
+    for (uint32_t i = (uint32_t)lane; i < N; i += 64) {
+        SortKey k;
+        if (i < n) k = in[i]; else { k.a = ~0ull; k.b = ~0ull; }
+        out[i] = k;
+    }
+    wave_sync();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = (uint32_t)lane; t < N / 2; t += 64) {
+                uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                uint32_t p = i | j;
+                SortKey x = out[i], y = out[p];
+                bool up = (i & k) == 0;
+                bool gt = key_gt(x.a, x.b, y.a, y.b);
+                if (up ? gt : !gt) { out[i] = y; out[p] = x; }
+            }
+            wave_sync();
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t float_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// PathBuffer::make_child, mapper.cpp:775-807; also fills the child's sort key
+__device__ __forceinline__ void make_child(const PathRec &p, PathRec &c, uint64_t s, uint64_t e, uint32_t kmer, float prob,
+                                           uint32_t move, const unc_params_t &P, uint32_t child_idx, SortKey &key) {
+    const uint32_t PATH_MASK = (1u << SEED_LEN) - 1u, PATH_TAIL_MOVE = 1u << (SEED_LEN - 1);
+    const uint32_t plen = (p.meta >> META_LEN_SHIFT) & 31u, pstay = (p.meta >> META_STAY_SHIFT) & 255u;
+    const uint32_t stay = 1u - move;
+    const bool full = plen == (uint32_t)SEED_LEN;
+    const uint32_t len = plen + (full ? 0u : 1u);
+    uint32_t moves = ((p.moves << 1) | move) & PATH_MASK;
+    const uint32_t cstay = (pstay + stay) * stay;
+    // prob_sums_: slide (full window) or copy, then append at idx
+#pragma unroll
+    for (int j = 0; j < SEED_LEN; ++j) c.ps[j] = full ? p.ps[j + 1] : p.ps[j];
+    c.ps[SEED_LEN] = p.ps[SEED_LEN];
+    c.ps[SEED_LEN + 1] = 0.0f;
+    const uint32_t at = full ? (uint32_t)SEED_LEN : len;
+    float appended = 0.0f;
+#pragma unroll
+    for (int j = 1; j <= SEED_LEN; ++j) {
+        float v = __fadd_rn(c.ps[j - 1], prob);
+        if ((uint32_t)j == at) { c.ps[j] = v; appended = v; }
+    }
+    float seed_prob;
+    if (full) {
+        seed_prob = __fdiv_rn(__fsub_rn(appended, c.ps[0]), (float)SEED_LEN);
+        moves |= PATH_TAIL_MOVE;
+    } else {
+        seed_prob = __fdiv_rn(appended, (float)len);
+    }
+    c.start = s;
+    c.end = e;
+    c.moves = moves;
+    c.seed_prob = seed_prob;
+    c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (p.meta & META_SA_CHECKED);
+    c.pad = 0;
+    // is_seed_valid(path_ended = false), mapper.cpp:842-855, known at creation time
+    const uint32_t move_count = (uint32_t)__popc(moves);
+    const bool seed_ok = len == P.seed_len && seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
+                         (float)(len - move_count) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
+    key.a = (s << KEY_LEN_BITS) | (e - s);
+    key.b = ((uint64_t)float_orderable(seed_prob) << 32) | ((uint64_t)child_idx << 16) | (seed_ok ? KEYB_SEED_FLAG : 0u) | kmer;
+}
+
+// PathBuffer::make_source, mapper.cpp:751-772: only the fields a length-1 path ever reads
+__device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    q[0] = make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32));
+    q[1] = make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), 0u);
+    q[2] = make_uint4(0u, __float_as_uint(prob), 0u, 0u);   // prob_sums_ = {0, prob}
+}
+
+__global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
+    __shared__ float s_probs[NKMER];
+    __shared__ uint32_t s_flags[NKMER / 32];
+    __shared__ uint64_t s_pstart[WAVE], s_pend[WAVE];
+    __shared__ uint32_t s_pphys[WAVE];
+    __shared__ uint16_t s_cand[CAND_MAX];
+    __shared__ uint64_t s_res_s[CAND_MAX], s_res_e[CAND_MAX];
+    __shared__ uint32_t s_cdesc[CHILD_MAX];
+
+    const int lane = lane_id();
+    const uint32_t slot = blockIdx.x;
+    const DevIndex &ix = A.ix;
+    const unc_params_t &P = A.P;
+    const uint32_t max_paths = A.sc.max_paths;
+
+    PathRec *const buf0 = A.sc.paths + (size_t)slot * 2 * max_paths;
+    uint32_t *const ord0 = A.sc.order + (size_t)slot * 2 * max_paths;
+    SortKey *const ukeys = A.sc.keys + (size_t)slot * 2 * A.sc.keys_cap;
+    SortKey *const skeys = ukeys + A.sc.keys_cap;
+    SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
+    uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
+    ClusterKey *const cl_keys = A.sc.cl_keys + (size_t)slot * A.sc.max_clusters;
+    ClusterPay *const cl_pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
+    SlotState *const st = A.sc.state + slot;
+
+    const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
+    const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
+
+    for (;;) {
+        // ---------------- fetch or resume a read ----------------
+        uint32_t r, event_i, n_parents, cur;
+        Tracker T;
+        uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
+        if (A.resume) {
+            r = st->read_idx; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
+            T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
+            T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map;
+            if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
+            if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
+            r = uniform32(r); event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
+            if (uniform32(st->done)) break;
+        } else {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(A.next_read, 1u);
+            r = bcast32(t, 0);
+            if (r >= A.rd.n_reads) break;
+            event_i = 0; n_parents = 0; cur = 0;
+            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f;
+            T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
+            if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
+        }
+        __syncthreads();
+        const unc_evt_info_t inf = A.rd.info[r];
+        const uint32_t n_events = inf.n_events;
+        const float scale = inf.scale, shift = inf.shift;
+        const float *means = A.rd.means + A.rd.moff[r];
+
+        uint32_t done = 0, steps = 0;
+        while (!done && steps < A.max_steps) {
+            // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
+            if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
+            ++steps;
+
+            // ---------------- P: match log-probs ----------------
+            const float level = __fadd_rn(__fmul_rn(scale, means[event_i]), shift);   // Normalizer::at
+#pragma unroll 4
+            for (int j = 0; j < NKMER / WAVE; ++j) {
+                const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+                const float mu = ix.model[k], v2 = ix.model[NKMER + k], ld = ix.model[2 * NKMER + k];
+                const float d = __fsub_rn(level, mu);
+                const double q = -((double)d * (double)d) / (double)v2;
+                s_probs[k] = (float)(q - (double)ld);
+            }
+            __syncthreads();
+
+            const PathRec *par = buf0 + (size_t)cur * max_paths;
+            PathRec *chd = buf0 + (size_t)(cur ^ 1u) * max_paths;
+            const uint32_t *pord = ord0 + (size_t)cur * max_paths;
+            uint32_t *nord = ord0 + (size_t)(cur ^ 1u) * max_paths;
+
+            // ---------------- E: extend parents ----------------
+            uint32_t nchild = 0, n_seedp = 0;
+            for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
+                const uint32_t pi = base + (uint32_t)lane;
+                const bool have = pi < n_parents;
+                uint32_t phys = 0, pmoves = 0, pmeta = 0;
+                uint64_t pstart = 1, pend = 1;
+                float pprob = 0.0f;
+                if (have) {
+                    phys = pord[pi];
+                    const uint4 *q = reinterpret_cast<const uint4 *>(par + phys);
+                    uint4 q0 = q[0], q1 = q[1];
+                    pstart = ((uint64_t)q0.y << 32) | q0.x;
+                    pend = ((uint64_t)q0.w << 32) | q0.z;
+                    pmoves = q1.x; pprob = __uint_as_float(q1.y); pmeta = q1.z;
+                }
+                const uint64_t plen_fm = pend - pstart + 1;
+                const float thr = __shfl(thr_lane, __clzll((long long)plen_fm));   // get_prob_thresh, :161-167
+                const uint32_t kmer = pmeta & META_KMER_MASK;
+                const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
+                const bool stay_ok = have && stays < P.max_consec_stay && s_probs[kmer] >= thr;
+                uint32_t mask = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4; ++b) {
+                    const uint32_t nk = ((kmer << 2) & KMASK) | b;    // kmer_neighbor, bp.hpp:105-108
+                    if (have && !(s_probs[nk] < thr)) mask |= 1u << b;
+                }
+                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pphys[lane] = phys;
+                const uint32_t ncand = (uint32_t)__popc(mask);
+                uint32_t ctot;
+                const uint32_t coff = excl_sum32(ncand, &ctot);
+                {
+                    uint32_t w = coff;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b)
+                        if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
+                }
+                __syncthreads();
+                // FM look-ups, every lane busy
+                for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
+                    const uint32_t ci = c0 + (uint32_t)lane;
+                    if (ci < ctot) {
+                        const uint32_t cd = s_cand[ci];
+                        uint64_t ns, ne;
+                        fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
+                        s_res_s[ci] = ns; s_res_e[ci] = ne;
+                    }
+                }
+                __syncthreads();
+                // children per parent, in the reference's order: stay, then bases 0..3
+                uint32_t vmask = 0;   // bit j: j-th candidate of this lane has a non-empty range
+                for (uint32_t j = 0; j < ncand; ++j)
+                    if (s_res_s[coff + j] <= s_res_e[coff + j]) vmask |= 1u << j;
+                const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
+                uint32_t chtot;
+                const uint32_t choff = excl_sum32(nch, &chtot);
+                const uint32_t room = max_paths - nchild;                 // > 0 here
+                const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
+                const bool visited = have && choff < room;                // reached before the buffer filled
+                // work counter: the get_neighbor calls the reference makes (it stops at the cut-off)
+                for (uint32_t j = 0; j < ncand; ++j)
+                    if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
+                {
+                    uint32_t w = choff;
+                    if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
+                    uint32_t jj = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        if (mask & (1u << b)) {
+                            if (vmask & (1u << jj)) {
+                                if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((coff + jj) << 9);
+                                ++w;
+                            }
+                            ++jj;
+                        }
+                    }
+                }
+                // dead ends -> update_seeds(prev_path, true), :513-519 / is_seed_valid :842-863
+                bool ended_seed = false;
+                uint32_t e_count = 0, e_mc = 0;
+                if (visited && nch == 0 && !(pmeta & META_SA_CHECKED)) {
+                    const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
+                    const uint32_t mc = (uint32_t)__popc(pmoves);
+                    const bool base_ok = plen == P.seed_len && pprob >= P.min_seed_prob;
+                    const bool uniq = plen_fm == 1 && (pmoves & 1u) == 1u &&
+                                      (float)(plen - mc) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
+                    const bool rep = plen_fm <= (uint64_t)P.max_rep_copy && mc >= P.min_rep_len;
+                    ended_seed = base_ok && (uniq || rep);
+                    e_count = (uint32_t)plen_fm;
+                    e_mc = mc;
+                }
+                {
+                    const uint64_t em = __ballot(ended_seed);
+                    const uint32_t pos = n_seedp + (uint32_t)__popcll(em & lanemask_lt());
+                    if (ended_seed) {
+                        if (pos < A.sc.max_seed_paths) {
+                            SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
+                            seedp[pos] = sp;
+                        }
+                    }
+                    n_seedp += (uint32_t)__popcll(em);
+                }
+                __syncthreads();
+                // one lane per child
+                for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
+                    const uint32_t li = l0 + (uint32_t)lane;
+                    if (li < nwrite) {
+                        const uint32_t d = s_cdesc[li];
+                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
+                        const PathRec *pp = par + s_pphys[pl];
+                        PathRec p;
+                        {
+                            const uint4 *q = reinterpret_cast<const uint4 *>(pp);
+                            uint4 *w = reinterpret_cast<uint4 *>(&p);
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) w[x] = q[x];
+                        }
+                        const uint32_t pk = p.meta & META_KMER_MASK;
+                        uint64_t cs, ce;
+                        uint32_t ck, mv;
+                        if (type == 0) { cs = p.start; ce = p.end; ck = pk; mv = 0; }
+                        else { cs = s_res_s[ci]; ce = s_res_e[ci]; ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1; }
+                        PathRec c;
+                        SortKey key;
+                        const uint32_t gi = nchild + li;
+                        make_child(p, c, cs, ce, ck, s_probs[ck], mv, P, gi, key);
+                        {
+                            uint4 *w = reinterpret_cast<uint4 *>(chd + gi);
+                            const uint4 *q = reinterpret_cast<const uint4 *>(&c);
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) w[x] = q[x];
+                        }
+                        ukeys[gi] = key;
+                    }
+                }
+                nchild += nwrite;
+                __syncthreads();
+            }
+            if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
+            wave_sync();
+
+            // ---------------- S + W: sort children, prune duplicates, gap sources ----------------
+            const uint32_t n = nchild;
+            uint32_t n_surv = 0, n_src = 0;
+            if (n > 0) {
+                if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
+                else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
+                else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
+                else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
+                else sort_global(ukeys, skeys, n, lane);
+                wave_sync();
+
+                uint32_t carry_kmer = NKMER;
+                uint64_t carry_U = 0;
+                const uint32_t room = max_paths - n;   // sources that still fit
+                for (uint32_t base = 0; base < n; base += WAVE) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const bool have = i < n;
+                    SortKey ki, kn;
+                    ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
+                    if (have) ki = skeys[i];
+                    const bool has_next = i + 1 < n;
+                    if (has_next) kn = skeys[i + 1];
+                    const uint64_t start = ki.a >> KEY_LEN_BITS, end = start + (ki.a & KEY_LEN_MASK);
+                    const uint32_t kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
+                    const uint32_t idx = (uint32_t)(ki.b >> 16) & 0xFFFFu;
+                    const uint32_t nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
+                    const uint64_t nstart = kn.a >> KEY_LEN_BITS;
+                    uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
+                    if (lane == 0) pk = carry_kmer;
+                    const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
+                    const bool next_same = has_next && nkmer == kmer;
+                    const bool dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
+                    const bool psrc = have && s_probs[have ? kmer : 0] >= source_prob;
+                    // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
+                    uint64_t U = seg_incl_max64(have ? end + 1 : 0, first || !have);
+                    const uint64_t heads = __ballot(first || !have);
+                    const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
+                    if (headless && carry_U > U) U = carry_U;
+                    uint64_t kr_s = 1, kr_e = 0;
+                    if (have) { kr_s = ix.kmer_ranges[2 * kmer]; kr_e = ix.kmer_ranges[2 * kmer + 1]; }
+                    const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
+                    const uint64_t c_s = U, c_e = next_same ? nstart - 1 : kr_e;                   // :579-589
+                    const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
+                    uint32_t stot;
+                    const uint32_t soff = excl_sum32((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
+                    const uint32_t q0 = n_src + soff;                      // sources appended before this child
+                    const bool not_full0 = q0 < room;                      // next_path != end at step A
+                    if (first && psrc && not_full0) atomicOr(&s_flags[kmer >> 5], 1u << (kmer & 31u));   // :547
+                    if (a_valid && not_full0) write_source(chd + n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
+                    const uint32_t qc = q0 + (a_valid ? 1u : 0u);
+                    if (c_valid && qc < room) write_source(chd + n + qc, c_s, c_e, kmer, s_probs[kmer]);
+                    // survivors keep sorted order in the next parent list
+                    const bool surv = have && !dup;
+                    const uint64_t sm = __ballot(surv);
+                    if (surv) nord[n_surv + (uint32_t)__popcll(sm & lanemask_lt())] = idx;
+                    n_surv += (uint32_t)__popcll(sm);
+                    // update_seeds(child, false), :601 -- validity was decided at creation
+                    const bool sv = surv && (ki.b & KEYB_SEED_FLAG);
+                    const uint64_t svm = __ballot(sv);
+                    if (sv) {
+                        const uint32_t pos = n_seedp + (uint32_t)__popcll(svm & lanemask_lt());
+                        PathRec *cp = chd + idx;
+                        const uint32_t mv = cp->moves;
+                        cp->meta |= META_SA_CHECKED;
+                        if (pos < A.sc.max_seed_paths) {
+                            SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i; sp.ref_len = (uint32_t)__popc(mv); sp.pad = 0;
+                            seedp[pos] = sp;
+                        }
+                    }
+                    n_seedp += (uint32_t)__popcll(svm);
+                    // carries into the next pass
+                    const uint32_t nv = n - base < WAVE ? n - base : WAVE;
+                    carry_kmer = bcast32(kmer, (int)nv - 1);
+                    carry_U = bcast64(U, (int)nv - 1);
+                    n_src += stot;
+                    if (n_src > room) n_src = room;
+                }
+                if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
+            }
+            __syncthreads();
+
+            // ---------------- F: remaining full-range sources, :605-624 ----------------
+            uint32_t ent = n + n_src;
+            for (int j = 0; j < NKMER / WAVE; ++j) {
+                const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+                const uint32_t fl = (s_flags[k >> 5] >> (k & 31u)) & 1u;
+                const uint64_t kr_s = ix.kmer_ranges[2 * k], kr_e = ix.kmer_ranges[2 * k + 1];
+                const bool cond = !fl && s_probs[k] >= source_prob && kr_s <= kr_e;
+                const uint64_t m = __ballot(cond);
+                const uint32_t before = ent + (uint32_t)__popcll(m & lanemask_lt());
+                const bool exec = before < max_paths;           // loop header: next_path != end
+                const bool app = cond && exec;
+                if (app) write_source(chd + before, kr_s, kr_e, k, s_probs[k]);
+                const uint64_t keep = __ballot(!exec && fl);    // flags survive only past the cut-off
+                __syncthreads();
+                if (lane == 0) { s_flags[2 * j] = (uint32_t)keep; s_flags[2 * j + 1] = (uint32_t)(keep >> 32); }
+                ent += (uint32_t)__popcll(__ballot(app));
+            }
+            __syncthreads();
+            const uint32_t nsrc_total = ent - n;
+            for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) nord[n_surv + q] = n + q;
+            n_parents = n_surv + nsrc_total;
+            cur ^= 1u;
+            wave_sync();
+
+            // ---------------- T: seeds ----------------
+            for (uint32_t sb = 0; sb < n_seedp && !T.status; sb += WAVE) {
+                const uint32_t si = sb + (uint32_t)lane;
+                SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
+                if (si < n_seedp) sp = seedp[si];
+                uint32_t ttot;
+                const uint32_t toff = excl_sum32(sp.count, &ttot);
+                for (uint32_t j = 0; j < sp.count; ++j) tasks[toff + j] = sp.start + j;
+                wave_sync();
+                for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
+                    const uint32_t ti = t0 + (uint32_t)lane;
+                    if (ti < ttot) {
+                        uint32_t lf;
+                        const uint64_t sa = fm_sa(ix, tasks[ti], &lf);
+                        tasks[ti] = ix.seq_len - sa;    // sa_end, mapper.cpp:678
+                        c_sa++;
+                        c_lf += lf;
+                    }
+                }
+                wave_sync();
+                const uint32_t nl = n_seedp - sb < WAVE ? n_seedp - sb : WAVE;
+                for (uint32_t l = 0; l < nl; ++l) {
+                    const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
+                    const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint64_t sa_end = uniform64(tasks[o + j]);
+                        add_seed(T, cl_keys, cl_pay, A.sc.max_clusters, P.min_map_len, sa_end, rl, ev, lane);
+                    }
+                }
+            }
+
+            // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
+            bool conf = false;
+            if (T.mm.total_len >= P.min_map_len && T.n_lens >= 2) {
+                const float mean_len = __fdiv_rn(T.len_sum, (float)T.n);
+                const float second_len = (float)T.max2;
+                const float ml = (float)T.mm.total_len;
+                conf = (P.min_mean_conf > 0 && __fdiv_rn(ml, mean_len) >= P.min_mean_conf) ||
+                       (P.min_top_conf > 0 && __fdiv_rn(ml, second_len) >= P.min_top_conf);
+            }
+            if (T.status) { done = 2; }
+            else if (conf) { done = 1; }
+            else event_i++;
+        }
+
+        // ---------------- publish / park ----------------
+        const uint64_t t_nbr = wave_sum64(c_nbr), t_sa = wave_sum64(c_sa), t_lf = wave_sum64(c_lf);
+        if (done && lane == 0) {
+            DevResult res;
+            res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
+            res.cluster = T.mm;
+            res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
+            A.results[r] = res;
+        }
+        if (A.resume || !done) {
+            if (lane == 0) {
+                st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
+                st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
+                st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
+                st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
+            }
+            if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
+            break;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace unc
+
+#include "unc_kernels.h"
+namespace unc {
+void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
+                uint32_t *next_read, uint32_t max_steps, uint32_t resume, uint32_t grid, hipStream_t st) {
+    MapArgs a;
+    a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
+    a.max_steps = max_steps; a.resume = resume;
+    hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
+}
+// resident single-wave workgroups per CU for the persistent grid: bounded by the kernel's LDS
+// footprint (about 11 KB of the CU's 160 KB) and kept at 8 so that the grid stays well inside what
+// the hardware admits whatever the register allocation turns out to be.
+uint32_t map_kernel_waves_per_cu() { return 8; }
+}  // namespace unc

@@ -1,0 +1,66 @@
+// Small kernels around the FM index and the pore model: the k-mer range table built at index load
+// (BwaIndex::load_index, bwa_index.hpp:124-132) and array-at-a-time taps used by the parity tests.
+#include <hip/hip_runtime.h>
+
+#include "fm_dev.h"
+#include "unc_dev_types.h"
+#include "unc_kernels.h"
+
+namespace unc {
+
+__global__ void k_kmer_ranges(DevIndex ix, uint64_t *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (uint32_t)NKMER) return;
+    const uint32_t head = (k >> (2 * UNC_KLEN - 2)) & 3u;          // kmer_head, bp.hpp:100-103
+    uint64_t s = ix.L2[head], e = ix.L2[head + 1];                 // get_base_range, bwa_index.hpp:172-174
+    for (int i = 1; i < UNC_KLEN; ++i) {
+        const uint32_t b = (k >> (2 * (UNC_KLEN - i - 1))) & 3u;   // kmer_base, bp.hpp:111-114
+        fm_get_neighbor(ix, s, e, b, &s, &e);
+    }
+    out[2 * k] = s;
+    out[2 * k + 1] = e;
+}
+
+__global__ void k_fm_neighbor(DevIndex ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os, uint64_t *oe) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t a, c;
+    fm_get_neighbor(ix, s[i], e[i], b[i], &a, &c);
+    os[i] = a;
+    oe[i] = c;
+}
+
+__global__ void k_fm_sa(DevIndex ix, uint32_t n, const uint64_t *rows, uint64_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t steps;
+    out[i] = fm_sa(ix, rows[i], &steps);
+}
+
+// PoreModel::match_prob for all 1024 k-mers of each level (mapper.cpp:443-445)
+__global__ void k_match_probs(DevIndex ix, uint32_t n, const float *levels, float *out) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const float level = levels[i];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)NKMER; k += blockDim.x) {
+        const float d = __fsub_rn(level, ix.model[k]);
+        const double q = -((double)d * (double)d) / (double)ix.model[NKMER + k];
+        out[(size_t)i * NKMER + k] = (float)(q - (double)ix.model[2 * NKMER + k]);
+    }
+}
+
+void launch_kmer_ranges(const DevIndex &ix, uint64_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_kmer_ranges, dim3(NKMER / 64), dim3(64), 0, st, ix, out);
+}
+void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
+                        uint64_t *oe, hipStream_t st) {
+    hipLaunchKernelGGL(k_fm_neighbor, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, s, e, b, os, oe);
+}
+void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fm_sa, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, rows, out);
+}
+void launch_match_probs(const DevIndex &ix, uint32_t n, const float *levels, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_match_probs, dim3(n), dim3(64), 0, st, ix, n, levels, out);
+}
+
+}  // namespace unc

@@ -1,0 +1,105 @@
+// Shared host/device data layout of the MI355X mapper (no HIP headers needed here).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/uncalled_hip.h"
+
+namespace unc {
+
+constexpr int WAVE = 64;
+constexpr int SEED_LEN = UNC_SEED_LEN;
+constexpr int NKMER = UNC_NKMER;
+constexpr uint32_t KMASK = NKMER - 1;
+constexpr int MAX_REP_COPY_LIMIT = 64;
+
+// One path of the forest = exactly one 128-byte line in HBM (Mapper::PathBuffer, mapper.hpp:139-196).
+struct alignas(16) PathRec {
+    uint64_t start, end;        // fm_range_
+    uint32_t moves;             // event_moves_ (22-bit shift register, LSB = newest event)
+    float seed_prob;            // seed_prob_
+    uint32_t meta;              // kmer | length | consec_stays | sa_checked, see below
+    uint32_t pad;
+    float ps[24];               // prob_sums_[0..22]
+};
+static_assert(sizeof(PathRec) == 128, "PathRec must be one cache line");
+
+constexpr uint32_t META_KMER_MASK = 0x3FFu;
+constexpr int META_LEN_SHIFT = 10;       // 5 bits
+constexpr int META_STAY_SHIFT = 16;      // 8 bits
+constexpr uint32_t META_SA_CHECKED = 1u << 24;
+
+// Sort key of one child (operator< of mapper.cpp:866-871 made total by creation order):
+//   a = fm_range_.start << 30 | (fm_range_.length - 1)      (start asc, then end asc)
+//   b = orderable(seed_prob_) << 32 | idx << 16 | seedflag << 10 | kmer
+// idx (creation order) sits above the payload bits so ties resolve by creation order only.
+struct alignas(16) SortKey { uint64_t a, b; };
+constexpr int KEY_LEN_BITS = 30;
+constexpr uint64_t KEY_LEN_MASK = (1ull << KEY_LEN_BITS) - 1;
+constexpr uint32_t KEYB_SEED_FLAG = 1u << 10;
+
+// A path that passed is_seed_valid (mapper.cpp:842-863): its FM rows become seeds
+struct alignas(8) SeedPath { uint64_t start; uint32_t count; uint32_t evt; uint32_t ref_len; uint32_t pad; };
+
+// SeedTracker state (seed_tracker.hpp:69-110).  Clusters live in an append-only payload pool; the
+// std::set ordering (ref_en_.start desc, evt_en_ desc) is a sorted array of 16-byte keys.
+struct alignas(16) ClusterKey { uint64_t rstart; uint32_t evt_en; uint32_t pidx; };
+struct alignas(16) ClusterPay { uint64_t ref_st, rend; uint32_t evt_st, total_len; uint32_t pad[2]; };
+
+struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
+
+// Resumable per-slot mapper state (everything Mapper keeps between map_next calls)
+struct alignas(16) SlotState {
+    uint32_t read_idx;
+    uint32_t event_i;
+    uint32_t n_parents;      // compacted list of valid parents, in the reference's visiting order
+    uint32_t cur;            // which of the two path buffers holds the parents
+    uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
+    uint32_t status;
+    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2;
+    float len_sum;
+    ClusterVal max_map;
+    uint64_t n_nbr, n_sa, n_lf;
+    uint32_t sources_added[NKMER / 32];
+};
+
+struct DevIndex {
+    const uint32_t *bwt;        // 64-byte blocks: 4 x u64 counts + 8 x u32 of 2-bit BWT (bwa layout)
+    const uint64_t *sa;         // sampled SA, interval 32; sa[0] unused
+    const uint64_t *kmer_ranges;  // [1024][2]
+    const float *model;         // [3][1024]: lv_means, lv_vars_x2, lognorm_denoms
+    uint64_t primary, seq_len;
+    uint64_t L2[5];
+    float thresholds[64];
+};
+
+struct DevScratch {
+    PathRec *paths;        // [n_slots][2][max_paths]
+    uint32_t *order;       // [n_slots][2][max_paths]
+    SortKey *keys;         // [n_slots][2][keys_cap]   (unsorted | sorted)
+    SeedPath *seedp;       // [n_slots][max_seed_paths]
+    uint64_t *sa_tasks;    // [n_slots][WAVE * MAX_REP_COPY_LIMIT]
+    ClusterKey *cl_keys;   // [n_slots][max_clusters]
+    ClusterPay *cl_pay;    // [n_slots][max_clusters]
+    SlotState *state;      // [n_slots]
+    uint32_t max_paths, keys_cap, max_seed_paths, max_clusters;
+};
+
+struct DevReads {
+    const int16_t *raw;
+    const uint64_t *offsets;      // n_reads + 1
+    const unc_calib_t *calib;
+    float *means;                 // event means, read i at means[moff[i]..]
+    const uint64_t *moff;         // n_reads + 1
+    unc_evt_info_t *info;
+    uint32_t n_reads;
+    float tgt_mean, tgt_stdv;     // PoreModel::get_means_mean/stdv (mapper.cpp:94)
+};
+
+// what the map kernel hands back per read
+struct alignas(16) DevResult {
+    uint32_t done, status, event_i, pad;
+    ClusterVal cluster;
+    uint64_t n_nbr, n_sa, n_lf;
+};
+
+}  // namespace unc

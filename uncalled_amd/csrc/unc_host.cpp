@@ -1,0 +1,690 @@
+// Host side of libuncalled_hip.so: index loader (BWA on-disk format -> HBM), per-GPU scratch, batch
+// driver for the two kernels, PAF coordinate arithmetic (Mapper::set_ref_loc, mapper.cpp:703-728) and
+// the extern "C" boundary declared in include/uncalled_hip.h.  Everything that maps reads runs on the
+// device; there is no CPU mapping path in this library.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "r94_model_table.h"
+#include "unc_dev_types.h"
+#include "unc_kernels.h"
+
+using namespace unc;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(UNC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" const char *unc_last_error(void) { return g_err; }
+extern "C" const char *unc_version(void) { return "uncalled_hip 0.1 (gfx950)"; }
+
+extern "C" void unc_params_default(unc_params_t *p) {
+    // mapper.cpp:29-40
+    p->seed_len = 22; p->min_rep_len = 0; p->max_rep_copy = 50; p->max_paths = 10000;
+    p->max_consec_stay = 8; p->max_events = 30000; p->max_stay_frac = 0.5f; p->min_seed_prob = -3.75f;
+    // event_detector.cpp:17-26
+    p->window_length1 = 3; p->window_length2 = 6; p->threshold1 = 1.4f; p->threshold2 = 9.0f;
+    p->peak_height = 0.2f; p->min_mean = 0.0f; p->max_mean = 400.0f;
+    // seed_tracker.cpp:28-32
+    p->min_map_len = 25; p->min_mean_conf = 6.00f; p->min_top_conf = 1.85f;
+    // read_buffer.cpp:26-32
+    p->bp_per_sec = 450.0f; p->sample_rate = 4000.0f; p->chunk_time = 1.0f; p->max_chunks = 1000000;
+}
+
+// ------------------------------------------------------------------ index
+struct SeqAnn { std::string name; uint64_t offset, len; };
+
+struct unc_index {
+    int device = 0;
+    uint64_t primary = 0, seq_len = 0, L2[5] = {0, 0, 0, 0, 0};
+    int64_t l_pac = 0;
+    std::vector<SeqAnn> seqs;
+    std::vector<uint64_t> kmer_ranges;       // 2048, host copy
+    float thresholds[64];
+    std::vector<float> model;                // [3][1024] host copy
+    float model_mean = 0, model_stdv = 0;
+    // device
+    uint32_t *d_bwt = nullptr;
+    uint64_t *d_sa = nullptr;
+    uint64_t *d_kmer_ranges = nullptr;
+    float *d_model = nullptr;
+    uint64_t device_bytes = 0;
+    DevIndex dev;
+};
+
+static bool read_file(const std::string &fn, std::vector<char> &out) {
+    FILE *fp = fopen(fn.c_str(), "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    out.resize((size_t)sz);
+    bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, fp) == (size_t)sz;
+    fclose(fp);
+    return ok;
+}
+
+// PoreModel(vector, cmpl=true): pore_model.hpp:77-103, init_kmer 58-62, init_stdv 48-56.  Host libm
+// builds the three float tables once; the device only ever consumes the resulting float32 values.
+static void build_model(unc_index *ix) {
+    ix->model.assign(3 * NKMER, 0.0f);
+    float *mu = ix->model.data(), *v2 = mu + NKMER, *ld = mu + 2 * NKMER;
+    float model_mean = 0;
+    for (uint32_t kmer = 0; kmer < (uint32_t)NKMER; ++kmer) {
+        float mean, stdv;
+        memcpy(&mean, &UNC_R94_MEAN_STDV_BITS[2 * kmer], 4);
+        memcpy(&stdv, &UNC_R94_MEAN_STDV_BITS[2 * kmer + 1], 4);
+        const uint32_t k = kmer ^ KMASK;   // complement model, mapper.cpp:57 / bp.hpp:77-80
+        mu[k] = mean;
+        float tv = 2 * stdv;
+        tv = tv * stdv;
+        v2[k] = tv;
+        ld[k] = (float)log(sqrt(M_PI * (double)v2[k]));
+        model_mean = model_mean + mean;
+    }
+    model_mean = model_mean / (float)NKMER;
+    float acc = 0;
+    for (uint32_t k = 0; k < (uint32_t)NKMER; ++k) {
+        float d = mu[k] - model_mean;
+        acc = (float)((double)acc + (double)d * (double)d);
+    }
+    ix->model_mean = model_mean;
+    ix->model_stdv = sqrtf(acc / (float)NKMER);
+}
+
+// mapper.cpp:123-157
+static int parse_uncl(const std::string &fn, const char *preset, float *thr) {
+    std::vector<char> buf;
+    if (!read_file(fn, buf)) return fail(UNC_ERR_IO, "failed to load uncalled index %s", fn.c_str());
+    buf.push_back(0);
+    bool found = false;
+    char *save = nullptr;
+    for (char *line = strtok_r(buf.data(), "\n", &save); line; line = strtok_r(nullptr, "\n", &save)) {
+        char *s1 = nullptr;
+        char *name = strtok_r(line, "\t", &s1);
+        char *fn_str = strtok_r(nullptr, "\t", &s1);
+        if (!name || !fn_str) continue;
+        if (preset && preset[0] && strcmp(name, preset) != 0) continue;
+        uint8_t bin = 63;
+        char *s2 = nullptr;
+        for (char *tok = strtok_r(fn_str, ",", &s2); tok; tok = strtok_r(nullptr, ",", &s2)) {
+            thr[bin] = (float)atof(tok);
+            bin--;
+        }
+        for (; bin < 64; bin--) thr[bin] = thr[bin + 1];
+        found = true;
+    }
+    if (!found) return fail(UNC_ERR_IO, "preset '%s' not found in %s", preset ? preset : "", fn.c_str());
+    return UNC_OK;
+}
+
+static int parse_ann(const std::string &fn, unc_index *ix) {
+    FILE *fp = fopen(fn.c_str(), "r");
+    if (!fp) return fail(UNC_ERR_IO, "failed to load BWA index: %s", fn.c_str());
+    long long l_pac; int n_seqs; unsigned seed;
+    if (fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) { fclose(fp); return fail(UNC_ERR_IO, "bad header in %s", fn.c_str()); }
+    ix->l_pac = l_pac;
+    char line[8192], name[4096];
+    for (int i = 0; i < n_seqs; ++i) {
+        unsigned gi;
+        if (fscanf(fp, "%u%4095s", &gi, name) != 2) { fclose(fp); return fail(UNC_ERR_IO, "bad record in %s", fn.c_str()); }
+        if (!fgets(line, sizeof line, fp)) line[0] = 0;
+        long long off; int len, n_ambs;
+        if (fscanf(fp, "%lld%d%d", &off, &len, &n_ambs) != 3) { fclose(fp); return fail(UNC_ERR_IO, "bad record in %s", fn.c_str()); }
+        ix->seqs.push_back(SeqAnn{name, (uint64_t)off, (uint64_t)len});
+    }
+    fclose(fp);
+    return UNC_OK;
+}
+
+extern "C" void unc_index_free(unc_index_t *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->d_bwt) (void)hipFree(ix->d_bwt);
+    if (ix->d_sa) (void)hipFree(ix->d_sa);
+    if (ix->d_kmer_ranges) (void)hipFree(ix->d_kmer_ranges);
+    if (ix->d_model) (void)hipFree(ix->d_model);
+    delete ix;
+}
+
+extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, int device, unc_index_t **out) {
+    if (!bwa_prefix || !out) return fail(UNC_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::string prefix(bwa_prefix);
+    unc_index *ix = new unc_index();
+    ix->device = device;
+    struct Guard { unc_index *p; ~Guard() { if (p) unc_index_free(p); } } guard{ix};
+
+    // .bwt = u64 primary; u64 L2[1..4]; u32 words (Occ counts interleaved every 128 symbols)
+    std::vector<char> bwt;
+    if (!read_file(prefix + ".bwt", bwt) || bwt.size() < 40) return fail(UNC_ERR_IO, "failed to load BWA index: %s.bwt", bwa_prefix);
+    memcpy(&ix->primary, bwt.data(), 8);
+    memcpy(&ix->L2[1], bwt.data() + 8, 32);
+    ix->seq_len = ix->L2[4];
+    const size_t n_words = (bwt.size() - 40) / 4;
+    const uint64_t n = ix->seq_len;
+    if (n_words != (n + 15) / 16 + 8 * ((n + 127) / 128 + 1)) return fail(UNC_ERR_IO, "%s.bwt: size does not match seq_len", bwa_prefix);
+    if (n >= (1ull << 34)) return fail(UNC_ERR_ARG, "reference too large: seq_len %llu >= 2^34", (unsigned long long)n);
+
+    // .sa = u64 primary; u64 x4; u64 intv; u64 seq_len; u64 sa[1..]
+    std::vector<char> sa;
+    if (!read_file(prefix + ".sa", sa) || sa.size() < 56) return fail(UNC_ERR_IO, "failed to load BWA index: %s.sa", bwa_prefix);
+    uint64_t sa_primary, sa_intv, sa_seq_len;
+    memcpy(&sa_primary, sa.data(), 8);
+    memcpy(&sa_intv, sa.data() + 40, 8);
+    memcpy(&sa_seq_len, sa.data() + 48, 8);
+    if (sa_primary != ix->primary || sa_seq_len != n || sa_intv != 32) return fail(UNC_ERR_IO, "%s.sa does not match the .bwt (interval must be 32)", bwa_prefix);
+    const uint64_t n_sa = (n + 32) / 32;
+    if (sa.size() != 56 + (n_sa - 1) * 8) return fail(UNC_ERR_IO, "%s.sa: unexpected size", bwa_prefix);
+
+    int rc = parse_ann(prefix + ".ann", ix);
+    if (rc) return rc;
+    rc = parse_uncl(prefix + ".uncl", idx_preset ? idx_preset : "default", ix->thresholds);
+    if (rc) return rc;
+    build_model(ix);
+
+    HIPCHK(hipSetDevice(device));
+    // pad the BWT to whole 64-byte blocks so that block loads of the last (partial) block stay in bounds
+    const size_t bwt_bytes = ((n_words * 4 + 63) / 64 + 1) * 64;
+    HIPCHK(hipMalloc((void **)&ix->d_bwt, bwt_bytes));
+    HIPCHK(hipMemset(ix->d_bwt, 0, bwt_bytes));
+    HIPCHK(hipMemcpy(ix->d_bwt, bwt.data() + 40, n_words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&ix->d_sa, n_sa * 8));
+    {
+        std::vector<uint64_t> h(n_sa);
+        h[0] = ~0ull;   // bwt_restore_sa: sa[0] = -1
+        memcpy(h.data() + 1, sa.data() + 56, (n_sa - 1) * 8);
+        HIPCHK(hipMemcpy(ix->d_sa, h.data(), n_sa * 8, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void **)&ix->d_kmer_ranges, 2 * NKMER * 8));
+    HIPCHK(hipMalloc((void **)&ix->d_model, 3 * NKMER * 4));
+    HIPCHK(hipMemcpy(ix->d_model, ix->model.data(), 3 * NKMER * 4, hipMemcpyHostToDevice));
+    ix->device_bytes = bwt_bytes + n_sa * 8 + 2 * NKMER * 8 + 3 * NKMER * 4;
+
+    DevIndex &d = ix->dev;
+    d.bwt = ix->d_bwt; d.sa = ix->d_sa; d.kmer_ranges = ix->d_kmer_ranges; d.model = ix->d_model;
+    d.primary = ix->primary; d.seq_len = n;
+    for (int i = 0; i < 5; ++i) d.L2[i] = ix->L2[i];
+    memcpy(d.thresholds, ix->thresholds, sizeof d.thresholds);
+
+    // the 1024 k-mer ranges, derived on the device exactly as BwaIndex::load_index does (bwa_index.hpp:124-132)
+    launch_kmer_ranges(d, ix->d_kmer_ranges, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    ix->kmer_ranges.resize(2 * NKMER);
+    HIPCHK(hipMemcpy(ix->kmer_ranges.data(), ix->d_kmer_ranges, 2 * NKMER * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < NKMER; ++k) {
+        uint64_t s = ix->kmer_ranges[2 * k], e = ix->kmer_ranges[2 * k + 1];
+        if (s <= e && e - s >= (1ull << KEY_LEN_BITS)) return fail(UNC_ERR_ARG, "k-mer %d occurs more than 2^30 times: unsupported", k);
+    }
+    guard.p = nullptr;
+    *out = ix;
+    return UNC_OK;
+}
+
+extern "C" uint64_t unc_index_size(const unc_index_t *ix) { return ix->seq_len; }
+extern "C" int32_t unc_index_n_seqs(const unc_index_t *ix) { return (int32_t)ix->seqs.size(); }
+extern "C" const char *unc_index_seq_name(const unc_index_t *ix, int32_t rid) {
+    return (rid >= 0 && (size_t)rid < ix->seqs.size()) ? ix->seqs[rid].name.c_str() : "";
+}
+extern "C" uint64_t unc_index_seq_len(const unc_index_t *ix, int32_t rid) {
+    return (rid >= 0 && (size_t)rid < ix->seqs.size()) ? ix->seqs[rid].len : 0;
+}
+extern "C" uint64_t unc_index_device_bytes(const unc_index_t *ix) { return ix->device_bytes; }
+
+// bns_pos2rid behind BwaIndex::translate_loc, bwa_index.hpp:213-220
+extern "C" uint64_t unc_index_translate_loc(const unc_index_t *ix, uint64_t sa_loc, int32_t *rid, uint64_t *ref_loc) {
+    *rid = -1;
+    if ((int64_t)sa_loc >= ix->l_pac || ix->seqs.empty()) return 0;
+    int left = 0, mid = 0, right = (int)ix->seqs.size();
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (sa_loc >= ix->seqs[mid].offset) {
+            if (mid == (int)ix->seqs.size() - 1) break;
+            if (sa_loc < ix->seqs[mid + 1].offset) break;
+            left = mid + 1;
+        } else {
+            right = mid;
+        }
+    }
+    *rid = mid;
+    *ref_loc = sa_loc - ix->seqs[mid].offset;
+    return ix->seqs[mid].len;
+}
+
+extern "C" void unc_index_kmer_ranges(const unc_index_t *ix, uint64_t *out) { memcpy(out, ix->kmer_ranges.data(), 2 * NKMER * 8); }
+extern "C" void unc_index_thresholds(const unc_index_t *ix, float *out) { memcpy(out, ix->thresholds, sizeof ix->thresholds); }
+extern "C" void unc_index_model_tables(const unc_index_t *ix, float *mu, float *v2, float *ld, float *mm, float *ms) {
+    memcpy(mu, ix->model.data(), NKMER * 4);
+    memcpy(v2, ix->model.data() + NKMER, NKMER * 4);
+    memcpy(ld, ix->model.data() + 2 * NKMER, NKMER * 4);
+    *mm = ix->model_mean;
+    *ms = ix->model_stdv;
+}
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+extern "C" int unc_fm_get_neighbor(const unc_index_t *ix, uint32_t n, const uint64_t *starts, const uint64_t *ends,
+                                   const uint8_t *bases, uint64_t *out_s, uint64_t *out_e) {
+    HIPCHK(hipSetDevice(ix->device));
+    DevBuf<uint64_t> s, e, os, oe;
+    DevBuf<uint8_t> b;
+    HIPCHK(s.alloc(n)); HIPCHK(e.alloc(n)); HIPCHK(os.alloc(n)); HIPCHK(oe.alloc(n)); HIPCHK(b.alloc(n));
+    HIPCHK(hipMemcpy(s.p, starts, n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e.p, ends, n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b.p, bases, n, hipMemcpyHostToDevice));
+    launch_fm_neighbor(ix->dev, n, s.p, e.p, b.p, os.p, oe.p, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_s, os.p, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_e, oe.p, n * 8, hipMemcpyDeviceToHost));
+    return UNC_OK;
+}
+
+extern "C" int unc_fm_sa(const unc_index_t *ix, uint32_t n, const uint64_t *rows, uint64_t *out) {
+    HIPCHK(hipSetDevice(ix->device));
+    DevBuf<uint64_t> r, o;
+    HIPCHK(r.alloc(n)); HIPCHK(o.alloc(n));
+    HIPCHK(hipMemcpy(r.p, rows, n * 8, hipMemcpyHostToDevice));
+    launch_fm_sa(ix->dev, n, r.p, o.p, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, o.p, n * 8, hipMemcpyDeviceToHost));
+    return UNC_OK;
+}
+
+extern "C" int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *levels, float *out) {
+    HIPCHK(hipSetDevice(ix->device));
+    DevBuf<float> l, o;
+    HIPCHK(l.alloc(n)); HIPCHK(o.alloc((size_t)n * NKMER));
+    HIPCHK(hipMemcpy(l.p, levels, n * 4, hipMemcpyHostToDevice));
+    launch_match_probs(ix->dev, n, l.p, o.p, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, o.p, (size_t)n * NKMER * 4, hipMemcpyDeviceToHost));
+    return UNC_OK;
+}
+
+// ------------------------------------------------------------------ mapper
+struct unc_mapper {
+    const unc_index *ix = nullptr;
+    unc_params_t P;
+    uint32_t n_slots = 0;
+    DevScratch sc;
+    uint64_t device_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    float ms_events = 0, ms_map = 0;
+    uint32_t *d_next = nullptr;
+    // per-batch buffers (grown on demand)
+    int16_t *d_raw = nullptr; size_t raw_cap = 0;
+    uint64_t *d_offsets = nullptr; uint64_t *d_moff = nullptr; unc_calib_t *d_calib = nullptr;
+    unc_evt_info_t *d_info = nullptr; DevResult *d_results = nullptr; size_t reads_cap = 0;
+    float *d_means = nullptr; size_t means_cap = 0;
+    std::vector<uint64_t> h_moff;
+    std::vector<unc_evt_info_t> h_info;
+    std::vector<DevResult> h_results;
+    // trace state
+    uint32_t trace_n = 0;
+    bool trace_active = false;
+};
+
+extern "C" void unc_mapper_free(unc_mapper_t *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ix->device);
+    void *ptrs[] = {m->sc.paths, m->sc.order, m->sc.keys, m->sc.seedp, m->sc.sa_tasks, m->sc.cl_keys, m->sc.cl_pay, m->sc.state,
+                    m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out) {
+    if (!ix || !p || !out) return fail(UNC_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (p->seed_len != UNC_SEED_LEN) return fail(UNC_ERR_ARG, "seed_len must be %d", UNC_SEED_LEN);
+    if (p->window_length1 != UNC_WINDOW1 || p->window_length2 != UNC_WINDOW2) return fail(UNC_ERR_ARG, "event windows must be %d/%d", UNC_WINDOW1, UNC_WINDOW2);
+    if (p->max_paths == 0 || p->max_paths > 65535) return fail(UNC_ERR_ARG, "max_paths must be in 1..65535");
+    if (p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT) return fail(UNC_ERR_ARG, "max_rep_copy must be <= %d", MAX_REP_COPY_LIMIT);
+    if (p->max_consec_stay > 255) return fail(UNC_ERR_ARG, "max_consec_stay must be <= 255");
+    HIPCHK(hipSetDevice(ix->device));
+    unc_mapper *m = new unc_mapper();
+    struct Guard { unc_mapper *p; ~Guard() { if (p) unc_mapper_free(p); } } guard{m};
+    m->ix = ix;
+    m->P = *p;
+    memset(&m->sc, 0, sizeof m->sc);
+    uint32_t n_slots = opts ? opts->n_slots : 0;
+    if (n_slots == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ix->device));
+        n_slots = (uint32_t)prop.multiProcessorCount * map_kernel_waves_per_cu();
+    }
+    m->n_slots = n_slots;
+    DevScratch &sc = m->sc;
+    sc.max_paths = p->max_paths;
+    uint32_t kc = 64;
+    while (kc < p->max_paths) kc <<= 1;
+    sc.keys_cap = kc;
+    sc.max_seed_paths = (opts && opts->max_seed_paths) ? opts->max_seed_paths : p->max_paths;
+    sc.max_clusters = (opts && opts->max_clusters) ? opts->max_clusters : 16384;
+    const size_t S = n_slots;
+    size_t bytes = 0;
+#define ALLOC(field, type, count)                                            \
+    do {                                                                     \
+        size_t b_ = (size_t)(count) * sizeof(type);                          \
+        HIPCHK(hipMalloc((void **)&sc.field, b_));                           \
+        bytes += b_;                                                         \
+    } while (0)
+    ALLOC(paths, PathRec, S * 2 * sc.max_paths);
+    ALLOC(order, uint32_t, S * 2 * sc.max_paths);
+    ALLOC(keys, SortKey, S * 2 * sc.keys_cap);
+    ALLOC(seedp, SeedPath, S * sc.max_seed_paths);
+    ALLOC(sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
+    ALLOC(cl_keys, ClusterKey, S * sc.max_clusters);
+    ALLOC(cl_pay, ClusterPay, S * sc.max_clusters);
+    ALLOC(state, SlotState, S);
+#undef ALLOC
+    HIPCHK(hipMemset(sc.state, 0, S * sizeof(SlotState)));
+    HIPCHK(hipMalloc((void **)&m->d_next, 64));
+    m->device_bytes = bytes;
+    HIPCHK(hipStreamCreate(&m->stream));
+    for (auto &e : m->ev) HIPCHK(hipEventCreate(&e));
+    guard.p = nullptr;
+    *out = m;
+    return UNC_OK;
+}
+
+extern "C" uint64_t unc_mapper_device_bytes(const unc_mapper_t *m) { return m->device_bytes; }
+
+static int ensure_batch(unc_mapper *m, uint32_t n_reads, uint64_t total_samples, bool need_raw) {
+    if (need_raw && total_samples > m->raw_cap) {
+        if (m->d_raw) (void)hipFree(m->d_raw);
+        m->d_raw = nullptr;
+        HIPCHK(hipMalloc((void **)&m->d_raw, (total_samples + 64) * 2));
+        m->raw_cap = total_samples;
+    }
+    if (n_reads > m->reads_cap) {
+        void *ptrs[] = {m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        m->d_offsets = m->d_moff = nullptr; m->d_calib = nullptr; m->d_info = nullptr; m->d_results = nullptr;
+        HIPCHK(hipMalloc((void **)&m->d_offsets, ((size_t)n_reads + 1) * 8));
+        HIPCHK(hipMalloc((void **)&m->d_moff, ((size_t)n_reads + 1) * 8));
+        HIPCHK(hipMalloc((void **)&m->d_calib, (size_t)n_reads * sizeof(unc_calib_t)));
+        HIPCHK(hipMalloc((void **)&m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t)));
+        HIPCHK(hipMalloc((void **)&m->d_results, (size_t)n_reads * sizeof(DevResult)));
+        m->reads_cap = n_reads;
+    }
+    const uint64_t means_need = total_samples + 16ull * n_reads + 16;
+    if (means_need > m->means_cap) {
+        if (m->d_means) (void)hipFree(m->d_means);
+        m->d_means = nullptr;
+        HIPCHK(hipMalloc((void **)&m->d_means, means_need * 4));
+        m->means_cap = means_need;
+    }
+    return UNC_OK;
+}
+
+// uploads metadata, returns the DevReads view
+static int stage_batch(unc_mapper *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets, const unc_calib_t *calib,
+                       int on_device, hipStream_t st, DevReads *rd) {
+    if (n_reads == 0) return fail(UNC_ERR_ARG, "empty batch");
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(UNC_ERR_ARG, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) return fail(UNC_ERR_ARG, "read %u too long", i);
+    }
+    const uint64_t base = offsets[0], total = offsets[n_reads] - base;
+    int rc = ensure_batch(m, n_reads, total, !on_device);
+    if (rc) return rc;
+    m->h_moff.resize((size_t)n_reads + 1);
+    for (uint32_t i = 0; i <= n_reads; ++i) m->h_moff[i] = (offsets[i] - base) + 16ull * i;   // capacity n_i + 16 per read
+    HIPCHK(hipMemcpyAsync(m->d_offsets, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(m->d_moff, m->h_moff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(m->d_calib, calib, (size_t)n_reads * sizeof(unc_calib_t), hipMemcpyHostToDevice, st));
+    const int16_t *d_raw = raw;
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(m->d_raw, raw + base, total * 2, hipMemcpyHostToDevice, st));
+        d_raw = m->d_raw - base;   // kernels index raw[offsets[i]..]
+    }
+    rd->raw = d_raw; rd->offsets = m->d_offsets; rd->calib = m->d_calib; rd->means = m->d_means; rd->moff = m->d_moff;
+    rd->info = m->d_info; rd->n_reads = n_reads;
+    rd->tgt_mean = m->ix->model_mean; rd->tgt_stdv = m->ix->model_stdv;
+    return UNC_OK;
+}
+
+// Mapper::event_to_bp, mapper.cpp:703-706.  float -> u32 of an out-of-range value (evt_st - seed_len can
+// wrap, :716) follows x86-64's cvttss2si r64 + truncation, as the reference binary does.
+static uint32_t event_to_bp(const unc_params_t &P, uint32_t evt_i, float mean_event_len, bool last) {
+    float bp_per_samp = P.bp_per_sec / P.sample_rate;
+    float v = (float)evt_i * mean_event_len;
+    v = v * bp_per_samp;
+    v = v + (float)((int)last * (UNC_KLEN - 1));
+    return (uint32_t)(int64_t)v;
+}
+
+// Mapper::set_ref_loc (mapper.cpp:708-728) + Paf::set_mapped / set_read_len (read_buffer.cpp:133-155,264-267)
+static void fill_hit(const unc_mapper *m, const DevResult &res, const unc_evt_info_t &inf, uint64_t raw_len, unc_hit_t *h) {
+    const unc_params_t &P = m->P;
+    memset(h, 0, sizeof *h);
+    h->rid = -1;
+    h->status = res.status;
+    h->n_events = inf.n_events;
+    h->event_i = res.event_i;
+    float mel = inf.len_sum / (float)inf.total_events;   // EventDetector::mean_event_len, event_detector.cpp:151-153
+    h->mean_event_len = inf.total_events ? mel : 0.0f;
+    h->n_nbr = res.n_nbr; h->n_sa = res.n_sa; h->n_lf = res.n_lf;
+    if (res.done == 1 && res.status == 0) {
+        const ClusterVal &c = res.cluster;
+        const uint64_t size = m->ix->seq_len;
+        const bool fwd = c.ref_st < size / 2;
+        const uint64_t sa_st = fwd ? c.ref_st : size - (c.rend + UNC_KLEN - 1);
+        h->rd_st = event_to_bp(P, c.evt_st - P.seed_len, mel, false);
+        h->rd_en = event_to_bp(P, c.evt_en, mel, true);
+        h->rd_len = event_to_bp(P, res.event_i, mel, true);
+        uint64_t rf_st = 0;
+        int32_t rid;
+        const uint64_t rf_len = unc_index_translate_loc(m->ix, sa_st, &rid, &rf_st);
+        h->rid = rid;
+        h->rf_st = rf_st;
+        h->rf_len = rf_len;
+        h->rf_en = rf_st + (c.rend - c.ref_st + UNC_KLEN);
+        h->matches = (uint16_t)(c.total_len + UNC_KLEN - 1);
+        h->mapped = 1;
+        h->fwd = fwd ? 1 : 0;
+        h->cl_ref_st = c.ref_st; h->cl_ref_en_start = c.rstart; h->cl_ref_en_end = c.rend;
+        h->cl_evt_st = c.evt_st; h->cl_evt_en = c.evt_en; h->cl_total_len = c.total_len;
+    } else {
+        float bp_per_samp = P.bp_per_sec / P.sample_rate;
+        h->rd_len = (uint64_t)((float)raw_len * bp_per_samp);
+    }
+}
+
+extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                             const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits) {
+    if (!m || !raw || !offsets || !calib || !hits) return fail(UNC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    DevReads rd;
+    int rc = stage_batch(m, n_reads, raw, offsets, calib, on_device, st, &rd);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
+    HIPCHK(hipEventRecord(m->ev[0], st));
+    launch_events(rd, m->P, st);
+    HIPCHK(hipEventRecord(m->ev[1], st));
+    const uint32_t grid = n_reads < m->n_slots ? n_reads : m->n_slots;
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, grid, st);
+    HIPCHK(hipEventRecord(m->ev[2], st));
+    HIPCHK(hipGetLastError());
+    m->h_info.resize(n_reads);
+    m->h_results.resize(n_reads);
+    HIPCHK(hipMemcpyAsync(m->h_info.data(), m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(m->h_results.data(), m->d_results, (size_t)n_reads * sizeof(DevResult), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));
+    HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
+    int worst = UNC_OK;
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        fill_hit(m, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
+        if (hits[i].status) worst = UNC_ERR_OVERFLOW;
+    }
+    if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise max_clusters/max_seed_paths");
+    return UNC_OK;
+}
+
+extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
+    if (ms_events) *ms_events = m->ms_events;
+    if (ms_map) *ms_map = m->ms_map;
+    return UNC_OK;
+}
+
+extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                                 const unc_calib_t *calib, float *means, uint64_t means_cap, uint64_t *means_offsets,
+                                 unc_evt_info_t *info) {
+    if (!m || !raw || !offsets || !calib || !means || !means_offsets || !info) return fail(UNC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->ix->device));
+    hipStream_t st = m->stream;
+    DevReads rd;
+    int rc = stage_batch(m, n_reads, raw, offsets, calib, 0, st, &rd);
+    if (rc) return rc;
+    launch_events(rd, m->P, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(info, m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_reads; ++i) { means_offsets[i] = tot; tot += info[i].n_events; }
+    means_offsets[n_reads] = tot;
+    if (tot > means_cap) return fail(UNC_ERR_ARG, "means buffer too small: need %llu", (unsigned long long)tot);
+    for (uint32_t i = 0; i < n_reads; ++i)
+        HIPCHK(hipMemcpyAsync(means + means_offsets[i], m->d_means + m->h_moff[i], (size_t)info[i].n_events * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return UNC_OK;
+}
+
+// ------------------------------------------------------------------ step-wise trace of one read
+extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, const unc_calib_t *calib) {
+    if (!m || !raw || !calib) return fail(UNC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->ix->device));
+    hipStream_t st = m->stream;
+    uint64_t offsets[2] = {0, n};
+    DevReads rd;
+    int rc = stage_batch(m, 1, raw, offsets, calib, 0, st, &rd);
+    if (rc) return rc;
+    launch_events(rd, m->P, st);
+    SlotState s0;
+    memset(&s0, 0, sizeof s0);
+    s0.max_map.rstart = 1; s0.max_map.evt_st = 1;   // NULL_ALN
+    HIPCHK(hipMemcpyAsync(m->sc.state, &s0, sizeof s0, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    m->trace_n = n;
+    m->trace_active = true;
+    return UNC_OK;
+}
+
+static int trace_reads(unc_mapper *m, DevReads *rd) {
+    rd->raw = m->d_raw; rd->offsets = m->d_offsets; rd->calib = m->d_calib; rd->means = m->d_means; rd->moff = m->d_moff;
+    rd->info = m->d_info; rd->n_reads = 1; rd->tgt_mean = m->ix->model_mean; rd->tgt_stdv = m->ix->model_stdv;
+    return UNC_OK;
+}
+
+extern "C" int unc_trace_step(unc_mapper_t *m, uint32_t n_events, int *done) {
+    if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
+    HIPCHK(hipSetDevice(m->ix->device));
+    DevReads rd;
+    trace_reads(m, &rd);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, 1, m->stream);
+    HIPCHK(hipGetLastError());
+    SlotState s;
+    HIPCHK(hipMemcpyAsync(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (done) *done = s.done ? 1 : 0;
+    return UNC_OK;
+}
+
+extern "C" int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, uint32_t *n_out) {
+    if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
+    HIPCHK(hipSetDevice(m->ix->device));
+    SlotState s;
+    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ord(s.n_parents ? s.n_parents : 1);
+    std::vector<PathRec> recs(m->sc.max_paths);
+    HIPCHK(hipMemcpy(ord.data(), m->sc.order + (size_t)s.cur * m->sc.max_paths, (size_t)s.n_parents * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(recs.data(), m->sc.paths + (size_t)s.cur * m->sc.max_paths, (size_t)m->sc.max_paths * sizeof(PathRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s.n_parents && i < cap; ++i) {
+        const PathRec &r = recs[ord[i]];
+        unc_path_t &o = out[i];
+        memset(&o, 0, sizeof o);
+        o.fm_start = r.start; o.fm_end = r.end; o.event_moves = r.moves; o.seed_prob = r.seed_prob;
+        o.kmer = (uint16_t)(r.meta & META_KMER_MASK);
+        o.length = (uint8_t)((r.meta >> META_LEN_SHIFT) & 31u);
+        o.consec_stays = (uint8_t)((r.meta >> META_STAY_SHIFT) & 255u);
+        o.sa_checked = (r.meta & META_SA_CHECKED) ? 1 : 0;
+        for (int j = 0; j <= o.length && j <= UNC_SEED_LEN; ++j) o.prob_sums[j] = r.ps[j];
+    }
+    *n_out = s.n_parents;
+    return UNC_OK;
+}
+
+extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t cap, uint32_t *n_out, unc_cluster_t *max_map,
+                                  float *len_sum, uint32_t *n_lens) {
+    if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
+    HIPCHK(hipSetDevice(m->ix->device));
+    SlotState s;
+    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    std::vector<ClusterKey> keys(s.n_clusters ? s.n_clusters : 1);
+    std::vector<ClusterPay> pay(s.n_pay ? s.n_pay : 1);
+    HIPCHK(hipMemcpy(keys.data(), m->sc.cl_keys, (size_t)s.n_clusters * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pay.data(), m->sc.cl_pay, (size_t)s.n_pay * sizeof(ClusterPay), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s.n_clusters && i < cap; ++i) {
+        const ClusterPay &p = pay[keys[i].pidx];
+        out[i].ref_st = p.ref_st; out[i].ref_en_start = keys[i].rstart; out[i].ref_en_end = p.rend;
+        out[i].evt_st = p.evt_st; out[i].evt_en = keys[i].evt_en; out[i].total_len = p.total_len; out[i].pad = 0;
+    }
+    *n_out = s.n_clusters;
+    if (max_map) {
+        max_map->ref_st = s.max_map.ref_st; max_map->ref_en_start = s.max_map.rstart; max_map->ref_en_end = s.max_map.rend;
+        max_map->evt_st = s.max_map.evt_st; max_map->evt_en = s.max_map.evt_en; max_map->total_len = s.max_map.total_len; max_map->pad = 0;
+    }
+    if (len_sum) *len_sum = s.len_sum;
+    if (n_lens) *n_lens = s.n_lens;
+    return UNC_OK;
+}
+
+extern "C" int unc_trace_finish(unc_mapper_t *m, unc_hit_t *hit) {
+    if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
+    HIPCHK(hipSetDevice(m->ix->device));
+    SlotState s;
+    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    unc_evt_info_t inf;
+    HIPCHK(hipMemcpy(&inf, m->d_info, sizeof inf, hipMemcpyDeviceToHost));
+    DevResult res;
+    memset(&res, 0, sizeof res);
+    res.done = s.done; res.status = s.status; res.event_i = s.event_i; res.cluster = s.max_map;
+    res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
+    fill_hit(m, res, inf, m->trace_n, hit);
+    m->trace_active = false;
+    return UNC_OK;
+}

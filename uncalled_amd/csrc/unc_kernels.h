@@ -1,0 +1,17 @@
+// Launch wrappers implemented next to the kernels (k_events.hip, k_map.hip, k_taps.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "unc_dev_types.h"
+
+namespace unc {
+void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st);
+void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
+                uint32_t *next_read, uint32_t max_steps, uint32_t resume, uint32_t grid, hipStream_t st);
+uint32_t map_kernel_waves_per_cu();
+void launch_kmer_ranges(const DevIndex &ix, uint64_t *out2048, hipStream_t st);
+void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
+                        uint64_t *oe, hipStream_t st);
+void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st);
+void launch_match_probs(const DevIndex &ix, uint32_t n, const float *levels, float *out, hipStream_t st);
+}  // namespace unc

@@ -1,0 +1,75 @@
+// Wavefront (64-lane) primitives used by the kernels.  All of them are collectives: call them
+// from wave-uniform control flow only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace unc {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// compiler-level ordering of this wave's global/LDS traffic between cooperative phases (lanes of a
+// wave share the L1 and the memory pipeline executes a wave's accesses in order)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) { return (uint64_t)__shfl((unsigned long long)v, src); }
+__device__ __forceinline__ float bcastf(float v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    uint32_t lo = uniform32((uint32_t)v), hi = uniform32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// exclusive prefix sum of small per-lane counts; *total = sum over the wave
+__device__ __forceinline__ uint32_t excl_sum32(uint32_t v, uint32_t *total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane_id() >= d) x += y;
+    }
+    *total = bcast32(x, 63);
+    return x - v;
+}
+
+// exclusive prefix max (identity 0); *total = max over the wave
+__device__ __forceinline__ uint32_t excl_max32(uint32_t v, uint32_t *total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane_id() >= d) x = x > y ? x : y;
+    }
+    *total = bcast32(x, 63);
+    uint32_t e = (uint32_t)__shfl_up((int)x, 1);
+    return lane_id() == 0 ? 0u : e;
+}
+
+// segmented inclusive prefix max of u64: a lane with head != 0 starts a new segment
+__device__ __forceinline__ uint64_t seg_incl_max64(uint64_t v, bool head) {
+    uint64_t x = v;
+    uint32_t f = head ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = (uint64_t)__shfl_up((unsigned long long)x, d);
+        uint32_t g = (uint32_t)__shfl_up((int)f, d);
+        if (lane_id() >= d) {
+            if (!f) x = x > y ? x : y;
+            f |= g;
+        }
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d);
+    return v;
+}
+
+}  // namespace unc
