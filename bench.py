@@ -132,6 +132,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    pc = mapper.last_phase_cycles()
+    tot_c = float(sum(pc.values())) or 1.0
+    phase_share = {k: round(v / tot_c, 4) for k, v in pc.items()}
     if rank == 0:
         total_reads = a.reads * world * a.steps
         ev_bytes, map_bytes = algorithmic_bytes(hits, offsets)
@@ -148,7 +151,8 @@ def main():
                        "mean_ms_per_read_amortised": 1e3 * dt / (a.reads * a.steps),
                        "mapped_fraction": float(hits["mapped"].mean()),
                        "mean_events_per_read": float(hits["event_i"].mean()),
-                       "kernel_ms": {"k_events": float(np.mean(ms_ev)), "k_map": map_ms}},
+                       "kernel_ms": {"k_events": float(np.mean(ms_ev)), "k_map": map_ms},
+                       "k_map_phase_cycle_share": phase_share},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms,

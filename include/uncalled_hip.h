@@ -158,6 +158,9 @@ int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const u
                   const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits);
 /* wall-clock of the kernels of the last unc_map_batch, from HIP events on the launch stream */
 int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map);
+/* shader-clock cycles summed over the reads of the last batch, per k_map phase:
+ * [0] match probs, [1] extension, [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed, [7] rest */
+int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8);
 
 /* ---- stage taps (parity tests) */
 /* event detection + whole-read normalisation only (EventDetector::get_means, event_detector.cpp:133-145;

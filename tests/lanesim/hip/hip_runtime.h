@@ -165,6 +165,7 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __lanesim_shfl_abs(v, 0); }
 
+static inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

@@ -68,7 +68,7 @@ def load(path=None):
         raise UncalledHipError(
             f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "uncalled_amd has no CPU fallback.")
-    L = C.CDLL(str(path))
+    L = C.CDLL(str(path.resolve()))
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.unc_last_error.restype = C.c_char_p
     L.unc_version.restype = C.c_char_p
@@ -92,6 +92,7 @@ def load(path=None):
     L.unc_mapper_device_bytes.argtypes = [vp]; L.unc_mapper_device_bytes.restype = u64
     L.unc_map_batch.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp, vp]
     L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_detect_events.argtypes = [vp, u32, vp, vp, vp, vp, u64, vp, vp]
     L.unc_trace_begin.argtypes = [vp, vp, u32, vp]
     L.unc_trace_step.argtypes = [vp, u32, C.POINTER(C.c_int)]
@@ -242,6 +243,11 @@ class Mapper:
         a, b = C.c_float(), C.c_float()
         self.L.unc_mapper_last_timing(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def last_phase_cycles(self):
+        out = np.zeros(8, dtype=np.uint64)
+        self.L.unc_mapper_last_phase_cycles(self.h, out.ctypes.data)
+        return dict(zip(("probs", "extend", "sort", "walk", "sources", "sa", "add_seed", "rest"), out.tolist()))
 
     def detect_events(self, raw_i16, offsets_u64, calib):
         raw = np.ascontiguousarray(raw_i16, dtype=np.int16)

@@ -377,7 +377,10 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
     q[2] = make_uint4(0u, __float_as_uint(prob), 0u, 0u);   // prob_sums_ = {0, prob}
 }
 
-__global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
+#ifndef UNC_LB
+#define UNC_LB 2
+#endif
+__global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
     __shared__ uint64_t s_pstart[WAVE], s_pend[WAVE];
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
         uint32_t r, event_i, n_parents, cur;
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
+        uint64_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (A.resume) {
             r = st->read_idx; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
@@ -441,6 +445,12 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             ++steps;
 
             // ---------------- P: match log-probs ----------------
+            uint64_t tk = (uint64_t)clock64(), tn;
+#ifdef UNC_NO_PROFILE
+#define PHASE_END(i) (void)tn
+#else
+#define PHASE_END(i) tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn
+#endif
             const float level = __fadd_rn(__fmul_rn(scale, means[event_i]), shift);   // Normalizer::at
 #pragma unroll 4
             for (int j = 0; j < NKMER / WAVE; ++j) {
@@ -457,6 +467,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             const uint32_t *pord = ord0 + (size_t)cur * max_paths;
             uint32_t *nord = ord0 + (size_t)(cur ^ 1u) * max_paths;
 
+            PHASE_END(0);
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
@@ -598,6 +609,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
 
+            PHASE_END(1);
             // ---------------- S + W: sort children, prune duplicates, gap sources ----------------
             const uint32_t n = nchild;
             uint32_t n_surv = 0, n_src = 0;
@@ -608,6 +620,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
                 else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
                 else sort_global(ukeys, skeys, n, lane);
                 wave_sync();
+                PHASE_END(2);
 
                 uint32_t carry_kmer = NKMER;
                 uint64_t carry_U = 0;
@@ -679,6 +692,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             }
             __syncthreads();
 
+            PHASE_END(3);
             // ---------------- F: remaining full-range sources, :605-624 ----------------
             uint32_t ent = n + n_src;
             for (int j = 0; j < NKMER / WAVE; ++j) {
@@ -703,6 +717,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             cur ^= 1u;
             wave_sync();
 
+            PHASE_END(4);
             // ---------------- T: seeds ----------------
             for (uint32_t sb = 0; sb < n_seedp && !T.status; sb += WAVE) {
                 const uint32_t si = sb + (uint32_t)lane;
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
                     }
                 }
                 wave_sync();
+                PHASE_END(5);
                 const uint32_t nl = n_seedp - sb < WAVE ? n_seedp - sb : WAVE;
                 for (uint32_t l = 0; l < nl; ++l) {
                     const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
@@ -732,6 +748,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
                         add_seed(T, cl_keys, cl_pay, A.sc.max_clusters, P.min_map_len, sa_end, rl, ev, lane);
                     }
                 }
+                PHASE_END(6);
             }
 
             // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
@@ -746,6 +763,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             if (T.status) { done = 2; }
             else if (conf) { done = 1; }
             else event_i++;
+            PHASE_END(7);
         }
 
         // ---------------- publish / park ----------------
@@ -755,6 +773,7 @@ __global__ __launch_bounds__(64, 4) void k_map(MapArgs A) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
+            for (int i = 0; i < 8; ++i) res.cyc[i] = cyc[i];
             A.results[r] = res;
         }
         if (A.resume || !done) {

@@ -555,6 +555,13 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     return UNC_OK;
 }
 
+extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (const DevResult &r : m->h_results)
+        for (int i = 0; i < 8; ++i) out8[i] += r.cyc[i];
+    return UNC_OK;
+}
+
 extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
     if (ms_events) *ms_events = m->ms_events;
     if (ms_map) *ms_map = m->ms_map;

@@ -12,7 +12,11 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) -
 // compiler-level ordering of this wave's global/LDS traffic between cooperative phases (lanes of a
 // wave share the L1 and the memory pipeline executes a wave's accesses in order)
 __device__ __forceinline__ void wave_sync() {
+#ifdef UNC_STRONG_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // s_waitcnt vmcnt(0) lgkmcnt(0): stores have landed
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
