@@ -1,0 +1,57 @@
+"""CPU: the gfx950 library loads and exports every entry point include/uncalled_hip.h declares (no compute
+calls without a GPU), and the package refuses to work without it."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "uncalled_hip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(unc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("unc_index_load", "unc_mapper_create", "unc_map_batch", "unc_detect_events", "unc_params_default"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    lib = g.build_hip()          # hipcc cross-compiles for gfx950 without a GPU
+    L = ctypes.CDLL(str(lib))
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+    L.unc_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.unc_version()
+
+
+def test_params_default_match_reference_defaults():
+    from uncalled_amd import capi
+    p = capi.default_params()
+    # mapper.cpp:29-40, event_detector.cpp:17-26, seed_tracker.cpp:28-32, read_buffer.cpp:26-32
+    assert (p.seed_len, p.max_rep_copy, p.max_paths, p.max_consec_stay, p.max_events) == (22, 50, 10000, 8, 30000)
+    assert (p.window_length1, p.window_length2, p.min_map_len) == (3, 6, 25)
+    assert abs(p.min_seed_prob + 3.75) < 1e-7 and abs(p.threshold1 - 1.4) < 1e-6 and abs(p.min_top_conf - 1.85) < 1e-6
+    assert (p.bp_per_sec, p.sample_rate) == (450.0, 4000.0)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from uncalled_amd import capi
+    with pytest.raises(capi.UncalledHipError):
+        capi.load(tmp_path / "libuncalled_hip.so")
+
+
+def test_product_package_does_not_reference_the_oracle():
+    """The product path may not import, link or execute anything under oracle/ (or the lanesim emulator)."""
+    for f in list((ROOT / "uncalled_amd").rglob("*.py")) + list((ROOT / "uncalled_amd" / "csrc").glob("*")):
+        if f.suffix in (".so", ".o"):
+            continue
+        txt = f.read_text(errors="ignore")
+        assert "oracle" not in txt.replace("no CPU", "") or f.name == "r94_model_table.h", f
+        assert "unc_o_" not in txt and "pyoracle" not in txt and "pyref" not in txt, f
