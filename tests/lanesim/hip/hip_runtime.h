@@ -165,6 +165,14 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __lanesim_shfl_abs(v, 0); }
 
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned acc) {
+    int l = __lanesim_lane();
+    return acc + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned acc) {
+    int l = __lanesim_lane();
+    return acc + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
 static inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -242,29 +242,43 @@ __device__ __forceinline__ bool key_gt(uint64_t a1, uint64_t b1, uint64_t a2, ui
     return a1 > a2 || (a1 == a2 && b1 > b2);
 }
 
-// bitonic sort of n <= 64*E keys held E per lane (element p = e*64 + lane)
+// bitonic sort of n <= 64*E keys held E per lane, element p = lane*E + e: the j < E stages stay
+// inside a lane (static register indices), only the 21 stages with j >= E cross lanes (ds_bpermute)
 template <int E>
 __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     uint64_t a[E], b[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        uint32_t i = (uint32_t)e * 64 + (uint32_t)lane;
+        uint32_t i = (uint32_t)lane * E + (uint32_t)e;
         if (i < n) { SortKey k = in[i]; a[e] = k.a; b[e] = k.b; }
         else { a[e] = ~0ull; b[e] = ~0ull; }
     }
     constexpr uint32_t N = 64u * E;
     for (uint32_t k = 2; k <= N; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const uint32_t je = j >> 6;
+            if (j >= (uint32_t)E) {
+                const uint32_t d = j / (uint32_t)E;          // lane distance
+                const bool lower = ((uint32_t)lane & d) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
+                    uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)d);
+                    uint32_t p = (uint32_t)lane * E + (uint32_t)e;
+                    bool up = (p & k) == 0;
+                    bool want_min = lower == up;
+                    bool gt = key_gt(a[e], b[e], pa, pb);
+                    if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
+                }
+            } else {
 #pragma unroll
                 for (int jj = 1; jj < E; jj <<= 1) {
-                    if (je == (uint32_t)jj) {
+                    if (j == (uint32_t)jj) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             if (!(e & jj)) {
                                 const int pe = e | jj;
-                                bool up = (((uint32_t)e * 64u) & k) == 0;
+                                uint32_t p = (uint32_t)lane * E + (uint32_t)e;
+                                bool up = (p & k) == 0;
                                 bool gt = key_gt(a[e], b[e], a[pe], b[pe]);
                                 if (up ? gt : !gt) {
                                     uint64_t ta = a[e], tb = b[e];
@@ -275,23 +289,12 @@ __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane)
                         }
                     }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)j);
-                    uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)j);
-                    uint32_t p = (uint32_t)e * 64u + (uint32_t)lane;
-                    bool up = (p & k) == 0, lower = ((uint32_t)lane & j) == 0;
-                    bool want_min = lower == up;
-                    bool gt = key_gt(a[e], b[e], pa, pb);
-                    if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
-                }
             }
         }
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        uint32_t i = (uint32_t)e * 64 + (uint32_t)lane;
+        uint32_t i = (uint32_t)lane * E + (uint32_t)e;
         if (i < n) { SortKey k; k.a = a[e]; k.b = b[e]; out[i] = k; }
     }
 }
@@ -326,47 +329,44 @@ __device__ __forceinline__ uint32_t float_orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// PathBuffer::make_child, mapper.cpp:775-807; also fills the child's sort key
-__device__ __forceinline__ void make_child(const PathRec &p, PathRec &c, uint64_t s, uint64_t e, uint32_t kmer, float prob,
-                                           uint32_t move, const unc_params_t &P, uint32_t child_idx, SortKey &key) {
+// PathBuffer::make_child, mapper.cpp:775-807.  The 23 prob sums are kept as a ring in the record, so a
+// child is the parent's ring copied verbatim plus ONE float appended (the slot of the dropped oldest sum
+// once the window is full): no shifting.  `last` = prob_sums_[length_], `second` = prob_sums_[1].
+struct ChildHdr { uint32_t moves, meta, wslot; float seed_prob, appended; };
+__device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, float last, float second, uint64_t s, uint64_t e,
+                                               uint32_t kmer, float prob, uint32_t move, const unc_params_t &P,
+                                               uint32_t child_idx, SortKey &key) {
     const uint32_t PATH_MASK = (1u << SEED_LEN) - 1u, PATH_TAIL_MOVE = 1u << (SEED_LEN - 1);
-    const uint32_t plen = (p.meta >> META_LEN_SHIFT) & 31u, pstay = (p.meta >> META_STAY_SHIFT) & 255u;
+    const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u, pstay = (pmeta >> META_STAY_SHIFT) & 255u;
+    const uint32_t head = (pmeta >> META_HEAD_SHIFT) & 31u;
     const uint32_t stay = 1u - move;
     const bool full = plen == (uint32_t)SEED_LEN;
     const uint32_t len = plen + (full ? 0u : 1u);
-    uint32_t moves = ((p.moves << 1) | move) & PATH_MASK;
+    uint32_t moves = ((pmoves << 1) | move) & PATH_MASK;
     const uint32_t cstay = (pstay + stay) * stay;
-    // prob_sums_: slide (full window) or copy, then append at idx
-#pragma unroll
-    for (int j = 0; j < SEED_LEN; ++j) c.ps[j] = full ? p.ps[j + 1] : p.ps[j];
-    c.ps[SEED_LEN] = p.ps[SEED_LEN];
-    c.ps[SEED_LEN + 1] = 0.0f;
-    const uint32_t at = full ? (uint32_t)SEED_LEN : len;
-    float appended = 0.0f;
-#pragma unroll
-    for (int j = 1; j <= SEED_LEN; ++j) {
-        float v = __fadd_rn(c.ps[j - 1], prob);
-        if ((uint32_t)j == at) { c.ps[j] = v; appended = v; }
-    }
-    float seed_prob;
+    ChildHdr c;
+    c.appended = __fadd_rn(last, prob);
+    uint32_t nhead;
     if (full) {
-        seed_prob = __fdiv_rn(__fsub_rn(appended, c.ps[0]), (float)SEED_LEN);
+        c.seed_prob = __fdiv_rn(__fsub_rn(c.appended, second), (float)SEED_LEN);
         moves |= PATH_TAIL_MOVE;
+        nhead = head + 1u == PS_RING ? 0u : head + 1u;
+        c.wslot = head;                         // overwrite the dropped prob_sums_[0]
     } else {
-        seed_prob = __fdiv_rn(appended, (float)len);
+        c.seed_prob = __fdiv_rn(c.appended, (float)len);
+        nhead = head;
+        c.wslot = head + len;                   // head is 0 until the window fills
     }
-    c.start = s;
-    c.end = e;
     c.moves = moves;
-    c.seed_prob = seed_prob;
-    c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (p.meta & META_SA_CHECKED);
-    c.pad = 0;
+    c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (pmeta & META_SA_CHECKED) | (nhead << META_HEAD_SHIFT);
     // is_seed_valid(path_ended = false), mapper.cpp:842-855, known at creation time
     const uint32_t move_count = (uint32_t)__popc(moves);
-    const bool seed_ok = len == P.seed_len && seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
+    const bool seed_ok = len == P.seed_len && c.seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
                          (float)(len - move_count) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
     key.a = (s << KEY_LEN_BITS) | (e - s);
-    key.b = ((uint64_t)float_orderable(seed_prob) << 32) | ((uint64_t)child_idx << 16) | (seed_ok ? KEYB_SEED_FLAG : 0u) | kmer;
+    key.b = ((uint64_t)float_orderable(c.seed_prob) << 32) | ((uint64_t)child_idx << 16) | (move_count << KEYB_MOVES_SHIFT) |
+            (seed_ok ? KEYB_SEED_FLAG : 0u) | kmer;
+    return c;
 }
 
 // PathBuffer::make_source, mapper.cpp:751-772: only the fields a length-1 path ever reads
@@ -384,9 +384,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
     __shared__ uint64_t s_pstart[WAVE], s_pend[WAVE];
-    __shared__ uint32_t s_pphys[WAVE];
+    __shared__ uint32_t s_pphys[WAVE], s_pmoves[WAVE], s_pmeta[WAVE];
     __shared__ uint16_t s_cand[CAND_MAX];
-    __shared__ uint64_t s_res_s[CAND_MAX], s_res_e[CAND_MAX];
+    __shared__ uint64_t s_res[2 * CAND_MAX];          // FM results of a pass; reused as the source list in phase F
+    uint64_t *const s_res_s = s_res, *const s_res_e = s_res + CAND_MAX;
+    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_res);   // NKMER entries
     __shared__ uint32_t s_cdesc[CHILD_MAX];
 
     const int lane = lane_id();
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 
     const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
     const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
+    const uint32_t kvalid = ix.kmer_valid[lane];     // bit j: k-mer j*64+lane occurs in the reference
 
     for (;;) {
         // ---------------- fetch or resume a read ----------------
@@ -432,13 +435,14 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
             if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
         }
-        __syncthreads();
+        wave_sync();
         const unc_evt_info_t inf = A.rd.info[r];
         const uint32_t n_events = inf.n_events;
         const float scale = inf.scale, shift = inf.shift;
         const float *means = A.rd.means + A.rd.moff[r];
 
         uint32_t done = 0, steps = 0;
+        float next_mean = event_i < n_events ? means[event_i] : 0.0f;
         while (!done && steps < A.max_steps) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 #else
 #define PHASE_END(i) tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn
 #endif
-            const float level = __fadd_rn(__fmul_rn(scale, means[event_i]), shift);   // Normalizer::at
+            const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
+            if (event_i + 1 < n_events) next_mean = means[event_i + 1];
 #pragma unroll 4
             for (int j = 0; j < NKMER / WAVE; ++j) {
                 const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 const double q = -((double)d * (double)d) / (double)v2;
                 s_probs[k] = (float)(q - (double)ld);
             }
-            __syncthreads();
+            wave_sync();
 
             const PathRec *par = buf0 + (size_t)cur * max_paths;
             PathRec *chd = buf0 + (size_t)(cur ^ 1u) * max_paths;
@@ -470,14 +475,15 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             PHASE_END(0);
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
+            uint32_t phys_next = (uint32_t)lane < n_parents ? pord[lane] : 0u;
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
                 const uint32_t pi = base + (uint32_t)lane;
                 const bool have = pi < n_parents;
-                uint32_t phys = 0, pmoves = 0, pmeta = 0;
+                uint32_t phys = phys_next, pmoves = 0, pmeta = 0;
+                if (pi + WAVE < n_parents) phys_next = pord[pi + WAVE];
                 uint64_t pstart = 1, pend = 1;
                 float pprob = 0.0f;
                 if (have) {
-                    phys = pord[pi];
                     const uint4 *q = reinterpret_cast<const uint4 *>(par + phys);
                     uint4 q0 = q[0], q1 = q[1];
                     pstart = ((uint64_t)q0.y << 32) | q0.x;
@@ -495,17 +501,17 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     const uint32_t nk = ((kmer << 2) & KMASK) | b;    // kmer_neighbor, bp.hpp:105-108
                     if (have && !(s_probs[nk] < thr)) mask |= 1u << b;
                 }
-                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pphys[lane] = phys;
+                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pphys[lane] = phys; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta;
                 const uint32_t ncand = (uint32_t)__popc(mask);
                 uint32_t ctot;
-                const uint32_t coff = excl_sum32(ncand, &ctot);
+                const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
                 {
                     uint32_t w = coff;
 #pragma unroll
                     for (uint32_t b = 0; b < 4; ++b)
                         if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
                 }
-                __syncthreads();
+                wave_sync();
                 // FM look-ups, every lane busy
                 for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
                     const uint32_t ci = c0 + (uint32_t)lane;
@@ -516,14 +522,14 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         s_res_s[ci] = ns; s_res_e[ci] = ne;
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 // children per parent, in the reference's order: stay, then bases 0..3
                 uint32_t vmask = 0;   // bit j: j-th candidate of this lane has a non-empty range
                 for (uint32_t j = 0; j < ncand; ++j)
                     if (s_res_s[coff + j] <= s_res_e[coff + j]) vmask |= 1u << j;
                 const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
                 uint32_t chtot;
-                const uint32_t choff = excl_sum32(nch, &chtot);
+                const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
                 const uint32_t room = max_paths - nchild;                 // > 0 here
                 const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
                 const bool visited = have && choff < room;                // reached before the buffer filled
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 }
                 {
                     const uint64_t em = __ballot(ended_seed);
-                    const uint32_t pos = n_seedp + (uint32_t)__popcll(em & lanemask_lt());
+                    const uint32_t pos = n_seedp + (uint32_t)prefix_popc(em);
                     if (ended_seed) {
                         if (pos < A.sc.max_seed_paths) {
                             SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     }
                     n_seedp += (uint32_t)__popcll(em);
                 }
-                __syncthreads();
+                wave_sync();
                 // one lane per child
                 for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
                     const uint32_t li = l0 + (uint32_t)lane;
@@ -578,33 +584,33 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         const uint32_t d = s_cdesc[li];
                         const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
                         const PathRec *pp = par + s_pphys[pl];
-                        PathRec p;
-                        {
-                            const uint4 *q = reinterpret_cast<const uint4 *>(pp);
-                            uint4 *w = reinterpret_cast<uint4 *>(&p);
-#pragma unroll
-                            for (int x = 0; x < 8; ++x) w[x] = q[x];
-                        }
-                        const uint32_t pk = p.meta & META_KMER_MASK;
+                        const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
+                        const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
+                        // the parent's ring (6 x 16 B) plus the two sums the child needs, all in one round trip
+                        const uint4 *q = reinterpret_cast<const uint4 *>(pp);
+                        const uint4 r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6], r7 = q[7];
+                        uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
+                        uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
+                        const float last = pp->ps[sl], second = pp->ps[s2];
+                        const uint32_t pk = pmt & META_KMER_MASK;
                         uint64_t cs, ce;
                         uint32_t ck, mv;
-                        if (type == 0) { cs = p.start; ce = p.end; ck = pk; mv = 0; }
+                        if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
                         else { cs = s_res_s[ci]; ce = s_res_e[ci]; ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1; }
-                        PathRec c;
                         SortKey key;
                         const uint32_t gi = nchild + li;
-                        make_child(p, c, cs, ce, ck, s_probs[ck], mv, P, gi, key);
-                        {
-                            uint4 *w = reinterpret_cast<uint4 *>(chd + gi);
-                            const uint4 *q = reinterpret_cast<const uint4 *>(&c);
-#pragma unroll
-                            for (int x = 0; x < 8; ++x) w[x] = q[x];
-                        }
+                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, key);
+                        PathRec *cp = chd + gi;
+                        uint4 *w = reinterpret_cast<uint4 *>(cp);
+                        w[0] = make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32));
+                        w[1] = make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u);
+                        w[2] = r2; w[3] = r3; w[4] = r4; w[5] = r5; w[6] = r6; w[7] = r7;
+                        cp->ps[c.wslot] = c.appended;   // same lane, same address as the copy above: program order
                         ukeys[gi] = key;
                     }
                 }
                 nchild += nwrite;
-                __syncthreads();
+                wave_sync();
             }
             if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
                 else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
                 else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
+                else if (n <= 1024) sort_regs<16>(ukeys, skeys, n, lane);
                 else sort_global(ukeys, skeys, n, lane);
                 wave_sync();
                 PHASE_END(2);
@@ -650,33 +657,33 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
                     if (headless && carry_U > U) U = carry_U;
                     uint64_t kr_s = 1, kr_e = 0;
-                    if (have) { kr_s = ix.kmer_ranges[2 * kmer]; kr_e = ix.kmer_ranges[2 * kmer + 1]; }
+                    if (first && psrc) kr_s = ix.kmer_ranges[2 * kmer];
+                    if (have && !dup && psrc && !next_same) kr_e = ix.kmer_ranges[2 * kmer + 1];
                     const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
                     const uint64_t c_s = U, c_e = next_same ? nstart - 1 : kr_e;                   // :579-589
                     const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
                     uint32_t stot;
-                    const uint32_t soff = excl_sum32((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
+                    const uint32_t soff = excl_sum_bits<2>((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
                     const uint32_t q0 = n_src + soff;                      // sources appended before this child
                     const bool not_full0 = q0 < room;                      // next_path != end at step A
-                    if (first && psrc && not_full0) atomicOr(&s_flags[kmer >> 5], 1u << (kmer & 31u));   // :547
+                    if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
                     if (a_valid && not_full0) write_source(chd + n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
                     const uint32_t qc = q0 + (a_valid ? 1u : 0u);
                     if (c_valid && qc < room) write_source(chd + n + qc, c_s, c_e, kmer, s_probs[kmer]);
                     // survivors keep sorted order in the next parent list
                     const bool surv = have && !dup;
                     const uint64_t sm = __ballot(surv);
-                    if (surv) nord[n_surv + (uint32_t)__popcll(sm & lanemask_lt())] = idx;
+                    if (surv) nord[n_surv + (uint32_t)prefix_popc(sm)] = idx;
                     n_surv += (uint32_t)__popcll(sm);
                     // update_seeds(child, false), :601 -- validity was decided at creation
                     const bool sv = surv && (ki.b & KEYB_SEED_FLAG);
                     const uint64_t svm = __ballot(sv);
                     if (sv) {
-                        const uint32_t pos = n_seedp + (uint32_t)__popcll(svm & lanemask_lt());
-                        PathRec *cp = chd + idx;
-                        const uint32_t mv = cp->moves;
-                        cp->meta |= META_SA_CHECKED;
+                        const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
+                        atomicOr(&chd[idx].meta, META_SA_CHECKED);   // path.sa_checked_ = true (no value returned: no round trip)
                         if (pos < A.sc.max_seed_paths) {
-                            SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i; sp.ref_len = (uint32_t)__popc(mv); sp.pad = 0;
+                            SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
+                            sp.ref_len = (uint32_t)(ki.b >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
                             seedp[pos] = sp;
                         }
                     }
@@ -690,27 +697,40 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 }
                 if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             }
-            __syncthreads();
+            wave_sync();
 
             PHASE_END(3);
             // ---------------- F: remaining full-range sources, :605-624 ----------------
+            // sources_added_[k] for k = j*64 + lane lives in bit j of this lane's 16-bit field (two lanes per word).
+            // Pass 1 decides, in k-mer order, which k-mers get a full-range source and where (pure ALU + LDS);
+            // pass 2 fetches their ranges and writes the records, one lane per source, in one memory round trip.
             uint32_t ent = n + n_src;
-            for (int j = 0; j < NKMER / WAVE; ++j) {
-                const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
-                const uint32_t fl = (s_flags[k >> 5] >> (k & 31u)) & 1u;
-                const uint64_t kr_s = ix.kmer_ranges[2 * k], kr_e = ix.kmer_ranges[2 * k + 1];
-                const bool cond = !fl && s_probs[k] >= source_prob && kr_s <= kr_e;
-                const uint64_t m = __ballot(cond);
-                const uint32_t before = ent + (uint32_t)__popcll(m & lanemask_lt());
-                const bool exec = before < max_paths;           // loop header: next_path != end
-                const bool app = cond && exec;
-                if (app) write_source(chd + before, kr_s, kr_e, k, s_probs[k]);
-                const uint64_t keep = __ballot(!exec && fl);    // flags survive only past the cut-off
-                __syncthreads();
-                if (lane == 0) { s_flags[2 * j] = (uint32_t)keep; s_flags[2 * j + 1] = (uint32_t)(keep >> 32); }
-                ent += (uint32_t)__popcll(__ballot(app));
+            {
+                const uint32_t ent0 = ent;
+                const uint32_t myflags = (s_flags[lane >> 1] >> ((lane & 1) << 4)) & 0xFFFFu;
+                uint32_t newflags = 0;
+#pragma unroll 4
+                for (int j = 0; j < NKMER / WAVE; ++j) {
+                    const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+                    const uint32_t fl = (myflags >> j) & 1u;
+                    const bool cond = !fl && s_probs[k] >= source_prob && ((kvalid >> j) & 1u);
+                    const uint64_t m = __ballot(cond);
+                    const uint32_t before = ent + (uint32_t)prefix_popc(m);
+                    const bool exec = before < max_paths;           // loop header: next_path != end
+                    const bool app = cond && exec;
+                    if (app) s_list[before - ent0] = k;
+                    if (!exec && fl) newflags |= 1u << j;           // flags survive only past the cut-off
+                    ent += (uint32_t)__popcll(__ballot(app));
+                }
+                const uint32_t other = (uint32_t)__shfl_xor((int)newflags, 1);
+                wave_sync();
+                if (!(lane & 1)) s_flags[lane >> 1] = newflags | (other << 16);
+                for (uint32_t q = (uint32_t)lane; q < ent - ent0; q += WAVE) {
+                    const uint32_t k = s_list[q];
+                    write_source(chd + ent0 + q, ix.kmer_ranges[2 * k], ix.kmer_ranges[2 * k + 1], k, s_probs[k]);
+                }
             }
-            __syncthreads();
+            wave_sync();
             const uint32_t nsrc_total = ent - n;
             for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) nord[n_surv + q] = n + q;
             n_parents = n_surv + nsrc_total;
@@ -724,7 +744,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
                 if (si < n_seedp) sp = seedp[si];
                 uint32_t ttot;
-                const uint32_t toff = excl_sum32(sp.count, &ttot);
+                const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
                 for (uint32_t j = 0; j < sp.count; ++j) tasks[toff + j] = sp.start + j;
                 wave_sync();
                 for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
             break;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

@@ -19,7 +19,7 @@ struct alignas(16) PathRec {
     float seed_prob;            // seed_prob_
     uint32_t meta;              // kmer | length | consec_stays | sa_checked, see below
     uint32_t pad;
-    float ps[24];               // prob_sums_[0..22]
+    float ps[24];               // prob_sums_[0..22] as a ring: logical entry j sits in slot (head + j) % 23
 };
 static_assert(sizeof(PathRec) == 128, "PathRec must be one cache line");
 
@@ -27,6 +27,8 @@ constexpr uint32_t META_KMER_MASK = 0x3FFu;
 constexpr int META_LEN_SHIFT = 10;       // 5 bits
 constexpr int META_STAY_SHIFT = 16;      // 8 bits
 constexpr uint32_t META_SA_CHECKED = 1u << 24;
+constexpr int META_HEAD_SHIFT = 25;      // 5 bits: ring slot of prob_sums_[0]
+constexpr uint32_t PS_RING = UNC_SEED_LEN + 1;
 
 // Sort key of one child (operator< of mapper.cpp:866-871 made total by creation order):
 //   a = fm_range_.start << 30 | (fm_range_.length - 1)      (start asc, then end asc)
@@ -36,6 +38,7 @@ struct alignas(16) SortKey { uint64_t a, b; };
 constexpr int KEY_LEN_BITS = 30;
 constexpr uint64_t KEY_LEN_MASK = (1ull << KEY_LEN_BITS) - 1;
 constexpr uint32_t KEYB_SEED_FLAG = 1u << 10;
+constexpr int KEYB_MOVES_SHIFT = 11;     // 5 bits: popcount(event_moves_)
 
 // A path that passed is_seed_valid (mapper.cpp:842-863): its FM rows become seeds
 struct alignas(8) SeedPath { uint64_t start; uint32_t count; uint32_t evt; uint32_t ref_len; uint32_t pad; };
@@ -67,6 +70,7 @@ struct DevIndex {
     const uint64_t *sa;         // sampled SA, interval 32; sa[0] unused
     const uint64_t *kmer_ranges;  // [1024][2]
     const float *model;         // [3][1024]: lv_means, lv_vars_x2, lognorm_denoms
+    const uint16_t *kmer_valid; // [64]: bit j of entry l = range of k-mer j*64+l is non-empty
     uint64_t primary, seq_len;
     uint64_t L2[5];
     float thresholds[64];

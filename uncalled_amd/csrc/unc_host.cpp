@@ -68,6 +68,7 @@ struct unc_index {
     uint64_t *d_sa = nullptr;
     uint64_t *d_kmer_ranges = nullptr;
     float *d_model = nullptr;
+    uint16_t *d_kmer_valid = nullptr;
     uint64_t device_bytes = 0;
     DevIndex dev;
 };
@@ -164,6 +165,7 @@ extern "C" void unc_index_free(unc_index_t *ix) {
     if (ix->d_sa) (void)hipFree(ix->d_sa);
     if (ix->d_kmer_ranges) (void)hipFree(ix->d_kmer_ranges);
     if (ix->d_model) (void)hipFree(ix->d_model);
+    if (ix->d_kmer_valid) (void)hipFree(ix->d_kmer_valid);
     delete ix;
 }
 
@@ -236,6 +238,19 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     for (int k = 0; k < NKMER; ++k) {
         uint64_t s = ix->kmer_ranges[2 * k], e = ix->kmer_ranges[2 * k + 1];
         if (s <= e && e - s >= (1ull << KEY_LEN_BITS)) return fail(UNC_ERR_ARG, "k-mer %d occurs more than 2^30 times: unsupported", k);
+    }
+    {
+        uint16_t valid[WAVE];
+        for (int l = 0; l < WAVE; ++l) {
+            valid[l] = 0;
+            for (int j = 0; j < NKMER / WAVE; ++j) {
+                const int k = j * WAVE + l;
+                if (ix->kmer_ranges[2 * k] <= ix->kmer_ranges[2 * k + 1]) valid[l] |= (uint16_t)(1u << j);
+            }
+        }
+        HIPCHK(hipMalloc((void **)&ix->d_kmer_valid, sizeof valid));
+        HIPCHK(hipMemcpy(ix->d_kmer_valid, valid, sizeof valid, hipMemcpyHostToDevice));
+        ix->dev.kmer_valid = ix->d_kmer_valid;
     }
     guard.p = nullptr;
     *out = ix;
@@ -649,7 +664,8 @@ extern "C" int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, u
         o.length = (uint8_t)((r.meta >> META_LEN_SHIFT) & 31u);
         o.consec_stays = (uint8_t)((r.meta >> META_STAY_SHIFT) & 255u);
         o.sa_checked = (r.meta & META_SA_CHECKED) ? 1 : 0;
-        for (int j = 0; j <= o.length && j <= UNC_SEED_LEN; ++j) o.prob_sums[j] = r.ps[j];
+        const uint32_t head = (r.meta >> META_HEAD_SHIFT) & 31u;
+        for (int j = 0; j <= o.length && j <= UNC_SEED_LEN; ++j) o.prob_sums[j] = r.ps[(head + (uint32_t)j) % PS_RING];
     }
     *n_out = s.n_parents;
     return UNC_OK;

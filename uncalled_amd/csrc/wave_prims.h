@@ -29,6 +29,25 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi: two instructions, no cross-lane traffic)
+__device__ __forceinline__ uint32_t prefix_popc(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// exclusive prefix sum of per-lane counts < 2^BITS: one ballot + mbcnt per bit plane
+template <int BITS>
+__device__ __forceinline__ uint32_t excl_sum_bits(uint32_t v, uint32_t *total) {
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint64_t m = __ballot((v >> b) & 1u);
+        pre += prefix_popc(m) << b;
+        tot += (uint32_t)__popcll(m) << b;
+    }
+    *total = tot;
+    return pre;
+}
+
 // exclusive prefix sum of small per-lane counts; *total = sum over the wave
 __device__ __forceinline__ uint32_t excl_sum32(uint32_t v, uint32_t *total) {
     uint32_t x = v;
