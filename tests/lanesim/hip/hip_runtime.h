@@ -234,6 +234,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->totalGlobalMem = 1ull << 34;
     return 0;
 }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 1ull << 33; *t = 1ull << 34; return 0; }
 struct hipPointerAttribute_t { int type; };
 constexpr int hipMemoryTypeHost = 0, hipMemoryTypeDevice = 1;
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeDevice; return 0; }

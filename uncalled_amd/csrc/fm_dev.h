@@ -81,4 +81,13 @@ __device__ __forceinline__ uint64_t fm_sa(const DevIndex &ix, uint64_t k, uint32
     return (uint64_t)n + ix.sa[k >> 5];
 }
 
+// SA look-up through the dense table built at index load (k_dense_sa): entry = SA value (40 bits) | LF steps the
+// BWA-format walk above would have taken << 40 (kept so that the SURVEY 8(d) work counters stay those of
+// the reference's algorithm).  One 8-byte read instead of ~31 dependent 64-byte reads.
+__device__ __forceinline__ uint64_t fm_sa_dense(const DevIndex &ix, uint64_t k, uint32_t *steps) {
+    const uint64_t v = ix.sa_dense[k];
+    *steps = (uint32_t)(v >> 40);
+    return v & ((1ull << 40) - 1ull);
+}
+
 }  // namespace unc

@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     const uint32_t ti = t0 + (uint32_t)lane;
                     if (ti < ttot) {
                         uint32_t lf;
-                        const uint64_t sa = fm_sa(ix, tasks[ti], &lf);
+                        const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, tasks[ti], &lf) : fm_sa(ix, tasks[ti], &lf);
                         tasks[ti] = ix.seq_len - sa;    // sa_end, mapper.cpp:678
                         c_sa++;
                         c_lf += lf;

@@ -34,7 +34,17 @@ __global__ void k_fm_sa(DevIndex ix, uint32_t n, const uint64_t *rows, uint64_t 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t steps;
-    out[i] = fm_sa(ix, rows[i], &steps);
+    // row 0 is the sentinel suffix (SA stored as -1); path ranges never contain it
+    out[i] = (ix.sa_dense && rows[i] != 0) ? fm_sa_dense(ix, rows[i], &steps) : fm_sa(ix, rows[i], &steps);
+}
+
+// Dense SA: every row walks to its sampled row once, at index load (bwt_sa for all rows in parallel)
+__global__ void k_dense_sa(DevIndex ix, uint64_t *out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > ix.seq_len) return;
+    uint32_t steps;
+    const uint64_t sa = fm_sa(ix, k, &steps);
+    out[k] = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);   // row 0 (SA = -1) is never looked up
 }
 
 // PoreModel::match_prob for all 1024 k-mers of each level (mapper.cpp:443-445)
@@ -55,6 +65,10 @@ void launch_kmer_ranges(const DevIndex &ix, uint64_t *out, hipStream_t st) {
 void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
                         uint64_t *oe, hipStream_t st) {
     hipLaunchKernelGGL(k_fm_neighbor, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, s, e, b, os, oe);
+}
+void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st) {
+    const uint64_t n = ix.seq_len + 1;
+    hipLaunchKernelGGL(k_dense_sa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix, out);
 }
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st) {
     hipLaunchKernelGGL(k_fm_sa, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, rows, out);

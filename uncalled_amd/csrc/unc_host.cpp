@@ -69,6 +69,7 @@ struct unc_index {
     uint64_t *d_kmer_ranges = nullptr;
     float *d_model = nullptr;
     uint16_t *d_kmer_valid = nullptr;
+    uint64_t *d_sa_dense = nullptr;
     uint64_t device_bytes = 0;
     DevIndex dev;
 };
@@ -166,6 +167,7 @@ extern "C" void unc_index_free(unc_index_t *ix) {
     if (ix->d_kmer_ranges) (void)hipFree(ix->d_kmer_ranges);
     if (ix->d_model) (void)hipFree(ix->d_model);
     if (ix->d_kmer_valid) (void)hipFree(ix->d_kmer_valid);
+    if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
     delete ix;
 }
 
@@ -229,6 +231,23 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     for (int i = 0; i < 5; ++i) d.L2[i] = ix->L2[i];
     memcpy(d.thresholds, ix->thresholds, sizeof d.thresholds);
 
+    d.sa_dense = nullptr;
+    // Dense SA (8 bytes per BWT row; HBM is plentiful: 74 MB for E. coli, ~50 GB for GRCh38): every row walks LF to
+    // its sampled row once, here, instead of on every seed.  UNC_DENSE_SA=0 keeps the BWA sampling only.
+    {
+        const char *env = getenv("UNC_DENSE_SA");
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need = (n + 1) * 8;
+        if (!(env && env[0] == '0') && need < free_b / 2) {
+            HIPCHK(hipMalloc((void **)&ix->d_sa_dense, need));
+            launch_dense_sa(d, ix->d_sa_dense, nullptr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+            d.sa_dense = ix->d_sa_dense;
+            ix->device_bytes += need;
+        }
+    }
     // the 1024 k-mer ranges, derived on the device exactly as BwaIndex::load_index does (bwa_index.hpp:124-132)
     launch_kmer_ranges(d, ix->d_kmer_ranges, nullptr);
     HIPCHK(hipGetLastError());
