@@ -242,49 +242,41 @@ __device__ __forceinline__ bool key_gt(uint64_t a1, uint64_t b1, uint64_t a2, ui
     return a1 > a2 || (a1 == a2 && b1 > b2);
 }
 
-// bitonic sort of n <= 64*E keys held E per lane, element p = lane*E + e: the j < E stages stay
-// inside a lane (static register indices), only the 21 stages with j >= E cross lanes (ds_bpermute)
+// Bitonic network over keys held E per lane (block element q = lane*E + e, global index p = base + q).
+// merge_stages runs the stages j = j_from, j_from/2, .., 1 of merge size k: the j < E stages stay inside a
+// lane (static register indices), the j >= E stages cross lanes (at most 6 per merge).
 template <int E>
-__device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
-    uint64_t a[E], b[E];
+__device__ __forceinline__ void merge_stages(uint64_t (&a)[E], uint64_t (&b)[E], uint32_t base, uint32_t k, uint32_t j_from,
+                                             int lane) {
+    for (uint32_t j = j_from; j > 0; j >>= 1) {
+        if (j >= (uint32_t)E) {
+            const uint32_t d = j / (uint32_t)E;          // lane distance
+            const bool lower = ((uint32_t)lane & d) == 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) { SortKey k = in[i]; a[e] = k.a; b[e] = k.b; }
-        else { a[e] = ~0ull; b[e] = ~0ull; }
-    }
-    constexpr uint32_t N = 64u * E;
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= (uint32_t)E) {
-                const uint32_t d = j / (uint32_t)E;          // lane distance
-                const bool lower = ((uint32_t)lane & d) == 0;
+            for (int e = 0; e < E; ++e) {
+                uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
+                uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)d);
+                uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
+                bool up = (p & k) == 0;
+                bool want_min = lower == up;
+                bool gt = key_gt(a[e], b[e], pa, pb);
+                if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
+            }
+        } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
-                    uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)d);
-                    uint32_t p = (uint32_t)lane * E + (uint32_t)e;
-                    bool up = (p & k) == 0;
-                    bool want_min = lower == up;
-                    bool gt = key_gt(a[e], b[e], pa, pb);
-                    if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
-                }
-            } else {
+            for (int jj = 1; jj < E; jj <<= 1) {
+                if (j == (uint32_t)jj) {
 #pragma unroll
-                for (int jj = 1; jj < E; jj <<= 1) {
-                    if (j == (uint32_t)jj) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            if (!(e & jj)) {
-                                const int pe = e | jj;
-                                uint32_t p = (uint32_t)lane * E + (uint32_t)e;
-                                bool up = (p & k) == 0;
-                                bool gt = key_gt(a[e], b[e], a[pe], b[pe]);
-                                if (up ? gt : !gt) {
-                                    uint64_t ta = a[e], tb = b[e];
-                                    a[e] = a[pe]; b[e] = b[pe];
-                                    a[pe] = ta; b[pe] = tb;
-                                }
+                    for (int e = 0; e < E; ++e) {
+                        if (!(e & jj)) {
+                            const int pe = e | jj;
+                            uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
+                            bool up = (p & k) == 0;
+                            bool gt = key_gt(a[e], b[e], a[pe], b[pe]);
+                            if (up ? gt : !gt) {
+                                uint64_t ta = a[e], tb = b[e];
+                                a[e] = a[pe]; b[e] = b[pe];
+                                a[pe] = ta; b[pe] = tb;
                             }
                         }
                     }
@@ -292,25 +284,50 @@ __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane)
             }
         }
     }
+}
+
+template <int E>
+__device__ __forceinline__ void block_load(uint64_t (&a)[E], uint64_t (&b)[E], const SortKey *in, uint32_t base, uint32_t n, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) { SortKey k; k.a = a[e]; k.b = b[e]; out[i] = k; }
+        uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+        if (i < n) { SortKey k = in[i]; a[e] = k.a; b[e] = k.b; }
+        else { a[e] = ~0ull; b[e] = ~0ull; }
+    }
+}
+template <int E>
+__device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64_t (&b)[E], SortKey *out, uint32_t base, uint32_t lim, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+        if (i < lim) { SortKey k; k.a = a[e]; k.b = b[e]; out[i] = k; }
     }
 }
 
-// bitonic network through global memory for events with more than 512 children
-__device__ void sort_global(const SortKey *in, SortKey *out, uint32_t n, int lane) {
-    uint32_t N = 64;
+// n <= 64*E: the whole sort in registers
+template <int E>
+__device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+    uint64_t a[E], b[E];
+    block_load<E>(a, b, in, 0, n, lane);
+    for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages<E>(a, b, 0, k, k >> 1, lane);
+    block_store<E>(a, b, out, 0, n, lane);
+}
+
+// n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
+__device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+    constexpr int E = 8;
+    constexpr uint32_t B = 64u * E;
+    uint32_t N = 2 * B;
     while (N < n) N <<= 1;
-    for (uint32_t i = (uint32_t)lane; i < N; i += 64) {
-        SortKey k;
-        if (i < n) k = in[i]; else { k.a = ~0ull; k.b = ~0ull; }
-        out[i] = k;
+    uint64_t a[E], b[E];
+    for (uint32_t base = 0; base < N; base += B) {      // padded blocks sort like any other (keys = max)
+        block_load<E>(a, b, in, base, n, lane);
+        for (uint32_t k = 2; k <= B; k <<= 1) merge_stages<E>(a, b, base, k, k >> 1, lane);
+        block_store<E>(a, b, out, base, N, lane);
     }
     wave_sync();
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+    for (uint32_t k = 2 * B; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= B; j >>= 1) {
             for (uint32_t t = (uint32_t)lane; t < N / 2; t += 64) {
                 uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 uint32_t p = i | j;
@@ -321,6 +338,12 @@ __device__ void sort_global(const SortKey *in, SortKey *out, uint32_t n, int lan
             }
             wave_sync();
         }
+        for (uint32_t base = 0; base < N; base += B) {
+            block_load<E>(a, b, out, base, N, lane);
+            merge_stages<E>(a, b, base, k, B >> 1, lane);
+            block_store<E>(a, b, out, base, N, lane);
+        }
+        wave_sync();
     }
 }
 
@@ -378,7 +401,7 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 }
 
 #ifndef UNC_LB
-#define UNC_LB 2
+#define UNC_LB 3
 #endif
 __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ float s_probs[NKMER];
@@ -624,8 +647,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
                 else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
                 else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
-                else if (n <= 1024) sort_regs<16>(ukeys, skeys, n, lane);
-                else sort_global(ukeys, skeys, n, lane);
+                else sort_hybrid(ukeys, skeys, n, lane);
                 wave_sync();
                 PHASE_END(2);
 
@@ -822,7 +844,7 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
     hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
 }
 // resident single-wave workgroups per CU for the persistent grid: bounded by the kernel's LDS
-// footprint (about 11 KB of the CU's 160 KB) and kept at 8 so that the grid stays well inside what
+// footprint (about 12 KB of the CU's 160 KB) and by 3 waves per SIMD (launch bounds); 12 so that the grid stays well inside what
 // the hardware admits whatever the register allocation turns out to be.
-uint32_t map_kernel_waves_per_cu() { return 8; }
+uint32_t map_kernel_waves_per_cu() { return 12; }
 }  // namespace unc
