@@ -140,6 +140,12 @@ def main():
         ev_bytes, map_bytes = algorithmic_bytes(hits, offsets)
         map_ms = float(np.mean(ms_map))
         achieved = map_bytes / (map_ms * 1e-3) / 1e9
+        # HBM traffic of k_map from the committed rocprofv3 PMC passes of this same command/config
+        # (FETCH_SIZE and WRITE_SIZE cannot be collected from inside this process), scaled per read
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_pmc_k_map.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text())["hbm_bytes_per_read"] * a.reads
         out = {
             "metric": "reads_mapped_per_sec", "value": total_reads / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -154,7 +160,8 @@ def main():
                        "kernel_ms": {"k_events": float(np.mean(ms_ev)), "k_map": map_ms},
                        "k_map_phase_cycle_share": phase_share},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_k_map.json (FETCH_SIZE+WRITE_SIZE per read x reads)",
                          "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms,
                          "whole_path_bytes_per_step": ev_bytes + map_bytes},
         }
