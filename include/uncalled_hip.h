@@ -61,6 +61,7 @@ typedef struct { float range, offset, digitisation; } unc_calib_t;
 #define UNC_READ_OK 0u
 #define UNC_READ_CLUSTER_OVERFLOW 1u   /* seed-cluster scratch exhausted: result for this read is invalid */
 #define UNC_READ_SEED_OVERFLOW 2u      /* per-event seed list exhausted: result for this read is invalid */
+#define UNC_READ_NORM_FULL 4u          /* chunked path: >= 6000 unread events (the reference's #SKIP branch, mapper.cpp:336-351) */
 
 /* One PAF record's worth of coordinates (Paf, read_buffer.hpp:42-126; set by Mapper::set_ref_loc,
  * mapper.cpp:708-728) plus the work counters of SURVEY.md section 8(d). */
@@ -161,6 +162,42 @@ int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_ma
 /* shader-clock cycles summed over the reads of the last batch, per k_map phase:
  * [0] match probs, [1] extension, [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed, [7] rest */
 int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8);
+
+/* ---- chunked (realtime) path: replaces RealtimePool + per-channel Mapper::new_read(Chunk&) / add_chunk /
+ * process_chunk / map_chunk (realtime_pool.cpp:74-142,349-358; mapper.cpp:210-431) with the deterministic
+ * semantics of MapPoolOrd (map_pool_ord.cpp:61-112; timeouts disabled as Conf(Mode::MAP_ORD), conf.hpp:88-91):
+ * one call processes at most one chunk per channel and maps every chunk completely before returning, so a
+ * caller adds the next chunk of a read only after the previous one is mapped.  Per-channel state (streaming
+ * event detector, EventProfiler window, rolling Normalizer -- which survives across reads, mapper.cpp:225-226 --
+ * path buffers, seed clusters) stays resident in HBM between calls. */
+#define UNC_RT_FIRST 1u   /* first chunk of a read: Mapper::new_read(Chunk&) (mapper.cpp:210-217) */
+#define UNC_RT_LAST 2u    /* no chunk follows: a read still unmapped afterwards is given up (request_reset, realtime_pool.cpp:115-123) */
+typedef struct {
+    uint32_t channel;       /* 0-based channel index (Chunk::get_channel_idx) */
+    uint32_t read_number;   /* Chunk::get_number */
+    uint32_t flags;         /* UNC_RT_FIRST | UNC_RT_LAST */
+    uint32_t n_samples;     /* <= chunk_time * sample_rate (4000) */
+    uint64_t offset;        /* first sample in `raw` */
+    unc_calib_t calib;      /* the channel's calibration */
+    uint32_t pad;
+} unc_rt_chunk_t;
+#define UNC_RT_MAPPING 0    /* chunk fully mapped, read not decided yet (Mapper::chunk_mapped) */
+#define UNC_RT_MAPPED 1     /* State::SUCCESS: hit holds the PAF record */
+#define UNC_RT_FAILED 2     /* State::FAILURE (max_events, max_chunks, or given up): hit holds the unmapped record */
+#define UNC_RT_IGNORED 3    /* chunk of a read this channel is not mapping (already finished / never started) */
+typedef struct {
+    int32_t state;
+    int32_t ended;          /* Paf::is_ended (set_ended, mapper.cpp:389) */
+    unc_hit_t hit;
+} unc_rt_result_t;
+typedef struct unc_rt unc_rt_t;
+int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint32_t n_channels, unc_rt_t **out);
+void unc_rt_free(unc_rt_t *rt);
+uint64_t unc_rt_device_bytes(const unc_rt_t *rt);
+/* raw: int16 samples (host, or device when on_device != 0); chunks/results: host arrays of n_chunks */
+int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, int on_device,
+                          void *stream, unc_rt_result_t *results);
+int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *ms_map);
 
 /* ---- stage taps (parity tests) */
 /* event detection + whole-read normalisation only (EventDetector::get_means, event_detector.cpp:133-145;

@@ -63,6 +63,8 @@ def lib():
         L.unc_o_mapper_free.argtypes = [vp]
         L.unc_o_map_read.argtypes = [vp, vp, u32, vp]
         L.unc_o_map_batch.argtypes = [vp, C.POINTER(Params), C.c_int, u32, vp, vp, vp]; L.unc_o_map_batch.restype = C.c_double
+        L.unc_o_chunk_read.argtypes = [vp, vp, u32, u32, vp, u32p]
+        L.unc_o_set_max_chunks.argtypes = [vp, u32]
         L.unc_o_trace_begin.argtypes = [vp, vp, u32]
         L.unc_o_trace_step.argtypes = [vp]
         L.unc_o_trace_paths.argtypes = [vp, vp, u32]; L.unc_o_trace_paths.restype = u32
@@ -188,6 +190,16 @@ class Mapper:
         hit = np.zeros(1, dtype=O_HIT)
         lib().unc_o_map_read(self.h, sig.ctypes.data, sig.size, hit.ctypes.data)
         return hit[0]
+
+    def chunk_read(self, signal_f32, chunk_len=4000):
+        sig = np.ascontiguousarray(signal_f32, dtype=np.float32)
+        hit = np.zeros(1, dtype=O_HIT)
+        used = C.c_uint32()
+        lib().unc_o_chunk_read(self.h, sig.ctypes.data, sig.size, chunk_len, hit.ctypes.data, C.byref(used))
+        return hit[0], used.value
+
+    def set_max_chunks(self, n):
+        lib().unc_o_set_max_chunks(self.h, n)
 
     def stats(self):
         a, b, d = C.c_uint64(), C.c_uint64(), C.c_uint64()

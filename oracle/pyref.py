@@ -55,6 +55,8 @@ def lib():
         L.ref_map_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RefHit)]
         L.ref_map_batch.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_map_batch.restype = C.c_double
+        L.ref_chunk_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RefHit), C.POINTER(C.c_uint32)]
+        L.ref_set_max_chunks.argtypes = [C.c_uint32]
         L.ref_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.ref_events.restype = C.c_uint32
         L.ref_norm_levels.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -118,6 +120,12 @@ class Mapper:
         hit = RefHit()
         lib().ref_map_read(self.h, sig.ctypes.data, sig.size, C.byref(hit))
         return hit
+
+    def chunk_read(self, signal_f32, chunk_len=4000, number=0):
+        sig = np.ascontiguousarray(signal_f32, dtype=np.float32)
+        hit, used = RefHit(), C.c_uint32()
+        lib().ref_chunk_read(self.h, sig.ctypes.data, sig.size, chunk_len, number, C.byref(hit), C.byref(used))
+        return hit, used.value
 
     def trace(self, signal_f32, max_paths=10000, max_clusters=1 << 16):
         """Generator: after each map_next() yields (done, event_i, paths, clusters, max_map, len_sum, n_lens)."""

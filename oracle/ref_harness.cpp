@@ -124,6 +124,50 @@ double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, cons
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// One read through the Mapper's chunk API the way MapPoolOrd drives it (map_pool_ord.cpp:61-112 ->
+// RealtimePool::try_add_chunk realtime_pool.cpp:112-142 -> MapperThread::run :349-358), single threaded.
+int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,
+                   uint32_t *chunks_used) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    Mapper::PRMS.chunk_timeout = FLT_MAX;   // Conf(Mode::MAP_ORD), conf.hpp:88-91
+    Mapper::PRMS.evt_timeout = FLT_MAX;
+    std::vector<float> sig(signal, signal + n);
+    std::string id = "read" + std::to_string(number);
+    minibwa_counters_reset();
+    uint32_t used = 0;
+    bool done = false;
+    for (uint32_t ci = 0;; ++ci) {
+        uint32_t st = ci * chunk_len, ln = chunk_len;        // ReadBuffer::get_chunk, read_buffer.cpp:303-318
+        if (st > sig.size()) st = sig.size();
+        if (st + ln > sig.size()) ln = sig.size() - st;
+        Chunk chunk(id, 1, number, st, sig, st, ln);
+        if (chunk.empty() && ci > 0) {
+            if (m->chunk_mapped() && !m->finished()) m->request_reset();
+        } else if (ci == 0) {
+            m->new_read(chunk);
+            used++;
+        } else {
+            if (!m->add_chunk(chunk)) break;
+            used++;
+        }
+        for (;;) {
+            m->process_chunk();
+            if (m->map_chunk()) { done = true; break; }
+            if (m->chunk_mapped()) break;
+        }
+        if (done) break;
+    }
+    fill_hit(m, m->get_read().loc_, out);
+    minibwa_counters_t c;
+    minibwa_counters_get(&c);
+    out->n_nbr = c.n_2occ; out->n_sa = c.n_sa; out->n_lf = c.n_lf;
+    m->deactivate();
+    if (chunks_used) *chunks_used = used;
+    return 0;
+}
+
+void ref_set_max_chunks(uint32_t max_chunks) { ReadBuffer::PRMS.max_chunks = max_chunks; }
+
 uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events) {
     EventDetector ed(Mapper::PRMS.event_prms);
     std::vector<float> raw(signal, signal + n);

@@ -55,6 +55,11 @@ int ref_map_read(void *m, const float *signal, uint32_t n, ref_hit_t *out);
  * (BASELINE.md "B1").  Returns wall seconds of the mapping loop. */
 double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out);
 
+/* chunked path: one read through new_read(Chunk)/add_chunk/process_chunk/map_chunk on this Mapper (= channel) */
+int ref_chunk_read(void *m, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,
+                   uint32_t *chunks_used);
+void ref_set_max_chunks(uint32_t max_chunks);
+
 /* stage taps */
 uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events);
 void ref_norm_levels(const float *means, uint32_t m, float *levels, float *scale, float *shift);

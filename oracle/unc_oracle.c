@@ -573,6 +573,138 @@ static cluster_t tracker_get_final(const tracker_t *t) {
     return NULL_ALN;
 }
 
+/* ------------------------------------------------------------------ chunked (realtime / MAP_ORD) path */
+
+#define NORM_LEN 6000     /* Normalizer::PRMS_DEF.len, normalizer.cpp:4-8 */
+#define PROF_WIN 25       /* EventProfiler::PRMS_DEF.win_len, event_profiler.cpp:4-10 */
+
+/* Normalizer in rolling mode: reset normalizer.cpp:84-95, push 46-75, pop 120-128, unread_size 131-134,
+ * skip_unread 136-152, get_mean/get_stdv 97-103 */
+typedef struct {
+    float *signal;
+    uint32_t size;
+    double mean, varsum;
+    uint32_t n, rd, wr;
+    int is_full, is_empty;
+} rnorm_t;
+
+static void rnorm_init(rnorm_t *r, uint32_t size) {
+    r->signal = (float *)calloc(size, sizeof(float));
+    r->size = size;
+    r->n = r->rd = r->wr = 0;
+    r->mean = r->varsum = 0;
+    r->is_full = 0;
+    r->is_empty = 1;
+}
+static void rnorm_reset(rnorm_t *r) {
+    r->n = r->rd = r->wr = 0;
+    r->mean = r->varsum = 0;
+    r->is_full = 0;
+    r->is_empty = 1;
+    r->signal[0] = 0;
+}
+static int rnorm_push(rnorm_t *r, float newevt) {
+    if (r->is_full) return 0;
+    double oldevt = (double)r->signal[r->wr];
+    r->signal[r->wr] = newevt;
+    if (r->n == r->size) {
+        double oldmean = r->mean;
+        r->mean += ((double)newevt - oldevt) / (double)r->size;
+        r->varsum += ((double)newevt + oldevt - oldmean - r->mean) * ((double)newevt - oldevt);
+    } else {
+        r->n++;
+        double dt1 = (double)newevt - r->mean;
+        r->mean += dt1 / (double)r->n;
+        double dt2 = (double)newevt - r->mean;
+        r->varsum += dt1 * dt2;
+    }
+    r->wr = (r->wr + 1) % r->size;
+    r->is_empty = 0;
+    r->is_full = r->wr == r->rd;
+    return 1;
+}
+static uint32_t rnorm_unread(const rnorm_t *r) {
+    if (r->rd < r->wr) return r->wr - r->rd;
+    return (r->n - r->rd) + r->wr;
+}
+static float rnorm_at(const rnorm_t *r, float tgt_mean, float tgt_stdv, uint32_t i) {
+    float scale = (float)((double)tgt_stdv / sqrt(r->varsum / (double)r->n));
+    float shift = (float)((double)tgt_mean - (double)scale * r->mean);
+    float prod = scale * r->signal[i];
+    return prod + shift;
+}
+static void rnorm_pop_advance(rnorm_t *r) {
+    r->rd = (r->rd + 1) % r->size;
+    r->is_empty = r->rd == r->wr;
+    r->is_full = 0;
+}
+static uint32_t rnorm_skip_unread(rnorm_t *r, uint32_t nkeep) {
+    if (nkeep >= rnorm_unread(r)) return 0;
+    r->is_full = 0;
+    r->is_empty = nkeep == 0;
+    uint32_t new_rd;
+    if (nkeep <= r->wr) new_rd = r->wr - nkeep;
+    else new_rd = r->n - (nkeep - r->wr);
+    uint32_t nskip;
+    if (new_rd > r->rd) nskip = new_rd - r->rd;
+    else nskip = (r->n - r->rd) + new_rd;
+    r->rd = new_rd;
+    return nskip;
+}
+
+/* EventProfiler, event_profiler.hpp:35-104 (a 25-long rolling Normalizer + a deque of the same events) */
+typedef struct {
+    rnorm_t window;
+    float evq[PROF_WIN + 1];
+    uint32_t q_head, q_len;
+    float next_mean;
+    int is_full;
+    uint32_t to_mask;
+    float win_stdv_min;
+} evprof_t;
+
+static void evprof_reset(evprof_t *p) {
+    rnorm_reset(&p->window);
+    p->q_head = p->q_len = 0;
+    p->next_mean = 0;
+    p->is_full = 0;
+    p->to_mask = 0;
+}
+
+/* returns event_ready() */
+static int evprof_add_event(evprof_t *p, float mean) {
+    rnorm_push(&p->window, mean);
+    p->evq[(p->q_head + p->q_len) % (PROF_WIN + 1)] = mean;
+    p->q_len++;
+    if (rnorm_unread(&p->window) <= PROF_WIN / 2) return 0;
+    float win_stdv = (float)sqrt(p->window.varsum / (double)p->window.n);   /* Normalizer::get_stdv */
+    if (win_stdv < p->win_stdv_min) {
+        p->to_mask = PROF_WIN - 1;
+    } else if (p->to_mask > 0) {
+        p->to_mask--;
+    }
+    if (p->window.is_full) {
+        p->next_mean = p->evq[p->q_head];
+        p->q_head = (p->q_head + 1) % (PROF_WIN + 1);
+        p->q_len--;
+        rnorm_pop_advance(&p->window);     /* window_.pop(): the value is discarded */
+        p->is_full = 1;
+    }
+    return p->is_full && p->to_mask == 0;
+}
+
+typedef struct {
+    rnorm_t norm;
+    evprof_t prof;
+    int inited;
+    /* ReadBuffer chunk bookkeeping, read_buffer.cpp:248-292 */
+    uint64_t raw_len;
+    uint32_t chunk_count;
+    int chunk_processed, finished, ended, active;
+    const float *chunk;
+    uint32_t chunk_n;
+} rt_state_t;
+
 /* ------------------------------------------------------------------ mapper */
 
 typedef struct {
@@ -605,6 +737,9 @@ struct unc_o_mapper {
     minibwa_counters_t c0;
     uint64_t stat_parents, stat_children, stat_seeds;
     uint32_t stat_max_children;
+    int rt_mode, reset_req;
+    uint32_t max_chunks;
+    rt_state_t rt;
 };
 
 unc_o_mapper_t *unc_o_mapper_new(const unc_o_index_t *ix, const unc_o_params_t *p) {
@@ -628,6 +763,7 @@ void unc_o_mapper_free(unc_o_mapper_t *m) {
     if (!m) return;
     free(m->prev_paths); free(m->next_paths); free(m->sort_tmp);
     free(m->norm.signal); free(m->tracker.clusters); free(m->tracker.lens); free(m->means);
+    if (m->rt.inited) { free(m->rt.norm.signal); free(m->rt.prof.window.signal); }
     free(m);
 }
 
@@ -750,9 +886,15 @@ static void set_ref_loc(unc_o_mapper_t *m, const cluster_t *seeds) {
 static int map_next(unc_o_mapper_t *m) {
     const unc_o_index_t *ix = m->ix;
     const uint32_t max_paths = m->P.max_paths;
-    if (m->norm.is_empty || m->event_i >= m->P.max_events) return 1; /* State::FAILURE */
-
-    float event = norm_pop(&m->norm);
+    float event;
+    if (m->rt_mode) {   /* rolling normaliser of the chunked path (persists across reads, mapper.cpp:225-226) */
+        if (m->rt.norm.is_empty || m->reset_req || m->event_i >= m->P.max_events) return 1;
+        event = rnorm_at(&m->rt.norm, m->norm.tgt_mean, m->norm.tgt_stdv, m->rt.norm.rd);
+        rnorm_pop_advance(&m->rt.norm);
+    } else {
+        if (m->norm.is_empty || m->event_i >= m->P.max_events) return 1; /* State::FAILURE */
+        event = norm_pop(&m->norm);
+    }
     for (uint32_t k = 0; k < UNC_O_NKMER; ++k) m->kmer_probs[k] = match_prob(m->model, event, k);
     const float *kp = m->kmer_probs;
     const float source_prob = ix->prob_threshes[0]; /* mapper.cpp:169-171 */
@@ -947,6 +1089,154 @@ void unc_o_stats(const unc_o_mapper_t *m, uint64_t *sum_parents, uint64_t *sum_c
     if (sum_children) *sum_children = m->stat_children;
     if (max_children) *max_children = m->stat_max_children;
     if (n_seeds) *n_seeds = m->stat_seeds;
+}
+
+/* ---- Mapper's chunk API, mapper.cpp:210-431, driven the way MapPoolOrd does (map_pool_ord.cpp:61-112 +
+ * realtime_pool.cpp:112-142,349-358): a chunk is added only after the previous one is fully mapped, timeouts are
+ * infinite (conf.hpp:88-91), an exhausted read is given up with request_reset(). */
+
+static void rt_set_failed(unc_o_mapper_t *m) { m->rt.finished = 1; m->reset_req = 0; }
+
+static void rt_new_read(unc_o_mapper_t *m, const float *chunk, uint32_t n) {
+    if (!m->rt.inited) {
+        rnorm_init(&m->rt.norm, NORM_LEN);
+        rnorm_init(&m->rt.prof.window, PROF_WIN);
+        rnorm_reset(&m->rt.norm);
+        m->rt.prof.win_stdv_min = 5.0f;
+        m->rt.inited = 1;
+    }
+    /* Mapper::reset, mapper.cpp:219-246 */
+    m->prev_size = 0;
+    m->event_i = 0;
+    m->reset_req = 0;
+    m->state_success = 0;
+    rnorm_skip_unread(&m->rt.norm, 0);
+    tracker_reset(&m->tracker);
+    evdt_reset(&m->evdt);
+    evprof_reset(&m->rt.prof);
+    memset(&m->hit, 0, sizeof m->hit);
+    m->hit.rid = -1;
+    minibwa_counters_get(&m->c0);
+    m->stat_parents = m->stat_children = m->stat_seeds = 0;
+    m->stat_max_children = 0;
+    /* ReadBuffer(Chunk&), read_buffer.cpp:248-260 */
+    m->rt.chunk_count = 1;
+    m->rt.chunk_processed = 0;
+    m->rt.finished = m->rt.ended = 0;
+    m->rt.raw_len = n;
+    m->rt.chunk = chunk;
+    m->rt.chunk_n = n;
+    m->rt.active = 1;
+}
+
+/* Mapper::add_chunk 281-305 + ReadBuffer::add_chunk read_buffer.cpp:268-281 */
+static int rt_add_chunk(unc_o_mapper_t *m, const float *chunk, uint32_t n) {
+    if (!m->rt.chunk_processed || m->rt.finished || m->reset_req) return 0;
+    if (m->rt.chunk_count >= m->max_chunks) { rt_set_failed(m); return 1; }
+    m->rt.chunk_processed = 0;
+    m->rt.chunk_count++;
+    m->rt.raw_len += n;
+    m->rt.chunk = chunk;
+    m->rt.chunk_n = n;
+    return 1;
+}
+
+/* Mapper::process_chunk 307-367 */
+static uint32_t rt_process_chunk(unc_o_mapper_t *m) {
+    if (m->rt.chunk_processed || m->reset_req) return 0;
+    uint32_t nevents = 0;
+    for (uint32_t i = 0; i < m->rt.chunk_n; ++i) {
+        if (evdt_add_sample(&m->evdt, m->rt.chunk[i])) {
+            if (!evprof_add_event(&m->rt.prof, m->evdt.event.mean)) continue;
+            float evt_mean = m->rt.prof.next_mean;
+            if (!rnorm_push(&m->rt.norm, evt_mean)) {
+                uint32_t nskip = rnorm_skip_unread(&m->rt.norm, nevents);
+                m->event_i += nskip;   /* skip_events, :256-259 */
+                m->prev_size = 0;
+                if (!rnorm_push(&m->rt.norm, evt_mean)) return nevents;
+            }
+            nevents++;
+        }
+    }
+    m->rt.chunk_n = 0;
+    m->rt.chunk_processed = 1;
+    return nevents;
+}
+
+static int rt_chunk_mapped(const unc_o_mapper_t *m) { return m->rt.chunk_processed && m->rt.norm.is_empty; }
+
+/* Mapper::map_chunk 381-431 with chunk_timeout = evt_timeout = FLT_MAX */
+static int rt_map_chunk(unc_o_mapper_t *m) {
+    if (m->reset_req || m->event_i >= m->P.max_events) {
+        rt_set_failed(m);
+        m->rt.ended = 1;
+        return 1;
+    } else if (m->rt.norm.is_empty && m->rt.chunk_processed && m->rt.chunk_count >= m->max_chunks) {
+        rt_set_failed(m);
+        return 1;
+    }
+    if (m->rt.norm.is_empty) return 0;
+    uint32_t nevents = 5;   /* evt_batch_size, mapper.cpp:38,173-177 */
+    if (m->event_i + nevents > m->P.max_events) nevents = m->P.max_events - m->event_i;
+    for (uint32_t i = 0; i < nevents && !m->rt.norm.is_empty; ++i) {
+        if (map_next(m)) {
+            rnorm_skip_unread(&m->rt.norm, 0);
+            m->rt.finished = 1;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+void unc_o_set_max_chunks(unc_o_mapper_t *m, uint32_t max_chunks) { m->max_chunks = max_chunks; }
+
+/* One read on this mapper (= one channel), chunk by chunk.  chunks_used: chunks handed to the mapper. */
+int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_t chunk_len, unc_o_hit_t *out,
+                     uint32_t *chunks_used) {
+    m->rt_mode = 1;
+    if (m->max_chunks == 0) m->max_chunks = 1000000;   /* ReadBuffer::PRMS.max_chunks */
+    uint32_t used = 0, ci = 0;
+    int done = 0;
+    for (;; ++ci) {
+        uint64_t st = (uint64_t)ci * chunk_len;
+        if (st > n) st = n;
+        uint32_t ln = (uint32_t)((st + chunk_len > n) ? n - st : chunk_len);   /* ReadBuffer::get_chunk, read_buffer.cpp:303-318 */
+        if (ln == 0 && ci > 0) {
+            /* RealtimePool::try_add_chunk on an empty chunk, realtime_pool.cpp:115-123 */
+            if (rt_chunk_mapped(m) && !m->rt.finished) m->reset_req = 1;
+        } else if (ci == 0) {
+            rt_new_read(m, signal + st, ln);
+            used++;
+        } else {
+            if (!rt_add_chunk(m, signal + st, ln)) break;   /* cannot happen in ordered mode */
+            used++;
+        }
+        for (;;) {   /* RealtimePool::MapperThread::run, realtime_pool.cpp:349-358 */
+            rt_process_chunk(m);
+            if (rt_map_chunk(m)) { done = 1; break; }
+            if (rt_chunk_mapped(m)) break;
+        }
+        if (done) break;
+    }
+    /* result: read_.loc_ */
+    unc_o_hit_t *h = &m->hit;
+    if (!m->state_success) {
+        float bp_per_samp = m->P.bp_per_sec / m->P.sample_rate;
+        h->rd_len = (uint64_t)((float)m->rt.raw_len * bp_per_samp);
+    }
+    h->n_events = m->evdt.total_events;
+    h->event_i = m->event_i;
+    h->mean_event_len = m->evdt.total_events ? evdt_mean_event_len(&m->evdt) : 0.0f;
+    minibwa_counters_t c1;
+    minibwa_counters_get(&c1);
+    h->n_nbr = c1.n_2occ - m->c0.n_2occ;
+    h->n_sa = c1.n_sa - m->c0.n_sa;
+    h->n_lf = c1.n_lf - m->c0.n_lf;
+    *out = *h;
+    if (chunks_used) *chunks_used = used;
+    m->rt.active = 0;
+    m->rt_mode = 0;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ threaded batch (cpu_baseline "port") */

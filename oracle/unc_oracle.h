@@ -97,6 +97,12 @@ int unc_o_map_read(unc_o_mapper_t *m, const float *signal, uint32_t n, unc_o_hit
 double unc_o_map_batch(const unc_o_index_t *ix, const unc_o_params_t *p, int n_threads, uint32_t n_reads,
                        const float *signals, const uint64_t *offsets, unc_o_hit_t *out);
 
+/* chunked (realtime / MAP_ORD) path: one read fed to this mapper chunk by chunk; the rolling normaliser persists
+ * across reads on the same mapper (= channel), mapper.cpp:225-226 */
+void unc_o_set_max_chunks(unc_o_mapper_t *m, uint32_t max_chunks);
+int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_t chunk_len, unc_o_hit_t *out,
+                     uint32_t *chunks_used);
+
 /* step-wise trace */
 void unc_o_trace_begin(unc_o_mapper_t *m, const float *signal, uint32_t n);
 int unc_o_trace_step(unc_o_mapper_t *m);

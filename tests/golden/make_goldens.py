@@ -44,6 +44,16 @@ def main():
         hh = m.map_read(pyref.calibrate(raw, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION))
         hits.append(hit_tuple(hh))
         mels.append(hh.mean_event_len)
+    # chunked path (Mapper::new_read(Chunk)/add_chunk/process_chunk/map_chunk as MapPoolOrd drives it), all reads
+    # one after the other on ONE Mapper = one channel, so the rolling normaliser carries over between reads
+    cm = pyref.Mapper()
+    chunk_hits, chunk_used = [], []
+    hh, used = cm.chunk_read(sig, 4000, 0)
+    chunk_hits.append(hit_tuple(hh)); chunk_used.append(used)
+    for i in range(30):
+        raw = sim["signal"][int(sim["offsets"][i]):int(sim["offsets"][i + 1])]
+        hh, used = cm.chunk_read(pyref.calibrate(raw, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION), 4000, i + 1)
+        chunk_hits.append(hit_tuple(hh)); chunk_used.append(used)
     kr = pyref.kmer_ranges()
     a, b, c, mm, ms = pyref.model_tables()
     np.savez_compressed(
@@ -53,6 +63,7 @@ def main():
         ex_hit=hit_tuple(h), ex_hit_mel=np.float32(h.mean_event_len),
         sim_signal=sim["signal"], sim_offsets=sim["offsets"], sim_contig=sim["contig"], sim_pos=sim["pos"],
         sim_strand=sim["strand"], sim_hits=np.stack(hits), sim_mel=np.array(mels, dtype=np.float32),
+        chunk_hits=np.stack(chunk_hits), chunk_used=np.array(chunk_used, dtype=np.int64),
         kmer_ranges=kr, thresholds=pyref.thresholds(), model_means=a, model_vars_x2=b, model_lognorm=c,
         model_mean=np.float32(mm), model_stdv=np.float32(ms),
         hit_fields=np.array(["mapped", "fwd", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "rf_len", "matches",

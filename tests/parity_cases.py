@@ -147,3 +147,50 @@ def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens):
     assert steps > 100
     dh, oh = m.trace_finish(), om.trace_finish()
     assert_hits_equal([dh], [oh], "trace")
+
+
+def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, n_reads=9, max_chunks=None):
+    """Config 5's path: reads replayed chunk by chunk over a few channels (MapPoolOrd semantics) through
+    unc_rt_process_chunks; per-channel state persists across chunks AND reads.  Checked against the oracle fed the
+    same reads in the same per-channel order, and (default max_chunks, channel 0 order) against the reference goldens."""
+    from uncalled_amd.realtime import MapPoolOrd
+    po = oracle_lib
+    dev_index = _index(lib, example)
+    oix = po.Index(example["prefix"])
+    p = capi.default_params(lib)
+    if max_chunks:
+        p.max_chunks = max_chunks
+    pool = MapPoolOrd(dev_index, n_channels=n_channels, params=p)
+    off = goldens["sim_offsets"]
+    reads = [(example["signal"], (example["range"], example["offset"], example["digitisation"]))]
+    for i in range(n_reads - 1):
+        reads.append((goldens["sim_signal"][int(off[i]):int(off[i + 1])], (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)))
+    oms = [po.Mapper(oix) for _ in range(n_channels)]
+    for om in oms:
+        if max_chunks:
+            om.set_max_chunks(max_chunks)
+    want = {}
+    for i, (raw, cal) in enumerate(reads):
+        ch = i % n_channels
+        pool.add_read(ch, i, raw, cal, key=i)
+        want[i] = oms[ch].chunk_read(po.calibrate(raw, *cal), 4000)[0]
+    got = {}
+    rounds = 0
+    while pool.running():
+        for key, r in pool.update():
+            got[key] = r
+        rounds += 1
+        assert rounds < 1000
+    names = dev_index.seq_names()
+    for i in range(len(reads)):
+        h, o = got[i]["hit"], want[i]
+        assert int(h["status"]) == 0
+        assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), i
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+            assert int(h[f]) == int(o[f]), (i, f)
+        assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), i
+    if n_channels == 1 and not max_chunks:
+        f = {str(n): j for j, n in enumerate(goldens["hit_fields"])}
+        for i in range(len(reads)):
+            for name in ("mapped", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_lf"):
+                assert int(got[i]["hit"][name]) == int(goldens["chunk_hits"][i][f[name]]), (i, name)

@@ -43,6 +43,11 @@ def test_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
     pc.case_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
 
 
+@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 31, None), (3, 31, None), (2, 8, 2)])
+def test_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks):
+    pc.case_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
+
+
 @pytest.fixture(scope="module")
 def ecoli(tmp_path_factory):
     """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (tools/build_index.py)."""

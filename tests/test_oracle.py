@@ -161,3 +161,45 @@ def test_oracle_trace_equals_live_reference(oracle_lib, ref_lib, example, golden
             assert omm == rmm
         steps += 1
     assert steps == 178
+
+
+CHUNK_FIELDS = ("mapped", "fwd", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "rf_len", "matches", "event_i", "n_nbr", "n_sa", "n_lf")
+
+
+def _chunk_signals(oracle_lib, goldens):
+    po = oracle_lib
+    off = goldens["sim_offsets"]
+    return [goldens["ex_calibrated"]] + [
+        po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION) for i in range(30)]
+
+
+def test_chunked_path_matches_golden(oracle_lib, example, goldens):
+    """Mapper's chunk API (rolling normaliser, EventProfiler, 5-event batches) on one channel, 31 reads in a row."""
+    po = oracle_lib
+    ix = po.Index(example["prefix"])
+    om = po.Mapper(ix)
+    f = {str(n): j for j, n in enumerate(goldens["hit_fields"])}
+    for i, sig in enumerate(_chunk_signals(po, goldens)):
+        h, used = om.chunk_read(sig, 4000)
+        for name in CHUNK_FIELDS:
+            assert int(h[name]) == int(goldens["chunk_hits"][i][f[name]]), (i, name)
+        assert used == int(goldens["chunk_used"][i]), i
+    # the survey's probe of the chunk path on the example read: 67 41 67 - ... 6948 6977 29 30, 107 events
+    g0 = goldens["chunk_hits"][0]
+    assert (g0[f["rd_len"]], g0[f["rd_st"]], g0[f["rd_en"]], g0[f["rf_st"]], g0[f["rf_en"]], g0[f["matches"]], g0[f["event_i"]]) == \
+        (67, 41, 67, 6948, 6977, 29, 107)
+
+
+@pytest.mark.parametrize("max_chunks", [1000000, 2])
+def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, goldens, max_chunks):
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    pr.lib().ref_set_max_chunks(max_chunks)
+    ix = po.Index(example["prefix"])
+    om, rm = po.Mapper(ix), pr.Mapper()
+    om.set_max_chunks(max_chunks)
+    for i, sig in enumerate(_chunk_signals(po, goldens)[:12]):
+        (h, hu), (r, ru) = om.chunk_read(sig, 4000), rm.chunk_read(sig, 4000, i)
+        assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), i
+        assert (hu, int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (ru, r.event_i, r.n_nbr, r.n_sa, r.n_lf), i
+    pr.lib().ref_set_max_chunks(1000000)

@@ -51,6 +51,12 @@ PATH = np.dtype([("fm_start", "<u8"), ("fm_end", "<u8"), ("event_moves", "<u4"),
 CLUSTER = np.dtype([("ref_st", "<u8"), ("ref_en_start", "<u8"), ("ref_en_end", "<u8"),
                     ("evt_st", "<u4"), ("evt_en", "<u4"), ("total_len", "<u4"), ("pad", "<u4")])
 
+RT_CHUNK = np.dtype([("channel", "<u4"), ("read_number", "<u4"), ("flags", "<u4"), ("n_samples", "<u4"), ("offset", "<u8"),
+                     ("calib", CALIB), ("pad", "<u4")])
+RT_RESULT = np.dtype([("state", "<i4"), ("ended", "<i4"), ("hit", HIT)])
+RT_FIRST, RT_LAST = 1, 2
+RT_MAPPING, RT_MAPPED, RT_FAILED, RT_IGNORED = 0, 1, 2, 3
+
 _libs = {}
 
 
@@ -94,6 +100,11 @@ def load(path=None):
     L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_detect_events.argtypes = [vp, u32, vp, vp, vp, vp, u64, vp, vp]
+    L.unc_rt_create.argtypes = [vp, C.POINTER(Params), u32, C.POINTER(vp)]
+    L.unc_rt_free.argtypes = [vp]
+    L.unc_rt_device_bytes.argtypes = [vp]; L.unc_rt_device_bytes.restype = u64
+    L.unc_rt_process_chunks.argtypes = [vp, u32, vp, vp, C.c_int, vp, vp]
+    L.unc_rt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_trace_begin.argtypes = [vp, vp, u32, vp]
     L.unc_trace_step.argtypes = [vp, u32, C.POINTER(C.c_int)]
     L.unc_trace_paths.argtypes = [vp, vp, u32, C.POINTER(u32)]
@@ -285,3 +296,45 @@ class Mapper:
         hit = np.zeros(1, dtype=HIT)
         _check(self.L, self.L.unc_trace_finish(self.h, hit.ctypes.data))
         return hit[0]
+
+
+class Realtime:
+    """Chunked path: RealtimePool + one Mapper per channel with MapPoolOrd's deterministic semantics
+    (realtime_pool.cpp:74-142,349-358; map_pool_ord.cpp:61-112)."""
+
+    def __init__(self, index, n_channels=512, params=None):
+        self.index = index
+        self.L = index.L
+        self.params = params or default_params(self.L)
+        self.n_channels = n_channels
+        h = C.c_void_p()
+        _check(self.L, self.L.unc_rt_create(index.h, C.byref(self.params), n_channels, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.unc_rt_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def device_bytes(self):
+        return self.L.unc_rt_device_bytes(self.h)
+
+    def process_chunks(self, chunks, raw_i16=None, raw_ptr=None, stream=None):
+        """chunks: RT_CHUNK array (at most one per channel); raw: host int16 array or a device address."""
+        ch = np.ascontiguousarray(chunks, dtype=RT_CHUNK)
+        res = np.zeros(ch.size, dtype=RT_RESULT)
+        if raw_ptr is not None:
+            ptr, on_dev = C.c_void_p(raw_ptr), 1
+        else:
+            raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
+            ptr, on_dev = C.c_void_p(raw.ctypes.data), 0
+        _check(self.L, self.L.unc_rt_process_chunks(self.h, ch.size, ch.ctypes.data, ptr, on_dev, C.c_void_p(stream or 0),
+                                                    res.ctypes.data))
+        return res
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        self.L.unc_rt_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value

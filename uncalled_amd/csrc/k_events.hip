@@ -177,8 +177,167 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P) {
 
 }  // namespace unc
 
+namespace unc {
+// ---------------------------------------------------------------------------------------------------
+// Chunked (realtime / MAP_ORD) path: Mapper::process_chunk (mapper.cpp:307-367) for one chunk per channel,
+// one lane per channel, with the per-channel state a Mapper keeps between chunks held in HBM (RtChan):
+// the streaming detector, the 25-event EventProfiler window (event_profiler.hpp:71-104: events are released
+// 24 late and masked while the window's stdv < 5) and the rolling 6000-event Normalizer
+// (normalizer.cpp:46-75), which deliberately survives across reads (mapper.cpp:225-226).
+__device__ __forceinline__ bool roll_push(float *signal, uint32_t size, double &mean, double &varsum, uint32_t &n, uint32_t &rd,
+                                          uint32_t &wr, uint32_t &full, float newevt) {
+    if (full) return false;
+    const double oldevt = (double)signal[wr];
+    signal[wr] = newevt;
+    if (n == size) {
+        const double oldmean = mean;
+        mean += ((double)newevt - oldevt) / (double)size;
+        varsum += ((double)newevt + oldevt - oldmean - mean) * ((double)newevt - oldevt);
+    } else {
+        n++;
+        const double dt1 = (double)newevt - mean;
+        mean += dt1 / (double)n;
+        const double dt2 = (double)newevt - mean;
+        varsum += dt1 * dt2;
+    }
+    wr = wr + 1 == size ? 0 : wr + 1;
+    full = wr == rd ? 1u : 0u;
+    return true;
+}
+__device__ __forceinline__ uint32_t roll_unread(uint32_t n, uint32_t rd, uint32_t wr) {
+    return rd < wr ? wr - rd : (n - rd) + wr;   // Normalizer::unread_size, normalizer.cpp:131-134
+}
+
+__global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans,
+                                                  float *norm_ring, unc_params_t P, float tgt_mean, float tgt_stdv,
+                                                  unc_evt_info_t *info, uint32_t *ring0_out) {
+    __shared__ double s_sum[RING * WAVE];
+    __shared__ double s_sumsq[RING * WAVE];
+    const int lane = lane_id();
+    const uint32_t ci = blockIdx.x * WAVE + lane;
+    if (ci >= n_chunks) return;   // no collectives in this kernel
+    const RtChunkDesc cd = chunks[ci];
+    RtChan *C = chans + cd.channel;
+    float *ring = norm_ring + (size_t)cd.channel * NORM_LEN;
+
+    // ---- load (or reset) the per-channel state
+    uint32_t t, evt_st, total_events, n_pushed, ring0, status = 0;
+    double evt_st_sum, evt_st_sumsq;
+    float len_sum;
+    Detector sd, ld;
+    double n_mean = C->n_mean, n_varsum = C->n_varsum;
+    uint32_t n_n = C->n_n, n_rd = C->n_rd, n_wr = C->n_wr, n_full = C->n_full;
+    double pw_mean, pw_varsum;
+    uint32_t pw_n, pw_rd, pw_wr, pw_full, q_head, q_len, prof_full, to_mask;
+    if (cd.new_read) {
+        // Mapper::reset (mapper.cpp:219-246): evdt_.reset(), evt_prof_.reset(), norm_.skip_unread()
+        s_sum[lane] = 0.0; s_sumsq[lane] = 0.0;
+        t = 1; evt_st = 0; total_events = 0; evt_st_sum = evt_st_sumsq = 0.0; len_sum = 0.0f;
+        sd = Detector{P.threshold1, P.window_length1, 0u, -1, FLT_MAX, false};
+        ld = Detector{P.threshold2, P.window_length2, 0u, -1, FLT_MAX, false};
+        pw_mean = pw_varsum = 0.0; pw_n = pw_rd = pw_wr = pw_full = 0; q_head = q_len = 0; prof_full = 0; to_mask = 0;
+        C->pw_signal[0] = 0.0f;
+        n_rd = n_wr;            // skip_unread(0): drop whatever the previous read left unread
+        n_full = 0;
+        ring0 = n_wr;
+        n_pushed = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) { s_sum[i * WAVE + lane] = C->sum[i]; s_sumsq[i * WAVE + lane] = C->sumsq[i]; }
+        t = C->t; evt_st = C->evt_st; total_events = C->total_events; evt_st_sum = C->evt_st_sum; evt_st_sumsq = C->evt_st_sumsq;
+        len_sum = C->len_sum;
+        sd = Detector{C->sd.threshold, C->sd.window_length, C->sd.masked_to, C->sd.peak_pos, C->sd.peak_value, C->sd.valid_peak != 0};
+        ld = Detector{C->ld.threshold, C->ld.window_length, C->ld.masked_to, C->ld.peak_pos, C->ld.peak_value, C->ld.valid_peak != 0};
+        pw_mean = C->pw_mean; pw_varsum = C->pw_varsum; pw_n = C->pw_n; pw_rd = C->pw_rd; pw_wr = C->pw_wr; pw_full = C->pw_full;
+        q_head = C->q_head; q_len = C->q_len; prof_full = C->prof_full; to_mask = C->to_mask;
+        ring0 = C->ring0; n_pushed = C->n_pushed; status = C->status;
+    }
+
+    const int16_t *rp = raw + cd.offset;
+    for (uint32_t k = 0; k < cd.n_samples; ++k) {
+        const uint16_t ru = (uint16_t)rp[k];
+        const float s = __fdiv_rn(__fmul_rn(cd.cal_range, __fadd_rn((float)(int)ru, cd.cal_offset)), cd.cal_digit);
+        const uint32_t cur = (t & (RING - 1)) * WAVE + lane, prv = ((t - 1) & (RING - 1)) * WAVE + lane;
+        const float ss = __fmul_rn(s, s);
+        s_sum[cur] = s_sum[prv] + (double)s;
+        s_sumsq[cur] = s_sumsq[prv] + (double)ss;
+        t++;
+        const uint32_t buf_mid = t - 7;
+        const float t1 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW1);
+        const float t2 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW2);
+        const bool p1 = peak_detect(sd, &ld, t1, buf_mid, P.peak_height);
+        const bool p2 = peak_detect(ld, nullptr, t2, buf_mid, P.peak_height);
+        if (!(p1 || p2)) continue;
+        const uint32_t evt_en = buf_mid - UNC_WINDOW1 + 1;
+        const uint32_t eb = (evt_en & (RING - 1)) * WAVE + lane;
+        const uint32_t length = (uint32_t)(float)(evt_en - evt_st);
+        const double csum = s_sum[eb], csq = s_sumsq[eb];
+        float mean = (float)((csum - evt_st_sum) / (double)length);
+        evt_st = evt_en; evt_st_sum = csum; evt_st_sumsq = csq;
+        len_sum = __fadd_rn(len_sum, (float)length);
+        total_events++;
+        mean = __fmul_rn(__fadd_rn(mean, 0.0f), 1.0f);
+        if (!(mean >= P.min_mean && mean <= P.max_mean)) continue;
+        // EventProfiler::add_event
+        roll_push(C->pw_signal, PROF_WIN, pw_mean, pw_varsum, pw_n, pw_rd, pw_wr, pw_full, mean);
+        {
+            uint32_t qi = q_head + q_len; if (qi >= PROF_WIN + 1) qi -= PROF_WIN + 1;
+            C->evq[qi] = mean;
+            q_len++;
+        }
+        if (roll_unread(pw_n, pw_rd, pw_wr) <= PROF_WIN / 2) continue;
+        const float win_stdv = (float)sqrt(pw_varsum / (double)pw_n);
+        if (win_stdv < 5.0f) to_mask = PROF_WIN - 1;      // win_stdv_min, event_profiler.cpp:7
+        else if (to_mask > 0) to_mask--;
+        float next_mean = 0.0f;
+        if (pw_full) {
+            next_mean = C->evq[q_head];
+            q_head = q_head + 1 == PROF_WIN + 1 ? 0 : q_head + 1;
+            q_len--;
+            pw_rd = pw_rd + 1 == PROF_WIN ? 0 : pw_rd + 1;   // window_.pop()
+            pw_full = 0;
+            prof_full = 1;
+        }
+        if (!(prof_full && to_mask == 0)) continue;
+        // norm_.push(evt_mean), mapper.cpp:336-351.  A full ring (>= 6000 unread events) cannot happen when every
+        // chunk is mapped before the next one is added; it is reported instead of reproducing the #SKIP path.
+        if (!roll_push(ring, NORM_LEN, n_mean, n_varsum, n_n, n_rd, n_wr, n_full, next_mean)) { status |= UNC_READ_NORM_FULL; break; }
+        n_pushed++;
+    }
+
+    // ---- save state
+#pragma unroll
+    for (int i = 0; i < RING; ++i) { C->sum[i] = s_sum[i * WAVE + lane]; C->sumsq[i] = s_sumsq[i * WAVE + lane]; }
+    C->t = t; C->evt_st = evt_st; C->total_events = total_events; C->evt_st_sum = evt_st_sum; C->evt_st_sumsq = evt_st_sumsq;
+    C->len_sum = len_sum;
+    C->sd = RtDetector{sd.threshold, sd.window_length, sd.masked_to, sd.peak_pos, sd.peak_value, sd.valid_peak ? 1u : 0u};
+    C->ld = RtDetector{ld.threshold, ld.window_length, ld.masked_to, ld.peak_pos, ld.peak_value, ld.valid_peak ? 1u : 0u};
+    C->pw_mean = pw_mean; C->pw_varsum = pw_varsum; C->pw_n = pw_n; C->pw_rd = pw_rd; C->pw_wr = pw_wr; C->pw_full = pw_full;
+    C->q_head = q_head; C->q_len = q_len; C->prof_full = prof_full; C->to_mask = to_mask;
+    C->n_mean = n_mean; C->n_varsum = n_varsum; C->n_n = n_n; C->n_rd = n_rd; C->n_wr = n_wr; C->n_full = n_full;
+    C->ring0 = ring0; C->n_pushed = n_pushed; C->status = status;
+
+    // Normalizer::at: scale / shift from the rolling statistics after the whole chunk has been pushed
+    float scale = 0.0f, shift = 0.0f;
+    if (n_n > 0) {
+        scale = (float)((double)tgt_stdv / sqrt(n_varsum / (double)n_n));
+        shift = (float)((double)tgt_mean - (double)scale * n_mean);
+    }
+    unc_evt_info_t inf;
+    inf.n_events = n_pushed; inf.total_events = total_events; inf.len_sum = len_sum; inf.scale = scale; inf.shift = shift;
+    inf.pad = status;
+    info[ci] = inf;
+    ring0_out[ci] = ring0;
+}
+}  // namespace unc
+
 #include "unc_kernels.h"
 namespace unc {
+void launch_rt_events(const int16_t *raw, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans, float *norm_ring,
+                      const unc_params_t &P, float tgt_mean, float tgt_stdv, unc_evt_info_t *info, uint32_t *ring0_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + WAVE - 1) / WAVE), dim3(WAVE), 0, st, raw, chunks, n_chunks, chans, norm_ring, P,
+                       tgt_mean, tgt_stdv, info, ring0_out);
+}
 void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st) {
     hipLaunchKernelGGL(k_events, dim3((rd.n_reads + WAVE - 1) / WAVE), dim3(WAVE), 0, st, rd, P);
 }

@@ -39,6 +39,7 @@ struct MapArgs {
     uint32_t *next_read;    // work-queue head
     uint32_t max_steps;     // map_next calls per launch (0xFFFFFFFF = run to completion)
     uint32_t resume;        // 1: continue the read saved in SlotState (trace / chunked mode)
+    const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
 };
 
 struct Tracker {
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ uint32_t s_cdesc[CHILD_MAX];
 
     const int lane = lane_id();
-    const uint32_t slot = blockIdx.x;
+    const uint32_t slot = (A.resume && A.slot_map) ? A.slot_map[blockIdx.x] : blockIdx.x;
     const DevIndex &ix = A.ix;
     const unc_params_t &P = A.P;
     const uint32_t max_paths = A.sc.max_paths;
@@ -440,14 +441,21 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
         uint64_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (A.resume) {
-            r = st->read_idx; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
+        const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
+        if (A.resume && !fresh) {
+            r = blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
             T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
-            r = uniform32(r); event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
+            event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
             if (uniform32(st->done)) break;
+        } else if (A.resume) {
+            r = blockIdx.x;
+            event_i = 0; n_parents = 0; cur = 0;
+            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f;
+            T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
+            if (lane < NKMER / 32) s_flags[lane] = 0;
         } else {
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(A.next_read, 1u);
@@ -463,11 +471,14 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         const uint32_t n_events = inf.n_events;
         const float scale = inf.scale, shift = inf.shift;
         const float *means = A.rd.means + A.rd.moff[r];
+        const uint32_t ring_mod = A.rd.ring_mod, ring_r0 = ring_mod ? A.rd.ring0[r] : 0u;
+#define MEAN_AT(e) means[ring_mod ? (ring_r0 + (e)) % ring_mod : (e)]
 
         uint32_t done = 0, steps = 0;
-        float next_mean = event_i < n_events ? means[event_i] : 0.0f;
+        float next_mean = event_i < n_events ? MEAN_AT(event_i) : 0.0f;
         while (!done && steps < A.max_steps) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
+            if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
             ++steps;
 
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 #define PHASE_END(i) tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn
 #endif
             const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
-            if (event_i + 1 < n_events) next_mean = means[event_i + 1];
+            if (event_i + 1 < n_events) next_mean = MEAN_AT(event_i + 1);
 #pragma unroll 4
             for (int j = 0; j < NKMER / WAVE; ++j) {
                 const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
@@ -837,10 +848,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 #include "unc_kernels.h"
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
-                uint32_t *next_read, uint32_t max_steps, uint32_t resume, uint32_t grid, hipStream_t st) {
+                uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st) {
     MapArgs a;
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
-    a.max_steps = max_steps; a.resume = resume;
+    a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map;
     hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
 }
 // resident single-wave workgroups per CU for the persistent grid: bounded by the kernel's LDS

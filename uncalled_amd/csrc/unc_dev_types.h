@@ -89,6 +89,42 @@ struct DevScratch {
     uint32_t max_paths, keys_cap, max_seed_paths, max_clusters;
 };
 
+// ---- chunked (realtime) path: state a Mapper keeps per channel between chunks (mapper.hpp:209-226) ----
+constexpr uint32_t NORM_LEN = 6000;   // Normalizer::PRMS_DEF.len, normalizer.cpp:4-8
+constexpr uint32_t PROF_WIN = 25;     // EventProfiler::PRMS_DEF.win_len, event_profiler.cpp:4-10
+
+struct RtDetector { float threshold; uint32_t window_length, masked_to; int32_t peak_pos; float peak_value; uint32_t valid_peak; };
+
+struct alignas(16) RtChan {
+    // EventDetector (event_detector.hpp:106-128); cumulative sums by absolute position & 15
+    double sum[16], sumsq[16];
+    double evt_st_sum, evt_st_sumsq;
+    uint32_t t, evt_st, total_events;
+    float len_sum;
+    RtDetector sd, ld;
+    // EventProfiler (event_profiler.hpp:35-48): rolling 25-window + the queued event means
+    double pw_mean, pw_varsum;
+    float pw_signal[PROF_WIN + 3];
+    float evq[PROF_WIN + 3];
+    uint32_t pw_n, pw_rd, pw_wr, pw_full, q_head, q_len, prof_full, to_mask;
+    // Normalizer in rolling mode (normalizer.hpp:74-79); the 6000-float ring lives in DevRt::norm_ring
+    double n_mean, n_varsum;
+    uint32_t n_n, n_rd, n_wr, n_full, n_empty;
+    // current read
+    uint32_t ring0;        // ring slot holding event 0 of this read
+    uint32_t n_pushed;     // events pushed for this read so far
+    uint32_t status;       // UNC_READ_* bits
+    uint32_t pad[2];
+};
+
+struct RtChunkDesc {       // one chunk = one channel's next <= 4000 samples (Chunk, chunk.hpp:32-59)
+    uint64_t offset;       // into the raw int16 array
+    uint32_t n_samples;
+    uint32_t channel;
+    uint32_t new_read;     // Mapper::new_read(Chunk&) instead of add_chunk
+    float cal_range, cal_offset, cal_digit;
+};
+
 struct DevReads {
     const int16_t *raw;
     const uint64_t *offsets;      // n_reads + 1
@@ -98,6 +134,10 @@ struct DevReads {
     unc_evt_info_t *info;
     uint32_t n_reads;
     float tgt_mean, tgt_stdv;     // PoreModel::get_means_mean/stdv (mapper.cpp:94)
+    // chunked path: events live in a per-channel ring, event e of read r at means[moff[r] + (ring0[r] + e) % ring_mod]
+    const uint32_t *ring0;        // null in batch mode
+    const uint32_t *new_read;     // per descriptor: 1 = start from a fresh Mapper::reset() state
+    uint32_t ring_mod;            // 0 in batch mode
 };
 
 // what the map kernel hands back per read

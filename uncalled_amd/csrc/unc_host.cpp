@@ -507,6 +507,7 @@ static int stage_batch(unc_mapper *m, uint32_t n_reads, const int16_t *raw, cons
     rd->raw = d_raw; rd->offsets = m->d_offsets; rd->calib = m->d_calib; rd->means = m->d_means; rd->moff = m->d_moff;
     rd->info = m->d_info; rd->n_reads = n_reads;
     rd->tgt_mean = m->ix->model_mean; rd->tgt_stdv = m->ix->model_stdv;
+    rd->ring0 = nullptr; rd->new_read = nullptr; rd->ring_mod = 0;
     return UNC_OK;
 }
 
@@ -521,8 +522,8 @@ static uint32_t event_to_bp(const unc_params_t &P, uint32_t evt_i, float mean_ev
 }
 
 // Mapper::set_ref_loc (mapper.cpp:708-728) + Paf::set_mapped / set_read_len (read_buffer.cpp:133-155,264-267)
-static void fill_hit(const unc_mapper *m, const DevResult &res, const unc_evt_info_t &inf, uint64_t raw_len, unc_hit_t *h) {
-    const unc_params_t &P = m->P;
+static void fill_hit(const unc_index *ix, const unc_params_t &P, const DevResult &res, const unc_evt_info_t &inf, uint64_t raw_len,
+                     unc_hit_t *h) {
     memset(h, 0, sizeof *h);
     h->rid = -1;
     h->status = res.status;
@@ -533,7 +534,7 @@ static void fill_hit(const unc_mapper *m, const DevResult &res, const unc_evt_in
     h->n_nbr = res.n_nbr; h->n_sa = res.n_sa; h->n_lf = res.n_lf;
     if (res.done == 1 && res.status == 0) {
         const ClusterVal &c = res.cluster;
-        const uint64_t size = m->ix->seq_len;
+        const uint64_t size = ix->seq_len;
         const bool fwd = c.ref_st < size / 2;
         const uint64_t sa_st = fwd ? c.ref_st : size - (c.rend + UNC_KLEN - 1);
         h->rd_st = event_to_bp(P, c.evt_st - P.seed_len, mel, false);
@@ -541,7 +542,7 @@ static void fill_hit(const unc_mapper *m, const DevResult &res, const unc_evt_in
         h->rd_len = event_to_bp(P, res.event_i, mel, true);
         uint64_t rf_st = 0;
         int32_t rid;
-        const uint64_t rf_len = unc_index_translate_loc(m->ix, sa_st, &rid, &rf_st);
+        const uint64_t rf_len = unc_index_translate_loc(ix, sa_st, &rid, &rf_st);
         h->rid = rid;
         h->rf_st = rf_st;
         h->rf_len = rf_len;
@@ -570,7 +571,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     launch_events(rd, m->P, st);
     HIPCHK(hipEventRecord(m->ev[1], st));
     const uint32_t grid = n_reads < m->n_slots ? n_reads : m->n_slots;
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, grid, st);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, grid, st);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
@@ -582,7 +583,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
-        fill_hit(m, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
+        fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
         if (hits[i].status) worst = UNC_ERR_OVERFLOW;
     }
     if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise max_clusters/max_seed_paths");
@@ -648,6 +649,7 @@ extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, 
 static int trace_reads(unc_mapper *m, DevReads *rd) {
     rd->raw = m->d_raw; rd->offsets = m->d_offsets; rd->calib = m->d_calib; rd->means = m->d_means; rd->moff = m->d_moff;
     rd->info = m->d_info; rd->n_reads = 1; rd->tgt_mean = m->ix->model_mean; rd->tgt_stdv = m->ix->model_stdv;
+    rd->ring0 = nullptr; rd->new_read = nullptr; rd->ring_mod = 0;
     return UNC_OK;
 }
 
@@ -656,7 +658,7 @@ extern "C" int unc_trace_step(unc_mapper_t *m, uint32_t n_events, int *done) {
     HIPCHK(hipSetDevice(m->ix->device));
     DevReads rd;
     trace_reads(m, &rd);
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, 1, m->stream);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, nullptr, 1, m->stream);
     HIPCHK(hipGetLastError());
     SlotState s;
     HIPCHK(hipMemcpyAsync(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost, m->stream));
@@ -726,7 +728,253 @@ extern "C" int unc_trace_finish(unc_mapper_t *m, unc_hit_t *hit) {
     memset(&res, 0, sizeof res);
     res.done = s.done; res.status = s.status; res.event_i = s.event_i; res.cluster = s.max_map;
     res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
-    fill_hit(m, res, inf, m->trace_n, hit);
+    fill_hit(m->ix, m->P, res, inf, m->trace_n, hit);
     m->trace_active = false;
+    return UNC_OK;
+}
+
+// ------------------------------------------------------------------ chunked (realtime) path
+struct RtHostChan { int state = 0; /* 0 inactive, 1 mapping */ uint32_t number = 0, chunk_count = 0; uint64_t raw_len = 0; };
+
+struct unc_rt {
+    const unc_index *ix = nullptr;
+    unc_params_t P;
+    uint32_t n_channels = 0;
+    DevScratch sc;
+    RtChan *d_chans = nullptr;
+    float *d_ring = nullptr;
+    RtChunkDesc *d_desc = nullptr;
+    unc_evt_info_t *d_info = nullptr;
+    uint32_t *d_ring0 = nullptr, *d_newread = nullptr, *d_slotmap = nullptr, *d_next = nullptr;
+    uint64_t *d_moff = nullptr;
+    DevResult *d_results = nullptr;
+    int16_t *d_raw = nullptr;
+    size_t raw_cap = 0;
+    uint64_t device_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    float ms_events = 0, ms_map = 0;
+    std::vector<RtHostChan> chans;
+    std::vector<SlotState> h_state;
+    std::vector<unc_evt_info_t> h_info;
+};
+
+extern "C" void unc_rt_free(unc_rt_t *rt) {
+    if (!rt) return;
+    (void)hipSetDevice(rt->ix->device);
+    void *ptrs[] = {rt->sc.paths, rt->sc.order, rt->sc.keys, rt->sc.seedp, rt->sc.sa_tasks, rt->sc.cl_keys, rt->sc.cl_pay, rt->sc.state,
+                    rt->d_chans, rt->d_ring, rt->d_desc, rt->d_info, rt->d_ring0, rt->d_newread, rt->d_slotmap, rt->d_next, rt->d_moff,
+                    rt->d_results, rt->d_raw};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : rt->ev) if (e) (void)hipEventDestroy(e);
+    if (rt->stream) (void)hipStreamDestroy(rt->stream);
+    delete rt;
+}
+
+extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint32_t n_channels, unc_rt_t **out) {
+    if (!ix || !p || !out || n_channels == 0) return fail(UNC_ERR_ARG, "bad argument");
+    *out = nullptr;
+    if (p->seed_len != UNC_SEED_LEN || p->window_length1 != UNC_WINDOW1 || p->window_length2 != UNC_WINDOW2)
+        return fail(UNC_ERR_ARG, "seed_len/window lengths must be %d/%d/%d", UNC_SEED_LEN, UNC_WINDOW1, UNC_WINDOW2);
+    if (p->max_paths == 0 || p->max_paths > 65535 || p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT || p->max_consec_stay > 255)
+        return fail(UNC_ERR_ARG, "unsupported parameter value");
+    HIPCHK(hipSetDevice(ix->device));
+    unc_rt *rt = new unc_rt();
+    struct Guard { unc_rt *p; ~Guard() { if (p) unc_rt_free(p); } } guard{rt};
+    rt->ix = ix; rt->P = *p; rt->n_channels = n_channels;
+    memset(&rt->sc, 0, sizeof rt->sc);
+    DevScratch &sc = rt->sc;
+    sc.max_paths = p->max_paths;
+    uint32_t kc = 64;
+    while (kc < p->max_paths) kc <<= 1;
+    sc.keys_cap = kc; sc.max_seed_paths = p->max_paths; sc.max_clusters = 16384;
+    const size_t S = n_channels;
+    size_t bytes = 0;
+#define RALLOC(ptr, type, count)                                   \
+    do {                                                           \
+        size_t b_ = (size_t)(count) * sizeof(type);                \
+        HIPCHK(hipMalloc((void **)&(ptr), b_));                    \
+        HIPCHK(hipMemset((ptr), 0, b_));                           \
+        bytes += b_;                                               \
+    } while (0)
+    RALLOC(sc.paths, PathRec, S * 2 * sc.max_paths);
+    RALLOC(sc.order, uint32_t, S * 2 * sc.max_paths);
+    RALLOC(sc.keys, SortKey, S * 2 * sc.keys_cap);
+    RALLOC(sc.seedp, SeedPath, S * sc.max_seed_paths);
+    RALLOC(sc.sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
+    RALLOC(sc.cl_keys, ClusterKey, S * sc.max_clusters);
+    RALLOC(sc.cl_pay, ClusterPay, S * sc.max_clusters);
+    RALLOC(sc.state, SlotState, S);
+    RALLOC(rt->d_chans, RtChan, S);
+    RALLOC(rt->d_ring, float, S * NORM_LEN);
+    RALLOC(rt->d_desc, RtChunkDesc, S);
+    RALLOC(rt->d_info, unc_evt_info_t, S);
+    RALLOC(rt->d_ring0, uint32_t, S);
+    RALLOC(rt->d_newread, uint32_t, S);
+    RALLOC(rt->d_slotmap, uint32_t, S);
+    RALLOC(rt->d_next, uint32_t, 16);
+    RALLOC(rt->d_moff, uint64_t, S + 1);
+    RALLOC(rt->d_results, DevResult, S);
+#undef RALLOC
+    rt->device_bytes = bytes;
+    rt->chans.resize(n_channels);
+    HIPCHK(hipStreamCreate(&rt->stream));
+    for (auto &e : rt->ev) HIPCHK(hipEventCreate(&e));
+    guard.p = nullptr;
+    *out = rt;
+    return UNC_OK;
+}
+
+extern "C" uint64_t unc_rt_device_bytes(const unc_rt_t *rt) { return rt->device_bytes; }
+extern "C" int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *ms_map) {
+    if (ms_events) *ms_events = rt->ms_events;
+    if (ms_map) *ms_map = rt->ms_map;
+    return UNC_OK;
+}
+
+static void rt_unmapped(const unc_rt *rt, const RtHostChan &hc, const SlotState &s, const unc_evt_info_t *inf, unc_hit_t *h) {
+    DevResult res;
+    memset(&res, 0, sizeof res);
+    res.done = 2; res.status = s.status; res.event_i = s.event_i;
+    res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
+    unc_evt_info_t z;
+    memset(&z, 0, sizeof z);
+    fill_hit(rt->ix, rt->P, res, inf ? *inf : z, hc.raw_len, h);
+}
+
+extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, int on_device,
+                                     void *stream, unc_rt_result_t *results) {
+    if (!rt || !chunks || !raw || !results) return fail(UNC_ERR_ARG, "null argument");
+    if (n_chunks > rt->n_channels) return fail(UNC_ERR_ARG, "more chunks than channels");
+    HIPCHK(hipSetDevice(rt->ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : rt->stream;
+    const uint32_t chunk_len = (uint32_t)(rt->P.chunk_time * rt->P.sample_rate);
+
+    // ---- host decisions that the reference takes before any signal is touched (RealtimePool::add_chunk /
+    //      try_add_chunk, Mapper::add_chunk): which chunks start a read, continue one, or are dropped
+    std::vector<RtChunkDesc> desc;
+    std::vector<uint32_t> slotmap, newread, active;   // active[i] = index into chunks[]
+    std::vector<uint64_t> moff;
+    std::vector<char> seen(rt->n_channels, 0);
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
+        const unc_rt_chunk_t &c = chunks[i];
+        memset(&results[i], 0, sizeof results[i]);
+        results[i].hit.rid = -1;
+        if (c.channel >= rt->n_channels) return fail(UNC_ERR_ARG, "chunk %u: channel %u out of range", i, c.channel);
+        if (seen[c.channel]) return fail(UNC_ERR_ARG, "two chunks for channel %u in one call", c.channel);
+        if (c.n_samples > chunk_len) return fail(UNC_ERR_ARG, "chunk %u longer than chunk_time * sample_rate", i);
+        seen[c.channel] = 1;
+        RtHostChan &hc = rt->chans[c.channel];
+        if (c.flags & UNC_RT_FIRST) {
+            hc.state = 1; hc.number = c.read_number; hc.chunk_count = 1; hc.raw_len = c.n_samples;   // ReadBuffer(Chunk&)
+        } else if (hc.state != 1 || hc.number != c.read_number) {
+            results[i].state = UNC_RT_IGNORED;
+            continue;
+        } else if (hc.chunk_count >= rt->P.max_chunks) {
+            // Mapper::add_chunk: read_.chunks_maxed() -> set_failed(), mapper.cpp:289-296 (the chunk is dropped)
+            results[i].state = UNC_RT_FAILED;
+            hc.state = 0;
+            active.push_back(i | 0x80000000u);   // needs the slot state for the record, nothing to launch
+            continue;
+        } else {
+            hc.chunk_count++;
+            hc.raw_len += c.n_samples;
+        }
+        RtChunkDesc d;
+        d.offset = c.offset; d.n_samples = c.n_samples; d.channel = c.channel; d.new_read = (c.flags & UNC_RT_FIRST) ? 1u : 0u;
+        d.cal_range = c.calib.range; d.cal_offset = c.calib.offset; d.cal_digit = c.calib.digitisation;
+        desc.push_back(d);
+        slotmap.push_back(c.channel);
+        newread.push_back(d.new_read);
+        moff.push_back((uint64_t)c.channel * NORM_LEN);
+        active.push_back(i);
+        if (c.n_samples) { lo = c.offset < lo ? c.offset : lo; hi = c.offset + c.n_samples > hi ? c.offset + c.n_samples : hi; }
+    }
+    const uint32_t n_act = (uint32_t)desc.size();
+    rt->ms_events = rt->ms_map = 0;
+    if (n_act) {
+        const int16_t *d_raw = raw;
+        if (!on_device) {
+            const uint64_t span = hi > lo ? hi - lo : 0;
+            if (span > rt->raw_cap) {
+                if (rt->d_raw) (void)hipFree(rt->d_raw);
+                rt->d_raw = nullptr;
+                HIPCHK(hipMalloc((void **)&rt->d_raw, (span + 64) * 2));
+                rt->raw_cap = span;
+            }
+            if (span) HIPCHK(hipMemcpyAsync(rt->d_raw, raw + lo, span * 2, hipMemcpyHostToDevice, st));
+            d_raw = rt->d_raw - lo;
+        }
+        moff.push_back(0);
+        HIPCHK(hipMemcpyAsync(rt->d_desc, desc.data(), n_act * sizeof(RtChunkDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(rt->d_slotmap, slotmap.data(), n_act * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(rt->d_newread, newread.data(), n_act * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(rt->d_moff, moff.data(), (n_act + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(rt->ev[0], st));
+        launch_rt_events(d_raw, rt->d_desc, n_act, rt->d_chans, rt->d_ring, rt->P, rt->ix->model_mean, rt->ix->model_stdv, rt->d_info,
+                         rt->d_ring0, st);
+        HIPCHK(hipEventRecord(rt->ev[1], st));
+        DevReads rd;
+        memset(&rd, 0, sizeof rd);
+        rd.means = rt->d_ring; rd.moff = rt->d_moff; rd.info = rt->d_info; rd.n_reads = n_act;
+        rd.tgt_mean = rt->ix->model_mean; rd.tgt_stdv = rt->ix->model_stdv;
+        rd.ring0 = rt->d_ring0; rd.new_read = rt->d_newread; rd.ring_mod = NORM_LEN;
+        launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st);
+        HIPCHK(hipEventRecord(rt->ev[2], st));
+        HIPCHK(hipGetLastError());
+        rt->h_info.resize(n_act);
+        HIPCHK(hipMemcpyAsync(rt->h_info.data(), rt->d_info, n_act * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
+    }
+    rt->h_state.resize(rt->n_channels);
+    HIPCHK(hipMemcpyAsync(rt->h_state.data(), rt->sc.state, (size_t)rt->n_channels * sizeof(SlotState), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_act) {
+        HIPCHK(hipEventElapsedTime(&rt->ms_events, rt->ev[0], rt->ev[1]));
+        HIPCHK(hipEventElapsedTime(&rt->ms_map, rt->ev[1], rt->ev[2]));
+    }
+
+    // ---- outcome per chunk (Mapper::map_chunk's exits, mapper.cpp:381-431)
+    int worst = UNC_OK;
+    uint32_t di = 0;
+    for (uint32_t a : active) {
+        const bool dropped = a & 0x80000000u;
+        const uint32_t i = a & 0x7FFFFFFFu;
+        const unc_rt_chunk_t &c = chunks[i];
+        RtHostChan &hc = rt->chans[c.channel];
+        const SlotState &s = rt->h_state[c.channel];
+        if (dropped) { rt_unmapped(rt, hc, s, nullptr, &results[i].hit); continue; }
+        const unc_evt_info_t &inf = rt->h_info[di++];
+        if (inf.pad || s.status) {   // RtChan status travels in info.pad
+            results[i].state = UNC_RT_FAILED;
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit);
+            results[i].hit.status = s.status | inf.pad;
+            hc.state = 0;
+            worst = UNC_ERR_OVERFLOW;
+        } else if (s.done == 1) {
+            DevResult res;
+            memset(&res, 0, sizeof res);
+            res.done = 1; res.event_i = s.event_i; res.cluster = s.max_map; res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
+            fill_hit(rt->ix, rt->P, res, inf, hc.raw_len, &results[i].hit);
+            results[i].state = UNC_RT_MAPPED;
+            hc.state = 0;
+        } else if (s.done == 2 || s.event_i >= rt->P.max_events) {
+            results[i].state = UNC_RT_FAILED; results[i].ended = 1;        // event_i_ >= max_events: set_failed + set_ended
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit);
+            hc.state = 0;
+        } else if (hc.chunk_count >= rt->P.max_chunks) {
+            results[i].state = UNC_RT_FAILED;                               // norm_.empty() && chunks_maxed(), :392-405
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit);
+            hc.state = 0;
+        } else if (c.flags & UNC_RT_LAST) {
+            results[i].state = UNC_RT_FAILED; results[i].ended = 1;        // request_reset -> set_failed + set_ended
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit);
+            hc.state = 0;
+        } else {
+            results[i].state = UNC_RT_MAPPING;
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit);                  // progress so far (event_i, counters)
+        }
+    }
+    if (worst) return fail(worst, "device scratch overflow on at least one channel (see hit.status)");
     return UNC_OK;
 }
