@@ -43,9 +43,10 @@ def test_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
     pc.case_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
 
 
-@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 31, None), (3, 31, None), (2, 8, 2)])
-def test_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks):
-    pc.case_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
+@pytest.mark.parametrize("n_channels,n_reads,max_chunks,long_read", [(1, 31, None, False), (3, 31, None, False), (2, 8, 2, False),
+                                                                   (2, 6, None, True)])
+def test_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks, long_read):
+    pc.case_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks, long_read)
 
 
 @pytest.fixture(scope="module")

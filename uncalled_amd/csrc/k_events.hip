@@ -251,6 +251,10 @@ __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const RtCh
         pw_mean = C->pw_mean; pw_varsum = C->pw_varsum; pw_n = C->pw_n; pw_rd = C->pw_rd; pw_wr = C->pw_wr; pw_full = C->pw_full;
         q_head = C->q_head; q_len = C->q_len; prof_full = C->prof_full; to_mask = C->to_mask;
         ring0 = C->ring0; n_pushed = C->n_pushed; status = C->status;
+        // every event of the previous chunk has been popped by the time the next chunk is added (a chunk is only
+        // added once Mapper::chunk_mapped(), realtime_pool.cpp:133-138): the read pointer has caught up
+        n_rd = n_wr;
+        n_full = 0;
     }
 
     const int16_t *rp = raw + cd.offset;
