@@ -160,8 +160,9 @@ int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const u
 /* wall-clock of the kernels of the last unc_map_batch, from HIP events on the launch stream */
 int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map);
 /* shader-clock cycles summed over the reads of the last batch, per k_map phase:
- * [0] match probs, [1] extension, [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed, [7] rest */
-int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8);
+ * [0] match probs, [1] extension (loop overhead), [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed,
+ * [7] rest, [8] E1 parent loads + candidates, [9] E2 FM look-ups, [10] E3 child slots, [11] E4 child records */
+int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
 
 /* ---- chunked (realtime) path: replaces RealtimePool + per-channel Mapper::new_read(Chunk&) / add_chunk /
  * process_chunk / map_chunk (realtime_pool.cpp:74-142,349-358; mapper.cpp:210-431) with the deterministic

@@ -24,6 +24,7 @@
 #include <vector>
 
 #define LANESIM 1
+#define ext_vector_type(n) vector_size(4 * (n))   /* GCC spelling of clang's 4-byte-element vectors */
 #define __global__
 #define __device__
 #define __host__
@@ -173,6 +174,8 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned acc) {
     int l = __lanesim_lane();
     return acc + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
 }
+template <class T> static inline void __builtin_nontemporal_store(T v, T *p) { *p = v; }
+template <class T> static inline T __builtin_nontemporal_load(const T *p) { return *p; }
 static inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -256,9 +256,9 @@ class Mapper:
         return a.value, b.value
 
     def last_phase_cycles(self):
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         self.L.unc_mapper_last_phase_cycles(self.h, out.ctypes.data)
-        return dict(zip(("probs", "extend", "sort", "walk", "sources", "sa", "add_seed", "rest"), out.tolist()))
+        return dict(zip(("probs", "extend_rest", "sort", "walk", "sources", "sa", "add_seed", "rest", "e1_parents", "e2_fm", "e3_slots", "e4_children"), out.tolist()))
 
     def detect_events(self, raw_i16, offsets_u64, calib):
         raw = np.ascontiguousarray(raw_i16, dtype=np.int16)

@@ -396,9 +396,9 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
 // PathBuffer::make_source, mapper.cpp:751-772: only the fields a length-1 path ever reads
 __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
     uint4 *q = reinterpret_cast<uint4 *>(dst);
-    q[0] = make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32));
-    q[1] = make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), 0u);
-    q[2] = make_uint4(0u, __float_as_uint(prob), 0u, 0u);   // prob_sums_ = {0, prob}
+    q[0] = (make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32)));
+    q[1] = (make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), 0u));
+    q[2] = (make_uint4(0u, __float_as_uint(prob), 0u, 0u));   // prob_sums_ = {0, prob}
 }
 
 #ifndef UNC_LB
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         uint32_t r, event_i, n_parents, cur;
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
-        uint64_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if (A.resume && !fresh) {
             r = blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
@@ -489,6 +489,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 #else
 #define PHASE_END(i) tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn
 #endif
+#ifdef UNC_PROFILE_FINE
+#define PHASE_FINE(i) PHASE_END(i)
+#else
+#define PHASE_FINE(i) (void)tn
+#endif
             const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
             if (event_i + 1 < n_events) next_mean = MEAN_AT(event_i + 1);
 #pragma unroll 4
@@ -509,17 +514,29 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             PHASE_END(0);
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
-            uint32_t phys_next = (uint32_t)lane < n_parents ? pord[lane] : 0u;
+            // parent index list and record headers are fetched one / two passes ahead of their use
+            uint32_t phys_cur = (uint32_t)lane < n_parents ? pord[lane] : 0u;
+            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? pord[lane + WAVE] : 0u;
+            uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)lane < n_parents) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(par + phys_cur);
+                q0c = q[0]; q1c = q[1];
+            }
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
                 const uint32_t pi = base + (uint32_t)lane;
                 const bool have = pi < n_parents;
-                uint32_t phys = phys_next, pmoves = 0, pmeta = 0;
-                if (pi + WAVE < n_parents) phys_next = pord[pi + WAVE];
+                const uint32_t phys = phys_cur;
+                const uint4 q0 = q0c, q1 = q1c;
+                phys_cur = phys_nxt;
+                if (pi + WAVE < n_parents) {
+                    const uint4 *q = reinterpret_cast<const uint4 *>(par + phys_nxt);
+                    q0c = q[0]; q1c = q[1];
+                }
+                if (pi + 2 * WAVE < n_parents) phys_nxt = pord[pi + 2 * WAVE];
+                uint32_t pmoves = 0, pmeta = 0;
                 uint64_t pstart = 1, pend = 1;
                 float pprob = 0.0f;
                 if (have) {
-                    const uint4 *q = reinterpret_cast<const uint4 *>(par + phys);
-                    uint4 q0 = q[0], q1 = q[1];
                     pstart = ((uint64_t)q0.y << 32) | q0.x;
                     pend = ((uint64_t)q0.w << 32) | q0.z;
                     pmoves = q1.x; pprob = __uint_as_float(q1.y); pmeta = q1.z;
@@ -546,6 +563,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
                 }
                 wave_sync();
+                PHASE_FINE(8);
                 // FM look-ups, every lane busy
                 for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
                     const uint32_t ci = c0 + (uint32_t)lane;
@@ -557,6 +575,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     }
                 }
                 wave_sync();
+                PHASE_FINE(9);
                 // children per parent, in the reference's order: stay, then bases 0..3
                 uint32_t vmask = 0;   // bit j: j-th candidate of this lane has a non-empty range
                 for (uint32_t j = 0; j < ncand; ++j)
@@ -611,6 +630,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     n_seedp += (uint32_t)__popcll(em);
                 }
                 wave_sync();
+                PHASE_FINE(10);
                 // one lane per child
                 for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
                     const uint32_t li = l0 + (uint32_t)lane;
@@ -622,7 +642,8 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
                         // the parent's ring (6 x 16 B) plus the two sums the child needs, all in one round trip
                         const uint4 *q = reinterpret_cast<const uint4 *>(pp);
-                        const uint4 r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6], r7 = q[7];
+                        const uint4 r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6],
+                                    r7 = q[7];
                         uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
                         uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
                         const float last = pp->ps[sl], second = pp->ps[s2];
@@ -636,15 +657,17 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, key);
                         PathRec *cp = chd + gi;
                         uint4 *w = reinterpret_cast<uint4 *>(cp);
-                        w[0] = make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32));
-                        w[1] = make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u);
-                        w[2] = r2; w[3] = r3; w[4] = r4; w[5] = r5; w[6] = r6; w[7] = r7;
+                        w[0] = (make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
+                        w[1] = (make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
+                        w[2] = (r2); w[3] = (r3); w[4] = (r4); w[5] = (r5); w[6] = (r6);
+                        w[7] = (r7);
                         cp->ps[c.wslot] = c.appended;   // same lane, same address as the copy above: program order
                         ukeys[gi] = key;
                     }
                 }
                 nchild += nwrite;
                 wave_sync();
+                PHASE_FINE(11);
             }
             if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
@@ -826,7 +849,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
-            for (int i = 0; i < 8; ++i) res.cyc[i] = cyc[i];
+            for (int i = 0; i < 12; ++i) res.cyc[i] = cyc[i];
             A.results[r] = res;
         }
         if (A.resume || !done) {

@@ -145,7 +145,7 @@ struct alignas(16) DevResult {
     uint32_t done, status, event_i, pad;
     ClusterVal cluster;
     uint64_t n_nbr, n_sa, n_lf;
-    uint64_t cyc[8];   // shader-clock cycles per phase: P, E, S, W, F, T(sa), T(add_seed), G
+    uint64_t cyc[12];  // shader-clock cycles per phase: P, E(rest), S, W, F, T(sa), T(add_seed), G, E1, E2, E3, E4
 };
 
 }  // namespace unc

@@ -591,9 +591,9 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
 }
 
 extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8) {
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int i = 0; i < 12; ++i) out8[i] = 0;
     for (const DevResult &r : m->h_results)
-        for (int i = 0; i < 8; ++i) out8[i] += r.cyc[i];
+        for (int i = 0; i < 12; ++i) out8[i] += r.cyc[i];
     return UNC_OK;
 }
 

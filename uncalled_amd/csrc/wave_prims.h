@@ -95,4 +95,19 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
+// Streaming (write-once / read-once) traffic such as the path records: keep it from evicting the FM index
+// out of the XCD's L2.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(uint4 *p, uint4 v) {
+    u32x4 w;
+    __builtin_memcpy(&w, &v, 16);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));   // global_store_dwordx4 ... nt
+}
+__device__ __forceinline__ uint4 nt_load(const uint4 *p) {
+    const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));   // global_load_dwordx4 ... nt
+    uint4 v;
+    __builtin_memcpy(&v, &w, 16);
+    return v;
+}
+
 }  // namespace unc
