@@ -23,14 +23,28 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def ensure_index(cache, rank, world, barrier):
-    """SURVEY 8(d) `ecoli_syn`: 1 contig, 4 641 652 bp, i.i.d. ACGT, GC 0.508, seed 1 -> BWA-format index."""
-    from tools.build_index import build_from_codes, synthetic_genome
-    prefix = cache / "ecoli_syn"
-    names, lens, codes = synthetic_genome(1, 4641652, seed=1)
+def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
+    """SURVEY 8(d) `ecoli_syn`: 1 contig, 4 641 652 bp, i.i.d. ACGT, GC 0.508, seed 1 -> BWA-format index.
+    `chr20`: 64 444 167 bp, seed 2, 30 % in N-runs (suffix array built on the GPU)."""
+    from tools.build_index import build_from_codes, masked_synthetic_genome, synthetic_genome
+    if workload == "chr20":
+        prefix = cache / "chr20_syn"
+        names, lens, codes, holes, n_ambs = masked_synthetic_genome(1, 64444167, seed=2, name="chr20_syn")
+    else:
+        prefix = cache / "ecoli_syn"
+        names, lens, codes = synthetic_genome(1, 4641652, seed=1)
+        holes, n_ambs = (), None
     if rank == 0 and not (Path(str(prefix) + ".sa").exists() and Path(str(prefix) + ".uncl").exists()):
         cache.mkdir(parents=True, exist_ok=True)
-        build_from_codes(prefix, names, [""] * len(names), lens, codes)
+        build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs,
+                         sa_device=device if workload == "chr20" else None)
+        # `uncalled index`: thresholds for THIS reference (self-alignment on the GPU + IndexParameterizer, preset
+        # "default" = tgt_speed 115, scripts/uncalled:58); build_from_codes left the example's vector as a placeholder
+        from uncalled_amd import capi
+        from uncalled_amd.index_params import parameterize
+        tmp_ix = capi.Index(prefix, device=int(str(device).split(":")[-1]) if device else 0)
+        parameterize(tmp_ix, prefix)
+        tmp_ix.close()
     barrier()
     return prefix, codes, lens
 
@@ -143,7 +157,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("UNC_BENCH_READS", 50000)),
                     help="reads per GPU per step (config: E. coli 4.6 Mb ref, 50k synthetic r9.4.1 reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["ecoli", "realtime"], default="ecoli")
+    ap.add_argument("--workload", choices=["ecoli", "chr20", "realtime"], default="ecoli")
     ap.add_argument("--channels", type=int, default=512)
     a = ap.parse_args()
 
@@ -167,7 +181,8 @@ def main():
     from uncalled_amd import capi
 
     cache = Path(os.environ.get("UNC_BENCH_CACHE", "/tmp/uncalled_amd_bench"))
-    prefix, codes, lens = ensure_index(cache, rank, world, barrier)
+    prefix, codes, lens = ensure_index(cache, rank, world, barrier, "chr20" if a.workload == "chr20" else "ecoli",
+                                       f"cuda:{local_rank}")
     ix = capi.Index(prefix, device=local_rank)
     if a.workload == "realtime":
         out = realtime_workload(a, ix, codes, lens, local_rank)
@@ -221,8 +236,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32/f64",
             "data": "synthetic",
-            "config": {"workload": "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1), synthetic r9.4.1 reads "
-                                   "(3600 bases ~ 32k samples, 10% off-target), all reference defaults",
+            "config": {"workload": ("repeat-masked chr20-sized synthetic ref (chr20_syn 64.4 Mb, seed 2, 30% N-runs)" if a.workload == "chr20"
+                                    else "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1)") +
+                                   ", synthetic r9.4.1 reads (3600 bases ~ 32k samples, 10% off-target), all reference defaults",
                        "reads_per_gpu_per_step": a.reads, "parallelism": f"reads sharded over {world} GPU(s), index replicated",
                        "mean_ms_per_read_amortised": 1e3 * dt / (a.reads * a.steps),
                        "mapped_fraction": float(hits["mapped"].mean()),

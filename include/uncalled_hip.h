@@ -138,6 +138,15 @@ int unc_fm_sa(const unc_index_t *ix, uint32_t n, const uint64_t *rows, uint64_t 
 /* device PoreModel::match_prob over all 1024 k-mers (pore_model.hpp:163-165; mapper.cpp:443-445) */
 int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *levels, float *out /* n x 1024 */);
 
+/* ---- `uncalled index` (scripts/uncalled:38-78): self-alignment of sampled reference positions, the FM walk whose
+ * range-size trajectories IndexParameterizer (uncalled/index.py:53-209) turns into the .uncl thresholds.  Replaces
+ * self_align(bwa_prefix, sample_dist) (src/self_align_ref.cpp:34-91): positions are sampled with the same
+ * srand(0)/rand() % sample_dist draw per base, the walks run on the device.  lens (host) receives up to `cap` range
+ * sizes per trajectory (row-major, n_paths x cap), full_len[i] the trajectory's true length.  Call with lens == NULL
+ * to get n_paths only.  Needs <prefix>.pac next to the index files. */
+int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sample_dist, uint32_t cap, uint64_t *lens,
+                   uint32_t *full_len, uint64_t max_paths, uint64_t *n_paths);
+
 /* ---- mapper: replaces N x (Mapper::new_read + Mapper::map_read) (mapper.cpp:188-207), i.e. the
  * body of MapPool::MapperThread::run (map_pool.cpp:130-158), for a whole batch of reads. */
 typedef struct {

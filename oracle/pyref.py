@@ -159,6 +159,19 @@ def map_batch(signals_f32, offsets_u64, n_threads):
     return list(hits), secs
 
 
+def self_align(prefix, sample_dist):
+    """-> list of uint64 arrays (the reference's std::vector<std::vector<u64>>)."""
+    L = lib()
+    L.ref_self_align.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ref_self_align.restype = C.c_uint64
+    n = C.c_uint64()
+    tot = L.ref_self_align(str(prefix).encode(), sample_dist, None, 0, None, 0, C.byref(n))
+    lens = np.empty(tot, dtype=np.uint64)
+    offs = np.empty(n.value + 1, dtype=np.uint64)
+    L.ref_self_align(str(prefix).encode(), sample_dist, lens.ctypes.data, tot, offs.ctypes.data, n.value + 1, C.byref(n))
+    return [lens[int(offs[i]):int(offs[i + 1])] for i in range(n.value)]
+
+
 def events(signal_f32):
     sig = np.ascontiguousarray(signal_f32, dtype=np.float32)
     out = np.zeros(sig.size // 2 + 16, dtype=REF_EVENT)

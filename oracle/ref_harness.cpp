@@ -30,6 +30,7 @@
 #undef private
 #undef protected
 
+#include "self_align_ref.hpp"
 #include "ref_harness.h"
 
 namespace {
@@ -167,6 +168,20 @@ int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len
 }
 
 void ref_set_max_chunks(uint32_t max_chunks) { ReadBuffer::PRMS.max_chunks = max_chunks; }
+
+// self_align (self_align_ref.cpp:34-91), the FM walk behind `uncalled index`: flattened into CSR form
+uint64_t ref_self_align(const char *bwa_prefix, uint32_t sample_dist, uint64_t *lens, uint64_t lens_cap, uint64_t *offsets,
+                        uint64_t offsets_cap, uint64_t *n_paths) {
+    std::vector<std::vector<u64>> r = self_align(bwa_prefix, sample_dist);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < r.size(); ++i) {
+        if (i < offsets_cap) offsets[i] = tot;
+        for (u64 v : r[i]) { if (tot < lens_cap) lens[tot] = v; ++tot; }
+    }
+    if (r.size() < offsets_cap) offsets[r.size()] = tot;
+    *n_paths = r.size();
+    return tot;
+}
 
 uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events) {
     EventDetector ed(Mapper::PRMS.event_prms);

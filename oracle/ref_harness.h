@@ -60,6 +60,10 @@ int ref_chunk_read(void *m, const float *signal, uint32_t n, uint32_t chunk_len,
                    uint32_t *chunks_used);
 void ref_set_max_chunks(uint32_t max_chunks);
 
+/* `uncalled index`: FM-range-size trajectories of sampled reference positions (self_align_ref.cpp:34-91) */
+uint64_t ref_self_align(const char *bwa_prefix, uint32_t sample_dist, uint64_t *lens, uint64_t lens_cap, uint64_t *offsets,
+                        uint64_t offsets_cap, uint64_t *n_paths);
+
 /* stage taps */
 uint32_t ref_events(const float *signal, uint32_t n, ref_event_t *out, uint32_t cap, float *mean_event_len, uint32_t *total_events);
 void ref_norm_levels(const float *means, uint32_t m, float *levels, float *scale, float *shift);

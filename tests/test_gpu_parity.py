@@ -57,6 +57,8 @@ def ecoli(tmp_path_factory):
     names, lens, codes = synthetic_genome(1, 4641652, seed=1)
     prefix = d / "ecoli_syn"
     build_from_codes(prefix, names, [""] * len(names), lens, codes)
+    from uncalled_amd.index_params import parameterize
+    parameterize(capi.Index(prefix), prefix)          # `uncalled index`: this reference's own .uncl
     return dict(prefix=prefix, codes=codes, lens=lens)
 
 
@@ -107,3 +109,33 @@ def test_batch_order_and_slot_independence(hip_lib, oracle_lib, example, goldens
     b = run(range(n - 1, -1, -1), 1)
     for f in ("mapped", "rd_st", "rd_en", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_sa", "n_lf"):
         assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.fixture(scope="module")
+def chr20(tmp_path_factory):
+    """SURVEY 8(d) `chr20_syn`: 64 444 167 bp, seed 2, 30 % of the length in N-runs (filled with seeded random bases and
+    recorded in .amb), BWA-format index with the suffix array built on the GPU (tools/build_index.py)."""
+    from tools.build_index import build_from_codes, masked_synthetic_genome
+    d = tmp_path_factory.mktemp("chr20")
+    names, lens, codes, holes, n_ambs = masked_synthetic_genome(1, 64444167, seed=2, name="chr20_syn")
+    prefix = d / "chr20_syn"
+    build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs, sa_device="cuda")
+    from uncalled_amd.index_params import parameterize
+    parameterize(capi.Index(prefix), prefix)
+    return dict(prefix=prefix, codes=codes, lens=lens)
+
+
+def test_chr20_scale_batch(hip_lib, oracle_lib, chr20):
+    """Config 3's index scale (seq_len 128.9 M: 64 MB of FM blocks + 1 GB dense SA, beyond any L2): 96 reads against
+    the oracle, bit-exact."""
+    n = 96
+    sim = simulate_reads(chr20["codes"], chr20["lens"], n, seed=43)
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    ix = capi.Index(chr20["prefix"], lib=hip_lib)
+    assert ix.size == 2 * 64444167
+    m = capi.Mapper(ix)
+    hits = m.map_batch(sim["signal"], sim["offsets"], cal)
+    oix = oracle_lib.Index(chr20["prefix"])
+    want = oracle_hits(oix, sim["signal"], sim["offsets"], cal)
+    assert_hits_equal(hits, want, "chr20")
+    assert int(hits["mapped"].sum()) >= 0.5 * n

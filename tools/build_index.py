@@ -140,7 +140,47 @@ def suffix_array(t):
     return sa
 
 
-def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, verbose=False):
+def suffix_array_torch(t, device="cuda"):
+    """Same prefix-doubling construction with the sorts on the GPU (torch): seconds for 10^8 symbols."""
+    import torch
+    n = int(t.size)
+    assert n < (1 << 31)
+    dev = torch.device(device)
+    K0 = 21
+    sym = torch.zeros(n + K0, dtype=torch.int64, device=dev)
+    sym[:n] = torch.as_tensor(t, device=dev).to(torch.int64) + 1
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    for j in range(K0):
+        key = (key << 3) | sym[j:j + n]
+    del sym
+    rank = torch.empty(n, dtype=torch.int64, device=dev)
+
+    def rerank(key):
+        sk, order = torch.sort(key)
+        newgrp = torch.ones(n, dtype=torch.int64, device=dev)
+        newgrp[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
+        del sk
+        rank[order] = torch.cumsum(newgrp, 0) - 1
+        del order, newgrp
+
+    rerank(key)
+    del key
+    k = K0
+    while int(rank.max().item()) + 1 < n:
+        nxt = torch.zeros(n, dtype=torch.int64, device=dev)
+        if k < n:
+            nxt[:n - k] = rank[k:] + 1
+        key = rank * (n + 1) + nxt      # < 2^62 for n < 2^31
+        del nxt
+        rerank(key)
+        del key
+        k *= 2
+    sa = torch.empty(n, dtype=torch.int64, device=dev)
+    sa[rank] = torch.arange(n, dtype=torch.int64, device=dev)
+    return sa.cpu().numpy()
+
+
+def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, verbose=False, sa_device=None):
     prefix = str(prefix)
     l_pac = int(codes.size)
     assert sum(lens) == l_pac
@@ -171,7 +211,7 @@ def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, u
     n = t.size
     if verbose:
         print(f"[build_index] suffix array of {n} symbols ...", file=sys.stderr)
-    sa = suffix_array(t)
+    sa = suffix_array_torch(t, sa_device) if sa_device else suffix_array(t)
     # full matrix rows: row 0 is the sentinel suffix (SA = n)
     sa_full = np.concatenate((np.array([n], dtype=np.int64), sa))
     del sa
@@ -241,6 +281,32 @@ def synthetic_genome(n_contigs, total_len, seed, gc=0.508, name="syn"):
     codes = rng.choice(4, size=total_len, p=p).astype(np.uint8)
     names = [f"{name}_{i + 1}" for i in range(n_contigs)]
     return names, lens, codes
+
+
+def masked_synthetic_genome(n_contigs, total_len, seed, masked_frac=0.30, mean_run=5000, gc=0.41, name="syn"):
+    """SURVEY 8(d) `chr20_syn`-style reference: i.i.d. contigs with `masked_frac` of the length covered by N-runs.
+    bwa replaces N by random bases and records the runs in .amb; here the runs are filled from the same seeded
+    generator (the genome is synthetic anyway) and returned as holes for the .amb file."""
+    names, lens, codes = synthetic_genome(n_contigs, total_len, seed, gc=gc, name=name)
+    rng = np.random.default_rng(seed + 1000)
+    holes, n_ambs = [], []
+    off = 0
+    for ln in lens:
+        n_runs = max(1, int(ln * masked_frac / mean_run))
+        starts = np.sort(rng.integers(0, max(1, ln - mean_run), n_runs))
+        runs = rng.geometric(1.0 / mean_run, n_runs)
+        cnt, last_end = 0, 0
+        for st, rl in zip(starts, runs):
+            st = max(int(st), last_end + 1)
+            en = min(ln, st + int(rl))
+            if en <= st:
+                continue
+            holes.append((off + st, en - st, "N"))
+            last_end = en
+            cnt += 1
+        n_ambs.append(cnt)
+        off += ln
+    return names, lens, codes, holes, n_ambs
 
 
 def write_fasta(path, names, lens, codes, width=80):

@@ -93,6 +93,7 @@ def load(path=None):
     L.unc_fm_get_neighbor.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.unc_fm_sa.argtypes = [vp, u32, vp, vp]
     L.unc_match_probs.argtypes = [vp, u32, vp, vp]
+    L.unc_self_align.argtypes = [vp, C.c_char_p, u32, u32, vp, vp, u64, C.POINTER(u64)]
     L.unc_mapper_create.argtypes = [vp, C.POINTER(Params), C.POINTER(MapperOpts), C.POINTER(vp)]
     L.unc_mapper_free.argtypes = [vp]
     L.unc_mapper_device_bytes.argtypes = [vp]; L.unc_mapper_device_bytes.restype = u64
@@ -182,6 +183,16 @@ class Index:
         out = np.empty_like(r)
         _check(self.L, self.L.unc_fm_sa(self.h, r.size, r.ctypes.data, out.ctypes.data))
         return out
+
+    def self_align(self, prefix, sample_dist, cap=128):
+        """self_align(bwa_prefix, sample_dist) of the reference: (lens uint64[n, cap], full_len uint32[n])."""
+        n = C.c_uint64()
+        _check(self.L, self.L.unc_self_align(self.h, str(prefix).encode(), sample_dist, cap, None, None, 0, C.byref(n)))
+        lens = np.zeros((n.value, cap), dtype=np.uint64)
+        full = np.zeros(n.value, dtype=np.uint32)
+        _check(self.L, self.L.unc_self_align(self.h, str(prefix).encode(), sample_dist, cap, lens.ctypes.data, full.ctypes.data,
+                                             n.value, C.byref(n)))
+        return lens, full
 
     def match_probs(self, levels):
         lv = np.ascontiguousarray(levels, dtype=np.float32)

@@ -38,6 +38,34 @@ __global__ void k_fm_sa(DevIndex ix, uint32_t n, const uint64_t *rows, uint64_t 
     out[i] = (ix.sa_dense && rows[i] != 0) ? fm_sa_dense(ix, rows[i], &steps) : fm_sa(ix, rows[i], &steps);
 }
 
+// `uncalled index` self-alignment (self_align_ref.cpp:34-91): from every sampled reference position walk
+// the complemented forward strand through the FM index and record the range size before each step, until the
+// range is unique or the contig ends.  One lane per sample; the first SA_CAP sizes are stored, the full
+// length is always counted (IndexParameterizer only reads the head of each trajectory, index.py:84-100).
+__global__ void k_self_align(DevIndex ix, const uint8_t *pac, uint32_t n_samples, const uint64_t *pos, const uint64_t *remain,
+                             uint64_t *out, uint32_t cap, uint32_t *out_len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const uint64_t p0 = pos[i], rem = remain[i];      // rem = contig length - offset within the contig
+    uint64_t *o = out + (size_t)i * cap;
+    uint32_t n = 0;
+    uint32_t b = 3u - ((pac[p0 >> 2] >> (((3u ^ (uint32_t)p0) & 3u) << 1)) & 3u);   // BASE_COMP_B[get_base(st+i)]
+    uint64_t s = ix.L2[b], e = ix.L2[b + 1];                                          // get_base_range
+    uint64_t j = 1;
+    for (; j < rem && e - s + 1 > 1; ++j) {
+        if (n < cap) o[n] = e - s + 1;
+        ++n;
+        const uint64_t pj = p0 + j;
+        b = 3u - ((pac[pj >> 2] >> (((3u ^ (uint32_t)pj) & 3u) << 1)) & 3u);
+        fm_get_neighbor(ix, s, e, b, &s, &e);
+    }
+    if (e - s + 1 > 0) {   // "happens on Ns"
+        if (n < cap) o[n] = e - s + 1;
+        ++n;
+    }
+    out_len[i] = n;
+}
+
 // Dense SA: every row walks to its sampled row once, at index load (bwt_sa for all rows in parallel)
 __global__ void k_dense_sa(DevIndex ix, uint64_t *out) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,6 +93,10 @@ void launch_kmer_ranges(const DevIndex &ix, uint64_t *out, hipStream_t st) {
 void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
                         uint64_t *oe, hipStream_t st) {
     hipLaunchKernelGGL(k_fm_neighbor, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, s, e, b, os, oe);
+}
+void launch_self_align(const DevIndex &ix, const uint8_t *pac, uint32_t n, const uint64_t *pos, const uint64_t *remain, uint64_t *out,
+                       uint32_t cap, uint32_t *out_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_self_align, dim3((n + 63) / 64), dim3(64), 0, st, ix, pac, n, pos, remain, out, cap, out_len);
 }
 void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st) {
     const uint64_t n = ix.seq_len + 1;

@@ -316,6 +316,10 @@ extern "C" void unc_index_model_tables(const unc_index_t *ix, float *mu, float *
     *ms = ix->model_stdv;
 }
 
+template <class T> struct DevBuf;
+extern "C" int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sample_dist, uint32_t cap, uint64_t *lens,
+                              uint32_t *full_len, uint64_t max_paths, uint64_t *n_paths);
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -976,5 +980,46 @@ extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_
         }
     }
     if (worst) return fail(worst, "device scratch overflow on at least one channel (see hit.status)");
+    return UNC_OK;
+}
+
+// ------------------------------------------------------------------ uncalled index: self alignment
+extern "C" int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sample_dist, uint32_t cap, uint64_t *lens,
+                              uint32_t *full_len, uint64_t max_paths, uint64_t *n_paths) {
+    if (!ix || !bwa_prefix || !n_paths || sample_dist == 0) return fail(UNC_ERR_ARG, "bad argument");
+    // the reference draws rand() once per base of every sequence after srand(0) (self_align_ref.cpp:37,67)
+    std::vector<uint64_t> pos, remain;
+    srand(0);
+    uint64_t st = 0;
+    for (const SeqAnn &sq : ix->seqs) {
+        for (uint64_t i = 0; i < sq.len; ++i) {
+            if (rand() % (int)sample_dist != 0) continue;
+            pos.push_back(st + i);
+            remain.push_back(sq.len - i);
+        }
+        st += sq.len;
+    }
+    *n_paths = pos.size();
+    if (!lens) return UNC_OK;
+    if (pos.size() > max_paths) return fail(UNC_ERR_ARG, "output too small: %zu trajectories", pos.size());
+    if (pos.empty()) return UNC_OK;
+    std::vector<char> pac;
+    if (!read_file(std::string(bwa_prefix) + ".pac", pac)) return fail(UNC_ERR_IO, "cannot read %s.pac", bwa_prefix);
+    if ((int64_t)pac.size() < ix->l_pac / 4 + 1) return fail(UNC_ERR_IO, "%s.pac too short", bwa_prefix);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t n = (uint32_t)pos.size();
+    DevBuf<uint8_t> d_pac;
+    DevBuf<uint64_t> d_pos, d_rem, d_out;
+    DevBuf<uint32_t> d_len;
+    HIPCHK(d_pac.alloc(pac.size() + 16)); HIPCHK(d_pos.alloc(n)); HIPCHK(d_rem.alloc(n)); HIPCHK(d_out.alloc((size_t)n * cap)); HIPCHK(d_len.alloc(n));
+    HIPCHK(hipMemcpy(d_pac.p, pac.data(), pac.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pos.p, pos.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_rem.p, remain.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_out.p, 0, (size_t)n * cap * 8));
+    launch_self_align(ix->dev, d_pac.p, n, d_pos.p, d_rem.p, d_out.p, cap, d_len.p, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(lens, d_out.p, (size_t)n * cap * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(full_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return UNC_OK;
 }

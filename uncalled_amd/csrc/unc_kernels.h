@@ -14,6 +14,8 @@ uint32_t map_kernel_waves_per_cu();
 void launch_kmer_ranges(const DevIndex &ix, uint64_t *out2048, hipStream_t st);
 void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
                         uint64_t *oe, hipStream_t st);
+void launch_self_align(const DevIndex &ix, const uint8_t *pac, uint32_t n, const uint64_t *pos, const uint64_t *remain, uint64_t *out,
+                       uint32_t cap, uint32_t *out_len, hipStream_t st);
 void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st);
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st);
 void launch_match_probs(const DevIndex &ix, uint32_t n, const float *levels, float *out, hipStream_t st);
