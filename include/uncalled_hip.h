@@ -151,8 +151,8 @@ int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sampl
  * body of MapPool::MapperThread::run (map_pool.cpp:130-158), for a whole batch of reads. */
 typedef struct {
     uint32_t n_slots;        /* resident wavefronts (0 = 8 per CU) */
-    uint32_t max_clusters;   /* seed clusters per read (0 = 16384) */
-    uint32_t max_seed_paths; /* seed-valid paths per event (0 = max_paths) */
+    uint32_t max_clusters;   /* seed clusters per slot (0 = 32768; reads that outgrow it are re-mapped with 16x the room) */
+    uint32_t max_seed_paths; /* seed-valid paths per event (0 = 2 * max_paths, the bound) */
     uint32_t reserved;
 } unc_mapper_opts_t;
 

@@ -201,3 +201,16 @@ def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, 
         for i in range(len(reads)):
             for name in ("mapped", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_lf"):
                 assert int(got[i]["hit"][name]) == int(goldens["chunk_hits"][i][f[name]]), (i, name)
+
+
+def case_cluster_overflow_remap(lib, oracle_lib, example, goldens):
+    """The reference's SeedTracker is unbounded; reads that outgrow the per-slot cluster array are re-mapped on the device
+    with more room until they fit.  Forced here with an absurdly small array."""
+    dev_index = _index(lib, example)
+    oix = oracle_lib.Index(example["prefix"])
+    n = 6
+    off = goldens["sim_offsets"][:n + 1].copy()
+    raw = goldens["sim_signal"][:int(off[n])]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    hits = capi.Mapper(dev_index, n_slots=2, max_clusters=8).map_batch(raw, off, cal)
+    assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "remap")

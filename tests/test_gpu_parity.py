@@ -49,6 +49,10 @@ def test_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels
     pc.case_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks, long_read)
 
 
+def test_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens):
+    pc.case_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens)
+
+
 @pytest.fixture(scope="module")
 def ecoli(tmp_path_factory):
     """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (tools/build_index.py)."""

@@ -40,3 +40,7 @@ def test_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
 @pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 6, None), (3, 9, None), (2, 8, 2)])
 def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks):
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
+
+
+def test_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens):
+    pc.case_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens)

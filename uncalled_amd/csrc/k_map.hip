@@ -39,6 +39,7 @@ struct MapArgs {
     uint32_t *next_read;    // work-queue head
     uint32_t max_steps;     // map_next calls per launch (0xFFFFFFFF = run to completion)
     uint32_t resume;        // 1: continue the read saved in SlotState (trace / chunked mode)
+    const uint32_t *read_list;  // batch mode: the queue hands out read_list[t] instead of t (re-runs of selected reads)
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
 };
 
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             if (lane == 0) t = atomicAdd(A.next_read, 1u);
             r = bcast32(t, 0);
             if (r >= A.rd.n_reads) break;
+            if (A.read_list) r = uniform32(A.read_list[r]);
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
@@ -871,10 +873,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 #include "unc_kernels.h"
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
-                uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st) {
+                uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
+                const uint32_t *read_list) {
     MapArgs a;
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
-    a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map;
+    a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list;
     hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
 }
 // resident single-wave workgroups per CU for the persistent grid: bounded by the kernel's LDS

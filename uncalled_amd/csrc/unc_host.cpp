@@ -391,11 +391,48 @@ struct unc_mapper {
     bool trace_active = false;
 };
 
+static void free_scratch(DevScratch &sc) {
+    void *ptrs[] = {sc.paths, sc.order, sc.keys, sc.seedp, sc.sa_tasks, sc.cl_keys, sc.cl_pay, sc.state};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    memset(&sc, 0, sizeof sc);
+}
+
+static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, uint32_t max_clusters, uint32_t max_seed_paths,
+                         size_t *bytes_out) {
+    memset(&sc, 0, sizeof sc);
+    sc.max_paths = P.max_paths;
+    uint32_t kc = 64;
+    while (kc < P.max_paths) kc <<= 1;
+    sc.keys_cap = kc;
+    sc.max_seed_paths = max_seed_paths;
+    sc.max_clusters = max_clusters;
+    const size_t S = n_slots;
+    size_t bytes = 0;
+#define ALLOC(field, type, count)                                            \
+    do {                                                                     \
+        size_t b_ = (size_t)(count) * sizeof(type);                          \
+        HIPCHK(hipMalloc((void **)&sc.field, b_));                           \
+        bytes += b_;                                                         \
+    } while (0)
+    ALLOC(paths, PathRec, S * 2 * sc.max_paths);
+    ALLOC(order, uint32_t, S * 2 * sc.max_paths);
+    ALLOC(keys, SortKey, S * 2 * sc.keys_cap);
+    ALLOC(seedp, SeedPath, S * sc.max_seed_paths);
+    ALLOC(sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
+    ALLOC(cl_keys, ClusterKey, S * sc.max_clusters);
+    ALLOC(cl_pay, ClusterPay, S * sc.max_clusters);
+    ALLOC(state, SlotState, S);
+#undef ALLOC
+    HIPCHK(hipMemset(sc.state, 0, S * sizeof(SlotState)));
+    if (bytes_out) *bytes_out = bytes;
+    return UNC_OK;
+}
+
 extern "C" void unc_mapper_free(unc_mapper_t *m) {
     if (!m) return;
     (void)hipSetDevice(m->ix->device);
-    void *ptrs[] = {m->sc.paths, m->sc.order, m->sc.keys, m->sc.seedp, m->sc.sa_tasks, m->sc.cl_keys, m->sc.cl_pay, m->sc.state,
-                    m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means};
+    free_scratch(m->sc);
+    void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -423,31 +460,12 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         n_slots = (uint32_t)prop.multiProcessorCount * map_kernel_waves_per_cu();
     }
     m->n_slots = n_slots;
-    DevScratch &sc = m->sc;
-    sc.max_paths = p->max_paths;
-    uint32_t kc = 64;
-    while (kc < p->max_paths) kc <<= 1;
-    sc.keys_cap = kc;
-    sc.max_seed_paths = (opts && opts->max_seed_paths) ? opts->max_seed_paths : p->max_paths;
-    sc.max_clusters = (opts && opts->max_clusters) ? opts->max_clusters : 16384;
-    const size_t S = n_slots;
     size_t bytes = 0;
-#define ALLOC(field, type, count)                                            \
-    do {                                                                     \
-        size_t b_ = (size_t)(count) * sizeof(type);                          \
-        HIPCHK(hipMalloc((void **)&sc.field, b_));                           \
-        bytes += b_;                                                         \
-    } while (0)
-    ALLOC(paths, PathRec, S * 2 * sc.max_paths);
-    ALLOC(order, uint32_t, S * 2 * sc.max_paths);
-    ALLOC(keys, SortKey, S * 2 * sc.keys_cap);
-    ALLOC(seedp, SeedPath, S * sc.max_seed_paths);
-    ALLOC(sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
-    ALLOC(cl_keys, ClusterKey, S * sc.max_clusters);
-    ALLOC(cl_pay, ClusterPay, S * sc.max_clusters);
-    ALLOC(state, SlotState, S);
-#undef ALLOC
-    HIPCHK(hipMemset(sc.state, 0, S * sizeof(SlotState)));
+    // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
+    const uint32_t msp = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
+    const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
+    int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes);
+    if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     m->device_bytes = bytes;
     HIPCHK(hipStreamCreate(&m->stream));
@@ -585,6 +603,40 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));
     HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
+    // The reference's SeedTracker is an unbounded std::set.  Reads whose seed clusters outgrew the per-slot array are
+    // mapped again, on the device, with 16x the room (a few slots only), until they fit.
+    {
+        std::vector<uint32_t> redo;
+        for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) redo.push_back(i);
+        uint64_t cap = m->sc.max_clusters;
+        while (!redo.empty() && cap < (1ull << 26)) {
+            cap *= 16;
+            size_t slots = (size_t)(8ull << 30) / (cap * (sizeof(ClusterKey) + sizeof(ClusterPay)));
+            if (slots > redo.size()) slots = redo.size();
+            if (slots > 1024) slots = 1024;
+            if (slots == 0) slots = 1;
+            DevScratch big;
+            int rc2 = alloc_scratch(big, m->P, slots, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
+            if (rc2) { free_scratch(big); return rc2; }
+            uint32_t *d_list = nullptr;
+            HIPCHK(hipMalloc((void **)&d_list, redo.size() * 4));
+            HIPCHK(hipMemcpyAsync(d_list, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
+            DevReads rd2 = rd;
+            rd2.n_reads = (uint32_t)redo.size();
+            launch_map(m->ix->dev, big, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, d_list);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<uint32_t> still;
+            for (uint32_t i : redo) {
+                HIPCHK(hipMemcpy(&m->h_results[i], m->d_results + i, sizeof(DevResult), hipMemcpyDeviceToHost));
+                if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) still.push_back(i);
+            }
+            (void)hipFree(d_list);
+            free_scratch(big);
+            redo.swap(still);
+        }
+    }
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
         fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
@@ -791,7 +843,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     sc.max_paths = p->max_paths;
     uint32_t kc = 64;
     while (kc < p->max_paths) kc <<= 1;
-    sc.keys_cap = kc; sc.max_seed_paths = p->max_paths; sc.max_clusters = 16384;
+    sc.keys_cap = kc; sc.max_seed_paths = 2 * p->max_paths; sc.max_clusters = 65536;
     const size_t S = n_channels;
     size_t bytes = 0;
 #define RALLOC(ptr, type, count)                                   \
