@@ -44,9 +44,21 @@ struct MapArgs {
 };
 
 struct Tracker {
-    uint32_t n, n_pay, n_lens, max1, max2, status;
+    uint32_t n, n_pay, n_lens, max1, max2, status, n_leaves, n_alloc;
     float len_sum;
     ClusterVal mm;
+};
+
+// SeedTracker's std::set<SeedCluster> as a two-level sorted structure: a directory of leaves (first key + leaf id,
+// kept sorted) over leaves of up to 64 keys each (one lane per key).  Insert / erase touch one leaf (a lane-parallel
+// shift inside 64 entries) plus, once every ~32 inserts, a leaf split; nothing is ever O(#clusters).
+constexpr uint32_t LEAF = 64;
+struct TrackerMem {
+    ClusterKey *leaves;   // [max_leaves][LEAF]
+    ClusterKey *dir;      // [max_leaves]: first key of the leaf, .pidx = leaf id
+    uint32_t *cnt;        // [max_leaves] by leaf id
+    ClusterPay *pay;      // append-only payload pool
+    uint32_t max_leaves, max_pay;
 };
 
 __device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
@@ -67,107 +79,188 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
     else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
 }
 
-// move keys [a,b) one slot up (towards higher indices)
-__device__ __forceinline__ void keys_shift_up(ClusterKey *keys, uint32_t a, uint32_t b, int lane) {
+// move directory entries [a,b) one slot up / down
+__device__ __forceinline__ void dir_shift_up(ClusterKey *dir, uint32_t a, uint32_t b, int lane) {
     for (uint32_t hi = b; hi > a;) {
         uint32_t lo = hi - a > 64 ? hi - 64 : a;
         uint32_t idx = lo + lane;
         ClusterKey k;
         bool have = idx < hi;
-        if (have) k = keys[idx];
+        if (have) k = dir[idx];
         wave_sync();
-        if (have) keys[idx + 1] = k;
+        if (have) dir[idx + 1] = k;
         wave_sync();
         hi = lo;
     }
 }
-// move keys [a,b) one slot down
-__device__ __forceinline__ void keys_shift_down(ClusterKey *keys, uint32_t a, uint32_t b, int lane) {
+__device__ __forceinline__ void dir_shift_down(ClusterKey *dir, uint32_t a, uint32_t b, int lane) {
     for (uint32_t lo = a; lo < b; lo += 64) {
         uint32_t idx = lo + lane;
         ClusterKey k;
         bool have = idx < b;
-        if (have) k = keys[idx];
+        if (have) k = dir[idx];
         wave_sync();
-        if (have) keys[idx - 1] = k;
+        if (have) dir[idx - 1] = k;
         wave_sync();
     }
 }
 
+// remove entry `slot` of directory position L (leaf id, count c); keeps the directory's first keys right
+__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, int lane) {
+    const uint32_t id = M.dir[L].pidx, c = M.cnt[id];
+    ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
+    ClusterKey k;
+    const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
+    if (mv) k = leaf[lane];
+    wave_sync();
+    if (mv) leaf[lane - 1] = k;
+    wave_sync();
+    if (c == 1) {
+        dir_shift_down(M.dir, L + 1, T.n_leaves, lane);
+        T.n_leaves--;
+        if (lane == 0) M.cnt[id] = 0;
+    } else {
+        if (lane == 0) {
+            M.cnt[id] = c - 1;
+            if (slot == 0) { ClusterKey f = leaf[0]; f.pidx = id; M.dir[L] = f; }
+        }
+    }
+    wave_sync();
+}
+
+// insert key at (L, slot); L == n_leaves means "after everything".  Returns false on leaf-pool exhaustion.
+__device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, ClusterKey nk, int lane) {
+    if (T.n_leaves == 0) {
+        if (T.n_alloc >= M.max_leaves) return false;
+        const uint32_t id = T.n_alloc++;
+        if (lane == 0) {
+            M.leaves[(size_t)id * LEAF] = nk;
+            M.cnt[id] = 1;
+            ClusterKey f = nk; f.pidx = id; M.dir[0] = f;
+        }
+        T.n_leaves = 1;
+        wave_sync();
+        return true;
+    }
+    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = M.cnt[M.dir[L].pidx]; }   // append to the last leaf
+    uint32_t id = M.dir[L].pidx, c = M.cnt[id];
+    if (c == LEAF) {
+        // split: the upper half moves to a fresh leaf that follows this one in the directory
+        if (T.n_alloc >= M.max_leaves) return false;
+        const uint32_t nid = T.n_alloc++;
+        ClusterKey *src = M.leaves + (size_t)id * LEAF, *dst = M.leaves + (size_t)nid * LEAF;
+        if (lane >= (int)(LEAF / 2)) dst[lane - LEAF / 2] = src[lane];
+        wave_sync();
+        dir_shift_up(M.dir, L + 1, T.n_leaves, lane);
+        if (lane == 0) {
+            ClusterKey f = dst[0]; f.pidx = nid; M.dir[L + 1] = f;
+            M.cnt[id] = LEAF / 2; M.cnt[nid] = LEAF / 2;
+        }
+        T.n_leaves++;
+        wave_sync();
+        if (slot > LEAF / 2) { L = L + 1; slot -= LEAF / 2; id = nid; }
+        c = LEAF / 2;
+    }
+    ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
+    ClusterKey k;
+    const bool mv = (uint32_t)lane >= slot && (uint32_t)lane < c;
+    if (mv) k = leaf[lane];
+    wave_sync();
+    if (mv) leaf[lane + 1] = k;
+    if (lane == 0) {
+        leaf[slot] = nk;
+        M.cnt[id] = c + 1;
+        if (slot == 0) { ClusterKey f = nk; f.pidx = id; M.dir[L] = f; }
+    }
+    wave_sync();
+    return true;
+}
+
 // SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
-__device__ void add_seed(Tracker &T, ClusterKey *keys, ClusterPay *pay, uint32_t max_clusters, uint32_t min_map_len,
-                         uint64_t ref_en, uint32_t ref_len, uint32_t evt, int lane) {
+__device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
+                         int lane) {
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
     const uint32_t e2 = evt;
 
-    // lower_bound(new_seed): 64-ary search
-    uint32_t lo = 0, hi = T.n;
+    // ---- lower_bound(new_seed): leaves whose first key sorts before the seed (64-ary search), then inside one leaf
+    uint32_t lo = 0, hi = T.n_leaves;
     while (hi - lo > 64) {
         uint32_t step = (hi - lo + 63) / 64;
         uint32_t idx = lo + (uint32_t)lane * step;
         bool less = false;
-        if (idx < hi) less = key_less(keys[idx], r2, e2);
+        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
         uint32_t c = (uint32_t)__popcll(__ballot(less));
         uint32_t nlo = c ? lo + (c - 1) * step + 1 : lo;
         uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
         lo = nlo;
         hi = nhi;
     }
-    uint32_t lb;
+    uint32_t d;
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
-        if (idx < hi) less = key_less(keys[idx], r2, e2);
-        lb = lo + (uint32_t)__popcll(__ballot(less));
+        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
+        d = lo + (uint32_t)__popcll(__ballot(less));
+    }
+    uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
+    if (d > 0) {
+        const uint32_t id = M.dir[d - 1].pidx, c = M.cnt[id];
+        bool less = false;
+        if ((uint32_t)lane < c) less = key_less(M.leaves[(size_t)id * LEAF + lane], r2, e2);
+        const uint32_t s = (uint32_t)__popcll(__ballot(less));
+        if (s < c) { lbL = d - 1; lbS = s; } else { lbL = d; lbS = 0; }
     }
 
-    // forward scan for the best-supported cluster this seed can extend (:169-191)
-    uint32_t best_len = 0, match = 0xFFFFFFFFu;
+    // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
+    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0;
     bool stop = false;
-    for (uint32_t pos = lb; pos < T.n && !stop; pos += 64) {
-        uint32_t idx = pos + (uint32_t)lane;
-        bool have = idx < T.n;
-        uint64_t r1 = 0;
-        uint32_t e1 = 0, tl = 0;
-        if (have) {
-            ClusterKey k = keys[idx];
-            r1 = k.rstart;
-            e1 = k.evt_en;
-            tl = pay[k.pidx].total_len;
-        }
-        uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
-        bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
-        bool far = have && dr >= (uint64_t)e2;
-        uint32_t tot;
-        uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
-        if (pm < best_len) pm = best_len;
-        bool taken = in_range && tl > pm;
-        bool brk = have && !taken && far;
-        uint64_t bm = __ballot(brk), tm = __ballot(taken);
-        if (bm) {
-            int first = __ffsll((unsigned long long)bm) - 1;
-            tm &= (1ull << first) - 1ull;
-            stop = true;
-        }
-        int last = tm ? 63 - __clzll((long long)tm) : 0;
-        uint32_t tl_last = bcast32(tl, last);
-        if (tm) {
-            match = pos + (uint32_t)last;
-            best_len = tl_last;
-        }
-    }
-
-    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at lb
     {
-        uint64_t kr = 0; uint32_t ke = 0;
-        if (lb < T.n) { ClusterKey k = keys[lb]; kr = k.rstart; ke = k.evt_en; }
-        exists_at_lb = lb < T.n && kr == r2 && ke == e2;
+        uint32_t curL = lbL, curS = lbS;
+        while (curL < T.n_leaves && !stop) {
+            const uint32_t id = M.dir[curL].pidx, c = M.cnt[id];
+            const uint32_t e = curS + (uint32_t)lane;
+            const bool have = e < c;
+            uint64_t r1 = 0;
+            uint32_t e1 = 0, tl = 0;
+            if (have) {
+                ClusterKey k = M.leaves[(size_t)id * LEAF + e];
+                r1 = k.rstart;
+                e1 = k.evt_en;
+                tl = M.pay[k.pidx].total_len;
+            }
+            const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
+            const bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
+            const bool far = have && dr >= (uint64_t)e2;
+            uint32_t tot;
+            uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
+            if (pm < best_len) pm = best_len;
+            const bool taken = in_range && tl > pm;
+            const bool brk = have && !taken && far;
+            uint64_t bm = __ballot(brk), tm = __ballot(taken);
+            if (bm) {
+                int first = __ffsll((unsigned long long)bm) - 1;
+                tm &= (1ull << first) - 1ull;
+                stop = true;
+            }
+            const int last = tm ? 63 - __clzll((long long)tm) : 0;
+            const uint32_t tl_last = bcast32(tl, last);
+            if (tm) { mL = curL; mS = curS + (uint32_t)last; best_len = tl_last; }
+            curL++;
+            curS = 0;
+        }
     }
 
-    if (match != 0xFFFFFFFFu) {
-        ClusterKey mk = keys[match];
-        ClusterPay mp = pay[mk.pidx];
+    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
+    if (lbL < T.n_leaves) {
+        const ClusterKey k = M.leaves[(size_t)M.dir[lbL].pidx * LEAF + lbS];
+        exists_at_lb = k.rstart == r2 && k.evt_en == e2;
+    }
+
+    if (mL != 0xFFFFFFFFu) {
+        const uint32_t mid = M.dir[mL].pidx;
+        const ClusterKey mk = M.leaves[(size_t)mid * LEAF + mS];
+        const ClusterPay mp = M.pay[mk.pidx];
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
         a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mp.total_len;
@@ -190,26 +283,25 @@ __device__ void add_seed(Tracker &T, ClusterKey *keys, ClusterPay *pay, uint32_t
             if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
         }
         // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2)
+        ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
         wave_sync();
-        if (lb == match) {
+        if (lbL == mL && lbS == mS) {
             if (lane == 0) {
-                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
-                keys[match] = nk;
+                M.leaves[(size_t)mid * LEAF + mS] = nk;
+                if (mS == 0) { ClusterKey f = nk; f.pidx = mid; M.dir[mL] = f; }
             }
+            wave_sync();
         } else if (exists_at_lb) {
-            keys_shift_down(keys, match + 1, T.n, lane);   // the re-insert collides: cluster dropped
+            tracker_erase(T, M, mL, mS, lane);     // the re-insert collides: the cluster is dropped
             T.n--;
         } else {
-            keys_shift_up(keys, lb, match, lane);
-            if (lane == 0) {
-                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
-                keys[lb] = nk;
-            }
+            tracker_erase(T, M, mL, mS, lane);     // lb sorts before the match: its position is unaffected
+            if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
         if (lane == 0) {
             ClusterPay np; np.ref_st = a.ref_st; np.rend = a.rend; np.evt_st = a.evt_st; np.total_len = a.total_len;
             np.pad[0] = np.pad[1] = 0;
-            pay[mk.pidx] = np;
+            M.pay[mk.pidx] = np;
         }
         wave_sync();
     } else {
@@ -221,15 +313,14 @@ __device__ void add_seed(Tracker &T, ClusterKey *keys, ClusterPay *pay, uint32_t
             T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
         }
         if (!exists_at_lb) {
-            if (T.n >= max_clusters || T.n_pay >= max_clusters) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (T.n_pay >= M.max_pay) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = T.n_pay;
             wave_sync();
-            keys_shift_up(keys, lb, T.n, lane);
+            if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             if (lane == 0) {
-                ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = T.n_pay;
-                keys[lb] = nk;
                 ClusterPay np; np.ref_st = r2; np.rend = ref_en; np.evt_st = e2; np.total_len = ref_len;
                 np.pad[0] = np.pad[1] = 0;
-                pay[T.n_pay] = np;
+                M.pay[T.n_pay] = np;
             }
             T.n++;
             T.n_pay++;
@@ -428,8 +519,12 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     SortKey *const skeys = ukeys + A.sc.keys_cap;
     SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
     uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
-    ClusterKey *const cl_keys = A.sc.cl_keys + (size_t)slot * A.sc.max_clusters;
-    ClusterPay *const cl_pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
+    TrackerMem TM;
+    TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
+    TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
+    TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
+    TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
+    TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
     SlotState *const st = A.sc.state + slot;
 
     const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
@@ -446,7 +541,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         if (A.resume && !fresh) {
             r = blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
-            T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map;
+            T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
             event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
@@ -454,7 +549,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         } else if (A.resume) {
             r = blockIdx.x;
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f;
+            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
             if (lane < NKMER / 32) s_flags[lane] = 0;
         } else {
@@ -464,7 +559,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             if (r >= A.rd.n_reads) break;
             if (A.read_list) r = uniform32(A.read_list[r]);
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f;
+            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
             if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
         }
@@ -823,7 +918,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
                     for (uint32_t j = 0; j < cnt; ++j) {
                         const uint64_t sa_end = uniform64(tasks[o + j]);
-                        add_seed(T, cl_keys, cl_pay, A.sc.max_clusters, P.min_map_len, sa_end, rl, ev, lane);
+                        add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane);
                     }
                 }
                 PHASE_END(6);
@@ -859,6 +954,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
                 st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
+                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];

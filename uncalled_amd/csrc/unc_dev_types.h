@@ -58,7 +58,7 @@ struct alignas(16) SlotState {
     uint32_t cur;            // which of the two path buffers holds the parents
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
-    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2;
+    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2, n_leaves, n_alloc, pad0;
     float len_sum;
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
@@ -83,7 +83,9 @@ struct DevScratch {
     SortKey *keys;         // [n_slots][2][keys_cap]   (unsorted | sorted)
     SeedPath *seedp;       // [n_slots][max_seed_paths]
     uint64_t *sa_tasks;    // [n_slots][WAVE * MAX_REP_COPY_LIMIT]
-    ClusterKey *cl_keys;   // [n_slots][max_clusters]
+    ClusterKey *cl_keys;   // [n_slots][max_clusters / 16][64]: leaves of the seed-cluster set (16 bytes per key)
+    ClusterKey *cl_dir;    // [n_slots][max_clusters / 16]: sorted directory (first key + leaf id)
+    uint32_t *cl_cnt;      // [n_slots][max_clusters / 16]: keys per leaf
     ClusterPay *cl_pay;    // [n_slots][max_clusters]
     SlotState *state;      // [n_slots]
     uint32_t max_paths, keys_cap, max_seed_paths, max_clusters;

@@ -392,7 +392,7 @@ struct unc_mapper {
 };
 
 static void free_scratch(DevScratch &sc) {
-    void *ptrs[] = {sc.paths, sc.order, sc.keys, sc.seedp, sc.sa_tasks, sc.cl_keys, sc.cl_pay, sc.state};
+    void *ptrs[] = {sc.paths, sc.order, sc.keys, sc.seedp, sc.sa_tasks, sc.cl_keys, sc.cl_dir, sc.cl_cnt, sc.cl_pay, sc.state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     memset(&sc, 0, sizeof sc);
 }
@@ -419,7 +419,9 @@ static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, 
     ALLOC(keys, SortKey, S * 2 * sc.keys_cap);
     ALLOC(seedp, SeedPath, S * sc.max_seed_paths);
     ALLOC(sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
-    ALLOC(cl_keys, ClusterKey, S * sc.max_clusters);
+    ALLOC(cl_keys, ClusterKey, S * (sc.max_clusters / 16) * 64);   // leaves are at least half full after a split
+    ALLOC(cl_dir, ClusterKey, S * (sc.max_clusters / 16));
+    ALLOC(cl_cnt, uint32_t, S * (sc.max_clusters / 16));
     ALLOC(cl_pay, ClusterPay, S * sc.max_clusters);
     ALLOC(state, SlotState, S);
 #undef ALLOC
@@ -611,7 +613,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         uint64_t cap = m->sc.max_clusters;
         while (!redo.empty() && cap < (1ull << 26)) {
             cap *= 16;
-            size_t slots = (size_t)(8ull << 30) / (cap * (sizeof(ClusterKey) + sizeof(ClusterPay)));
+            size_t slots = (size_t)(8ull << 30) / (cap * (4 * sizeof(ClusterKey) + sizeof(ClusterPay) + 2));
             if (slots > redo.size()) slots = redo.size();
             if (slots > 1024) slots = 1024;
             if (slots == 0) slots = 1;
@@ -754,10 +756,20 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
     HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
-    std::vector<ClusterKey> keys(s.n_clusters ? s.n_clusters : 1);
+    // flatten the two-level set (directory order, then slot order inside each leaf)
+    const uint32_t max_leaves = m->sc.max_clusters / 16;
+    std::vector<ClusterKey> dir(s.n_leaves ? s.n_leaves : 1), leaves((size_t)(s.n_alloc ? s.n_alloc : 1) * 64), keys;
+    std::vector<uint32_t> cnt(s.n_alloc ? s.n_alloc : 1);
     std::vector<ClusterPay> pay(s.n_pay ? s.n_pay : 1);
-    HIPCHK(hipMemcpy(keys.data(), m->sc.cl_keys, (size_t)s.n_clusters * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    (void)max_leaves;
+    HIPCHK(hipMemcpy(dir.data(), m->sc.cl_dir, (size_t)s.n_leaves * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(leaves.data(), m->sc.cl_keys, (size_t)s.n_alloc * 64 * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), m->sc.cl_cnt, (size_t)s.n_alloc * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(pay.data(), m->sc.cl_pay, (size_t)s.n_pay * sizeof(ClusterPay), hipMemcpyDeviceToHost));
+    for (uint32_t L = 0; L < s.n_leaves; ++L)
+        for (uint32_t e = 0; e < cnt[dir[L].pidx]; ++e) keys.push_back(leaves[(size_t)dir[L].pidx * 64 + e]);
+    if (keys.size() != s.n_clusters) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: %zu keys, %u clusters", keys.size(), s.n_clusters);
+    if (keys.empty()) keys.resize(1);
     for (uint32_t i = 0; i < s.n_clusters && i < cap; ++i) {
         const ClusterPay &p = pay[keys[i].pidx];
         out[i].ref_st = p.ref_st; out[i].ref_en_start = keys[i].rstart; out[i].ref_en_end = p.rend;
@@ -818,7 +830,8 @@ struct unc_rt {
 extern "C" void unc_rt_free(unc_rt_t *rt) {
     if (!rt) return;
     (void)hipSetDevice(rt->ix->device);
-    void *ptrs[] = {rt->sc.paths, rt->sc.order, rt->sc.keys, rt->sc.seedp, rt->sc.sa_tasks, rt->sc.cl_keys, rt->sc.cl_pay, rt->sc.state,
+    void *ptrs[] = {rt->sc.paths, rt->sc.order, rt->sc.keys, rt->sc.seedp, rt->sc.sa_tasks, rt->sc.cl_keys, rt->sc.cl_dir, rt->sc.cl_cnt,
+                    rt->sc.cl_pay, rt->sc.state,
                     rt->d_chans, rt->d_ring, rt->d_desc, rt->d_info, rt->d_ring0, rt->d_newread, rt->d_slotmap, rt->d_next, rt->d_moff,
                     rt->d_results, rt->d_raw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -858,7 +871,9 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     RALLOC(sc.keys, SortKey, S * 2 * sc.keys_cap);
     RALLOC(sc.seedp, SeedPath, S * sc.max_seed_paths);
     RALLOC(sc.sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
-    RALLOC(sc.cl_keys, ClusterKey, S * sc.max_clusters);
+    RALLOC(sc.cl_keys, ClusterKey, S * (sc.max_clusters / 16) * 64);
+    RALLOC(sc.cl_dir, ClusterKey, S * (sc.max_clusters / 16));
+    RALLOC(sc.cl_cnt, uint32_t, S * (sc.max_clusters / 16));
     RALLOC(sc.cl_pay, ClusterPay, S * sc.max_clusters);
     RALLOC(sc.state, SlotState, S);
     RALLOC(rt->d_chans, RtChan, S);
