@@ -65,8 +65,9 @@ def cpu_baseline(prefix, sim_signal_host, offsets, calib, hits_gpu, seconds_targ
     cores = os.cpu_count() or 1
     kind = "reference" if pyref.available() else "port"
     n_avail = offsets.size - 1
-    # ~0.1 s per read per core on this class of host: size the sample for about seconds_target of wall time
-    n = int(min(n_avail, max(cores * 8, seconds_target * cores / 0.12)))
+    # measured on the GPU box's 256 oversubscribed host threads: ~3 thread-seconds per read with this reference's
+    # thresholds; size the sample for about seconds_target of wall time
+    n = int(min(n_avail, max(cores * 2, seconds_target * cores / 3.0)))
     off = offsets[:n + 1]
     raw = sim_signal_host[:int(off[-1])]
     sig = po.calibrate(raw, float(calib["range"][0]), float(calib["offset"][0]), float(calib["digitisation"][0]))

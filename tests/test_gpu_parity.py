@@ -53,6 +53,10 @@ def test_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens):
     pc.case_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens)
 
 
+def test_wide_sort_keys(hip_lib, oracle_lib, example, goldens, monkeypatch):
+    pc.case_wide_sort_keys(hip_lib, oracle_lib, example, goldens, monkeypatch)
+
+
 @pytest.fixture(scope="module")
 def ecoli(tmp_path_factory):
     """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (tools/build_index.py)."""

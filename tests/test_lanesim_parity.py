@@ -44,3 +44,7 @@ def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels
 
 def test_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens):
     pc.case_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens)
+
+
+def test_wide_sort_keys(sim_lib, oracle_lib, example, goldens, monkeypatch):
+    pc.case_wide_sort_keys(sim_lib, oracle_lib, example, goldens, monkeypatch)

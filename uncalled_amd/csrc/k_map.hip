@@ -440,6 +440,100 @@ __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lan
     }
 }
 
+// ---- narrow mode: start, length and creation index of a child fit one 64-bit key (index-dependent, decided at load:
+// DevIndex::key_len_bits).  Half the data to move per sort stage; the seed_prob
+// ordering inside runs of equal ranges is recovered afterwards by a segmented max over the children's info words.
+template <int E>
+__device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, uint32_t k, uint32_t j_from, int lane) {
+    for (uint32_t j = j_from; j > 0; j >>= 1) {
+        if (j >= (uint32_t)E) {
+            const uint32_t d = j / (uint32_t)E;
+            const bool lower = ((uint32_t)lane & d) == 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
+                const uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
+                const bool up = (p & k) == 0;
+                const bool want_min = lower == up;
+                const bool gt = a[e] > pa;
+                if (want_min ? gt : !gt) a[e] = pa;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 1; jj < E; jj <<= 1) {
+                if (j == (uint32_t)jj) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (!(e & jj)) {
+                            const int pe = e | jj;
+                            const uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
+                            const bool up = (p & k) == 0;
+                            const bool gt = a[e] > a[pe];
+                            if (up ? gt : !gt) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// in: the children's SortKey records (.a = packed key); out: compact sorted uint64 array
+template <int E>
+__device__ void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+    uint64_t a[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
+        a[e] = i < n ? in[i].a : ~0ull;
+    }
+    for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages64<E>(a, 0, k, k >> 1, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
+        if (i < n) out[i] = a[e];
+    }
+}
+
+__device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+    constexpr int E = 8;
+    constexpr uint32_t B = 64u * E;
+    uint32_t N = 2 * B;
+    while (N < n) N <<= 1;
+    uint64_t a[E];
+    for (uint32_t base = 0; base < N; base += B) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+            a[e] = i < n ? in[i].a : ~0ull;
+        }
+        for (uint32_t k = 2; k <= B; k <<= 1) merge_stages64<E>(a, base, k, k >> 1, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
+    }
+    wave_sync();
+    for (uint32_t k = 2 * B; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= B; j >>= 1) {
+            for (uint32_t t = (uint32_t)lane; t < N / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t p = i | j;
+                const uint64_t x = out[i], y = out[p];
+                const bool up = (i & k) == 0;
+                if (up ? x > y : x < y) { out[i] = y; out[p] = x; }
+            }
+            wave_sync();
+        }
+        for (uint32_t base = 0; base < N; base += B) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
+            merge_stages64<E>(a, base, k, B >> 1, lane);
+#pragma unroll
+            for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
+        }
+        wave_sync();
+    }
+}
+
 __device__ __forceinline__ uint32_t float_orderable(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -451,7 +545,7 @@ __device__ __forceinline__ uint32_t float_orderable(float f) {
 struct ChildHdr { uint32_t moves, meta, wslot; float seed_prob, appended; };
 __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, float last, float second, uint64_t s, uint64_t e,
                                                uint32_t kmer, float prob, uint32_t move, const unc_params_t &P,
-                                               uint32_t child_idx, SortKey &key) {
+                                               uint32_t child_idx, uint32_t key_len_bits, SortKey &key) {
     const uint32_t PATH_MASK = (1u << SEED_LEN) - 1u, PATH_TAIL_MOVE = 1u << (SEED_LEN - 1);
     const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u, pstay = (pmeta >> META_STAY_SHIFT) & 255u;
     const uint32_t head = (pmeta >> META_HEAD_SHIFT) & 31u;
@@ -479,7 +573,7 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
     const uint32_t move_count = (uint32_t)__popc(moves);
     const bool seed_ok = len == P.seed_len && c.seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
                          (float)(len - move_count) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
-    key.a = (s << KEY_LEN_BITS) | (e - s);
+    key.a = key_len_bits ? ((((s << key_len_bits) | (e - s)) << 16) | child_idx) : ((s << KEY_LEN_BITS) | (e - s));
     key.b = ((uint64_t)float_orderable(c.seed_prob) << 32) | ((uint64_t)child_idx << 16) | (move_count << KEYB_MOVES_SHIFT) |
             (seed_ok ? KEYB_SEED_FLAG : 0u) | kmer;
     return c;
@@ -529,6 +623,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 
     const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
     const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
+    const uint32_t klb = ix.key_len_bits;            // 0: 128-bit sort keys; else narrow 64-bit keys (see sort_regs64)
     const uint32_t kvalid = ix.kmer_valid[lane];     // bit j: k-mer j*64+lane occurs in the reference
 
     for (;;) {
@@ -611,6 +706,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             PHASE_END(0);
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
+            bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort below)
             // parent index list and record headers are fetched one / two passes ahead of their use
             uint32_t phys_cur = (uint32_t)lane < n_parents ? pord[lane] : 0u;
             uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? pord[lane + WAVE] : 0u;
@@ -749,9 +845,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         uint32_t ck, mv;
                         if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
                         else { cs = s_res_s[ci]; ce = s_res_e[ci]; ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1; }
+                        if (klb && cs == ce && (cs == ix.kmer_ranges[2 * ck] || cs == ix.kmer_ranges[2 * ck + 1])) bchild = true;
                         SortKey key;
                         const uint32_t gi = nchild + li;
-                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, key);
+                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
                         PathRec *cp = chd + gi;
                         uint4 *w = reinterpret_cast<uint4 *>(cp);
                         w[0] = (make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
@@ -774,35 +871,97 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             const uint32_t n = nchild;
             uint32_t n_surv = 0, n_src = 0;
             if (n > 0) {
-                if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
-                else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
-                else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
-                else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
-                else sort_hybrid(ukeys, skeys, n, lane);
+                uint64_t *const skeys64 = reinterpret_cast<uint64_t *>(skeys);
+                uint32_t kl = klb;     // key mode of THIS event
+                if (kl) {
+                    if (n <= 64) sort_regs64<1>(ukeys, skeys64, n, lane);
+                    else if (n <= 128) sort_regs64<2>(ukeys, skeys64, n, lane);
+                    else if (n <= 256) sort_regs64<4>(ukeys, skeys64, n, lane);
+                    else if (n <= 512) sort_regs64<8>(ukeys, skeys64, n, lane);
+                    else sort_hybrid64(ukeys, skeys64, n, lane);
+                    // BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can
+                    // share a boundary row and two children with the SAME one-row range may carry DIFFERENT k-mers.  The
+                    // reference then walks them in seed_prob order (mapper.cpp:543-563 runs per position), which the narrow
+                    // key cannot express: such an event (rare) is re-sorted with the full 128-bit keys.
+                    if (__any(bchild)) {
+                        wave_sync();
+                        bool mixed = false;
+                        for (uint32_t base = 0; base + 1 < n; base += WAVE) {
+                            const uint32_t i = base + (uint32_t)lane;
+                            if (i + 1 < n) {
+                                const uint64_t ki = skeys64[i], kn = skeys64[i + 1];
+                                if ((ki >> 16) == (kn >> 16) &&
+                                    ((ukeys[ki & 0xFFFFu].b ^ ukeys[kn & 0xFFFFu].b) & META_KMER_MASK)) mixed = true;
+                            }
+                        }
+                        if (__any(mixed)) {
+                            for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+                                const uint64_t ri = ukeys[i].a >> 16;
+                                ukeys[i].a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
+                            }
+                            kl = 0;
+                            wave_sync();
+                        }
+                    }
+                }
+                if (!kl) {
+                    if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
+                    else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
+                    else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
+                    else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
+                    else sort_hybrid(ukeys, skeys, n, lane);
+                }
                 wave_sync();
                 PHASE_END(2);
 
                 uint32_t carry_kmer = NKMER;
-                uint64_t carry_U = 0;
+                uint64_t carry_U = 0, carry_range = ~0ull, carry_w = 0;
                 const uint32_t room = max_paths - n;   // sources that still fit
                 for (uint32_t base = 0; base < n; base += WAVE) {
                     const uint32_t i = base + (uint32_t)lane;
                     const bool have = i < n;
-                    SortKey ki, kn;
-                    ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
-                    if (have) ki = skeys[i];
                     const bool has_next = i + 1 < n;
-                    if (has_next) kn = skeys[i + 1];
-                    const uint64_t start = ki.a >> KEY_LEN_BITS, end = start + (ki.a & KEY_LEN_MASK);
-                    const uint32_t kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
-                    const uint32_t idx = (uint32_t)(ki.b >> 16) & 0xFFFFu;
-                    const uint32_t nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
-                    const uint64_t nstart = kn.a >> KEY_LEN_BITS;
+                    uint64_t start, end, nstart, sb;     // sb: info word of the child that survives at this position
+                    uint32_t kmer, nkmer;
+                    bool dup;
+                    if (kl) {
+                        // narrow keys: range | creation index; the info word (seed_prob, idx, flags, k-mer) is gathered
+                        const uint64_t ki = have ? skeys64[i] : ~0ull, kn = has_next ? skeys64[i + 1] : ~0ull;
+                        const uint64_t ri = ki >> 16, rn = kn >> 16;
+                        const uint64_t bi = have ? ukeys[ki & 0xFFFFu].b : 0ull, bn = has_next ? ukeys[kn & 0xFFFFu].b : 0ull;
+                        start = ri >> kl; end = start + (ri & ((1ull << kl) - 1ull));
+                        nstart = rn >> kl;
+                        kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
+                        nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
+                        dup = has_next && rn == ri;
+                        // among equal ranges the reference keeps the highest (seed_prob, creation order): a running max of
+                        // the info words over each run, read off at the run's last position
+                        uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
+                        if (lane == 0) pr = carry_range;
+                        const bool rhead = !have || ri != pr;
+                        sb = seg_incl_max64(bi, rhead);
+                        const uint64_t rheads = __ballot(rhead);
+                        if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb) sb = carry_w;
+                        const uint32_t nvv = n - base < WAVE ? n - base : WAVE;
+                        carry_range = bcast64(ri, (int)nvv - 1);
+                        carry_w = bcast64(sb, (int)nvv - 1);
+                    } else {
+                        SortKey ki, kn;
+                        ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
+                        if (have) ki = skeys[i];
+                        if (has_next) kn = skeys[i + 1];
+                        start = ki.a >> KEY_LEN_BITS; end = start + (ki.a & KEY_LEN_MASK);
+                        nstart = kn.a >> KEY_LEN_BITS;
+                        kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
+                        nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
+                        dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
+                        sb = ki.b;                               // sorted by seed_prob inside the run: the last one survives
+                    }
+                    const uint32_t idx = (uint32_t)(sb >> 16) & 0xFFFFu;
                     uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
                     if (lane == 0) pk = carry_kmer;
                     const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
                     const bool next_same = has_next && nkmer == kmer;
-                    const bool dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
                     const bool psrc = have && s_probs[have ? kmer : 0] >= source_prob;
                     // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
                     uint64_t U = seg_incl_max64(have ? end + 1 : 0, first || !have);
@@ -829,14 +988,14 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     if (surv) nord[n_surv + (uint32_t)prefix_popc(sm)] = idx;
                     n_surv += (uint32_t)__popcll(sm);
                     // update_seeds(child, false), :601 -- validity was decided at creation
-                    const bool sv = surv && (ki.b & KEYB_SEED_FLAG);
+                    const bool sv = surv && (sb & KEYB_SEED_FLAG);
                     const uint64_t svm = __ballot(sv);
                     if (sv) {
                         const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
                         atomicOr(&chd[idx].meta, META_SA_CHECKED);   // path.sa_checked_ = true (no value returned: no round trip)
                         if (pos < A.sc.max_seed_paths) {
                             SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
-                            sp.ref_len = (uint32_t)(ki.b >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
+                            sp.ref_len = (uint32_t)(sb >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
                             seedp[pos] = sp;
                         }
                     }

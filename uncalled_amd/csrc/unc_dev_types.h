@@ -74,6 +74,8 @@ struct DevIndex {
     const uint16_t *kmer_valid; // [64]: bit j of entry l = range of k-mer j*64+l is non-empty
     uint64_t primary, seq_len;
     uint64_t L2[5];
+    uint32_t key_len_bits;      // > 0: (start, length, child index) pack into one 64-bit sort key with this many length bits
+    uint32_t pad_;
     float thresholds[64];
 };
 

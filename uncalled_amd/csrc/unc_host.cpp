@@ -259,6 +259,20 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         if (s <= e && e - s >= (1ull << KEY_LEN_BITS)) return fail(UNC_ERR_ARG, "k-mer %d occurs more than 2^30 times: unsupported", k);
     }
     {
+        // narrow sort keys: start | length | 16-bit creation index in 64 bits when the reference allows it
+        uint64_t max_len = 0;
+        for (int k = 0; k < NKMER; ++k) {
+            uint64_t s = ix->kmer_ranges[2 * k], e = ix->kmer_ranges[2 * k + 1];
+            if (s <= e && e - s > max_len) max_len = e - s;
+        }
+        uint32_t start_bits = 1, len_bits = 1;
+        while ((n >> start_bits) != 0) ++start_bits;
+        while ((max_len >> len_bits) != 0) ++len_bits;
+        const char *wide = getenv("UNC_WIDE_KEYS");
+        ix->dev.key_len_bits = (start_bits + len_bits + 16 <= 64 && !(wide && wide[0] == '1')) ? len_bits : 0;
+        ix->dev.pad_ = 0;
+    }
+    {
         uint16_t valid[WAVE];
         for (int l = 0; l < WAVE; ++l) {
             valid[l] = 0;
