@@ -1,0 +1,162 @@
+"""`python -m uncalled_amd {index,map,pafstats}` -- the offline subcommands of the reference's `scripts/uncalled`
+(index_cmd :38-78, map_cmd :126-167, pafstats) with the same options (uncalled/args.py:90-124,244-304) on the GPU path.
+"""
+import argparse
+import os
+import sys
+import time
+
+MAX_SLEEP = 0.01
+BWA_SUFFS = (".amb", ".ann", ".bwt", ".pac", ".sa")
+
+
+def _assert_exists(fname):
+    if not os.path.exists(fname):
+        sys.stderr.write("Error: '%s' does not exist\n" % fname)
+        sys.exit(1)
+
+
+def load_fast5s(paths, recursive):
+    """scripts/uncalled:80-119: directories (optionally recursive), .fast5 files, or text files of file names."""
+    def keep(path):
+        if path.startswith("#") or not path.endswith("fast5"):
+            return None
+        path = os.path.abspath(path)
+        if not os.path.isfile(path):
+            sys.stderr.write("Warning: \"%s\" is not a fast5 file.\n" % path)
+            return None
+        return path
+
+    for path in paths:
+        path = path.strip()
+        if not os.path.exists(path):
+            sys.stderr.write("Error: \"%s\" does not exist\n" % path)
+            sys.exit(1)
+        if os.path.isdir(path):
+            if recursive:
+                for root, _, files in os.walk(path):
+                    for f in files:
+                        yield keep(os.path.join(root, f))
+            else:
+                for f in os.listdir(path):
+                    yield keep(os.path.join(path, f))
+        elif path.endswith(".fast5"):
+            yield keep(path)
+        else:
+            with open(path) as fh:
+                for line in fh:
+                    yield keep(line.strip())
+
+
+def index_cmd(args):
+    from . import capi, index_params
+    prefix = args.bwa_prefix or args.fasta_filename
+    if all(os.path.exists(prefix + s) for s in BWA_SUFFS):
+        sys.stderr.write("Using previously built BWA index.\nNote: to fully re-build the index delete files with the "
+                         "\"%s.*\" prefix.\n" % prefix)
+    else:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import build_index
+        build_index.build_from_fasta(args.fasta_filename, prefix, verbose=True)
+    sys.stderr.write("Initializing parameter search\n")
+    presets = [("default", dict(tgt_speed=115))]
+    for tgt in (args.probs.split(",") if args.probs else []):
+        presets.append(("prob_%s" % tgt, dict(tgt_prob=float(tgt))))
+    for tgt in (args.speeds.split(",") if args.speeds else []):
+        presets.append(("speed_%s" % tgt, dict(tgt_speed=float(tgt))))
+    if not os.path.exists(prefix + ".uncl"):
+        open(prefix + ".uncl", "w").close()   # the loader wants the file; self-align does not read thresholds
+    ix = capi.Index(prefix, device=args.device)
+    index_params.parameterize(ix, prefix, presets=presets, max_sample_dist=args.max_sample_dist,
+                              min_samples=args.min_samples, max_samples=args.max_samples, kmer_len=args.kmer_len,
+                              matchpr1=args.matchpr1, matchpr2=args.matchpr2,
+                              pathlen_percentile=args.pathlen_percentile, max_replen=args.max_replen)
+    sys.stderr.write("Done\n")
+
+
+def map_cmd(args):
+    from . import _uncalled_amd as unc
+    conf = unc.Conf()
+    for k, v in vars(args).items():
+        if v is not None and not k.startswith("_") and hasattr(conf, k):
+            setattr(conf, k, v)
+    _assert_exists(conf.bwa_prefix + ".bwt")
+    _assert_exists(conf.bwa_prefix + ".uncl")
+    if conf.read_list:
+        _assert_exists(conf.read_list)
+    mapper = unc.MapPool(conf)
+    sys.stderr.write("Loading fast5s\n")
+    for f in load_fast5s(args.fast5s, args.recursive):
+        if f is not None:
+            mapper.add_fast5(f)
+    sys.stderr.write("Mapping\n")
+    sys.stderr.flush()
+    try:
+        while mapper.running():
+            t0 = time.time()
+            for p in mapper.update():
+                p.print_paf()
+            dt = time.time() - t0
+            if dt < MAX_SLEEP:
+                time.sleep(MAX_SLEEP - dt)
+    except KeyboardInterrupt:
+        pass
+    sys.stderr.write("Finishing\n")
+    mapper.stop()
+
+
+def get_parser():
+    from . import index_params, pafstats
+    d = index_params.DEFAULTS
+    ap = argparse.ArgumentParser(prog="uncalled_amd", description="Rapidly maps raw nanopore signal to DNA references (MI355X)")
+    sp = ap.add_subparsers(dest="subcmd")
+    sp.required = True
+
+    p = sp.add_parser("index", help="Builds the UNCALLED index of a FASTA reference")
+    p.add_argument("fasta_filename", type=str, help="FASTA file to index")
+    p.add_argument("-o", "--bwa-prefix", type=str, default=None, help="Index output prefix. Will use input fasta filename by default")
+    p.add_argument("-s", "--max-sample-dist", type=int, default=d["max_sample_dist"], help="Maximum average sampling distance between reference self-alignments.")
+    p.add_argument("--min-samples", type=int, default=d["min_samples"], help="Minimum number of self-alignments to produce (approximate, due to deterministically random start locations)")
+    p.add_argument("--max-samples", type=int, default=d["max_samples"], help="Maximum number of self-alignments to produce (approximate, due to deterministically random start locations)")
+    p.add_argument("-k", "--kmer-len", type=int, default=d["kmer_len"], help="Model k-mer length")
+    p.add_argument("-1", "--matchpr1", type=float, default=d["matchpr1"], help="Minimum event match probability")
+    p.add_argument("-2", "--matchpr2", type=float, default=d["matchpr2"], help="Maximum event match probability")
+    p.add_argument("-f", "--pathlen-percentile", type=float, default=d["pathlen_percentile"], help="")
+    p.add_argument("-m", "--max-replen", type=int, default=d["max_replen"], help="")
+    p.add_argument("--probs", type=str, default=None, help="Find parameters with specified target probabilites (comma separated)")
+    p.add_argument("--speeds", type=str, default=None, help="Find parameters with specified speed coefficents (comma separated)")
+    p.add_argument("--device", type=int, default=0, help="GPU ordinal")
+
+    p = sp.add_parser("map", help="Map fast5 files to a DNA reference")
+    p.add_argument("bwa_prefix", type=str, help="BWA prefix to mapping to. Must be processed by \"uncalled index\".")
+    p.add_argument("-p", "--idx-preset", type=str, default="default", help="Mapping mode")
+    p.add_argument("fast5s", nargs="+", type=str, help="Reads to map: directories, fast5 files, or text files with one fast5 name per line")
+    p.add_argument("-r", "--recursive", action="store_true")
+    p.add_argument("-l", "--read-list", type=str, default=None, help="Only map reads with these ids")
+    p.add_argument("-n", "--max-reads", type=int, default=None, help="Maximum number of reads to map")
+    p.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility; the GPU path batches reads instead")
+    p.add_argument("--num-channels", type=int, default=512)
+    p.add_argument("-e", "--max-events", type=int, default=30000, help="Will give up on a read after this many events have been processed")
+    p.add_argument("-c", "--max-chunks", type=int, default=1000000, help="Will give up on a read after this many chunks have been processed")
+    p.add_argument("--chunk-time", type=float, default=1, help="Length of chunks in seconds")
+    p.add_argument("--device", type=int, default=0, help="GPU ordinal")
+    p.add_argument("--batch-reads", type=int, default=4096, help="Reads per GPU batch")
+
+    p = sp.add_parser("pafstats", help="Computes speed and accuracy of UNCALLED mappings")
+    pafstats.add_opts(p)
+    return ap
+
+
+def main(argv=None):
+    args = get_parser().parse_args(argv)
+    if args.subcmd == "index":
+        index_cmd(args)
+    elif args.subcmd == "map":
+        map_cmd(args)
+    else:
+        from . import pafstats
+        pafstats.run(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+// pybind11 module `_uncalled_amd`: the subset of the reference's `_uncalled` (src/pybinder.cpp:14-91) that
+// `uncalled map` touches -- Conf, MapPool, Paf -- with the same names, properties and methods.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "unc_pool.hpp"
+
+namespace py = pybind11;
+using namespace unc_host;
+
+PYBIND11_MODULE(_uncalled_amd, m) {
+    m.doc() = "MI355X-native UNCALLED map path: Conf / MapPool / Paf over libuncalled_hip.so";
+
+    py::class_<Conf>(m, "Conf")
+        .def(py::init<>())
+#define PRP(P) .def_readwrite(#P, &Conf::P)
+        PRP(threads) PRP(bwa_prefix) PRP(idx_preset) PRP(model_path) PRP(max_events) PRP(seed_len) PRP(chunk_time) PRP(fast5_list)
+        PRP(read_list) PRP(max_reads) PRP(max_buffer) PRP(num_channels) PRP(max_chunks) PRP(sample_rate) PRP(device) PRP(batch_reads);
+#undef PRP
+
+    py::class_<Paf> paf(m, "Paf");
+    paf.def(py::init<>())
+        .def("print_paf", &Paf::print_paf)
+        .def("__str__", &Paf::str)
+        .def("is_mapped", &Paf::is_mapped)
+        .def("is_ended", &Paf::is_ended)
+        .def("set_int", &Paf::set_int)
+        .def("set_float", &Paf::set_float)
+        .def("set_str", &Paf::set_str);
+    py::enum_<Paf::Tag>(paf, "Tag")
+        .value("MAP_TIME", Paf::MAP_TIME).value("EJECT", Paf::EJECT).value("IN_SCAN", Paf::IN_SCAN).value("ENDED", Paf::ENDED)
+        .value("KEEP", Paf::KEEP).value("DELAY", Paf::DELAY)
+        .export_values();
+
+    // ReadBuffer as Fast5Reader::pop_read returns it (read_buffer.hpp:182-198): id / start / channel / raw, with the
+    // int16 samples and the calibration triple beside the calibrated floats
+    py::class_<RawRead>(m, "ReadBuffer")
+        .def("empty", [](const RawRead &r) { return r.signal.empty(); })
+        .def("size", [](const RawRead &r) { return r.signal.size(); })
+        .def_property_readonly("id", [](const RawRead &r) { return r.id; })
+        .def_property_readonly("start", [](const RawRead &r) { return r.start_sample; })
+        .def_property_readonly("number", [](const RawRead &r) { return r.number; })
+        .def_property_readonly("channel", [](const RawRead &r) { return (uint16_t)(r.channel_idx + 1); })
+        .def_property_readonly("calibration", [](const RawRead &r) { return py::make_tuple(r.calib.range, r.calib.offset, r.calib.digitisation); })
+        .def_property_readonly("raw_i16", [](const RawRead &r) { return r.signal; })
+        .def_property_readonly("raw", [](const RawRead &r) {   // fast5.hpp raw_samples_to_float arithmetic
+            std::vector<float> out(r.signal.size());
+            for (size_t i = 0; i < out.size(); ++i) {
+                const float t1 = (float)(int)(uint16_t)r.signal[i] + r.calib.offset;
+                const float t2 = r.calib.range * t1;
+                out[i] = t2 / r.calib.digitisation;
+            }
+            return out;
+        });
+
+    m.def("write_fast5",
+          [](const std::string &path, const std::vector<py::dict> &reads, bool multi, float sample_rate) {
+              std::vector<RawRead> rs;
+              for (const py::dict &d : reads) {
+                  RawRead r;
+                  r.id = d["id"].cast<std::string>();
+                  r.channel_idx = (uint16_t)(d["channel"].cast<int>() - 1);
+                  r.number = d.contains("number") ? d["number"].cast<uint32_t>() : 0;
+                  r.start_sample = d.contains("start") ? d["start"].cast<uint64_t>() : 0;
+                  r.calib.range = d["range"].cast<float>();
+                  r.calib.offset = d["offset"].cast<float>();
+                  r.calib.digitisation = d["digitisation"].cast<float>();
+                  r.signal = d["signal"].cast<std::vector<int16_t>>();
+                  rs.push_back(std::move(r));
+              }
+              return write_fast5(path, rs, multi, sample_rate);
+          },
+          py::arg("path"), py::arg("reads"), py::arg("multi") = true, py::arg("sample_rate") = 4000.0f);
+
+    py::class_<Fast5Reader>(m, "Fast5Reader")
+        .def(py::init<const Conf &>())
+        .def(py::init([](const std::string &fast5_list, const std::string &read_list, uint32_t max_reads, uint32_t max_buffer) {
+            Conf c; c.fast5_list = fast5_list; c.read_list = read_list; c.max_reads = max_reads; c.max_buffer = max_buffer;
+            return new Fast5Reader(c);
+        }))
+        .def("add_fast5", &Fast5Reader::add_fast5)
+        .def("load_fast5_list", &Fast5Reader::load_fast5_list)
+        .def("add_read", &Fast5Reader::add_read)
+        .def("load_read_list", &Fast5Reader::load_read_list)
+        .def("pop_read", &Fast5Reader::pop_read)
+        .def("buffer_size", &Fast5Reader::buffered)
+        .def("fill_buffer", &Fast5Reader::fill_buffer)
+        .def("all_buffered", &Fast5Reader::all_buffered)
+        .def("empty", &Fast5Reader::empty);
+
+    py::class_<MapPool>(m, "MapPool")
+        .def(py::init<const Conf &>())
+        .def("update", &MapPool::update)
+        .def("running", &MapPool::running)
+        .def("add_fast5", &MapPool::add_fast5)
+        .def("stop", &MapPool::stop);
+}

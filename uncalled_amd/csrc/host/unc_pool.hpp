@@ -1,0 +1,115 @@
+// Host C++ surface that keeps the reference's pybind11 shape for the map path -- Conf, Paf, MapPool (and the
+// Fast5Reader behind it) -- on top of the C ABI (include/uncalled_hip.h).  Mirrors, without sharing code with:
+//   Conf        src/conf.hpp:57-96,296-340 (the properties `uncalled map` sets, uncalled/args.py:264-304)
+//   Paf         src/read_buffer.hpp:42-126, read_buffer.cpp:34-160 (print_paf format, tags ch/st/mt)
+//   Fast5Reader src/fast5_reader.cpp:62-248 (single- and multi-fast5, read-id filter, max_reads)
+//   ReadBuffer  src/read_buffer.cpp:198-246 (attributes, max_chunks truncation; the int16 samples stay int16)
+//   MapPool     src/map_pool.cpp:28-158 (add_fast5 / update / running / stop)
+#pragma once
+#include <stdint.h>
+
+#include <deque>
+#include <string>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include "../../../include/uncalled_hip.h"
+
+namespace unc_host {
+
+struct Conf {
+    uint16_t threads = 1;            // kept for CLI compatibility; the GPU path batches instead
+    std::string bwa_prefix, idx_preset = "default", model_path;
+    uint32_t max_events = 30000, seed_len = 22, max_chunks = 1000000, max_reads = 0, max_buffer = 100, num_channels = 512;
+    float chunk_time = 1.0f, sample_rate = 4000.0f;
+    std::string fast5_list, read_list;
+    int device = 0;                  // GPU ordinal
+    uint32_t batch_reads = 4096;     // reads handed to one unc_map_batch call
+};
+
+class Paf {
+public:
+    enum Tag { MAP_TIME, WAIT_TIME, QUEUE_TIME, RECEIVE_TIME, CHANNEL, EJECT, READ_START, IN_SCAN, TOP_RATIO, MEAN_RATIO, ENDED, KEEP,
+               DELAY, SEED_CLUSTER, CONFIDENT_EVENT };
+    Paf() {}
+    Paf(const std::string &rd_name, uint16_t channel, uint64_t start_sample);
+    bool is_mapped() const { return is_mapped_; }
+    bool is_ended() const { return ended_; }
+    std::string str() const;       // one PAF line, no newline
+    void print_paf() const;
+    void set_read_len(uint64_t n) { rd_len_ = n; }
+    void set_mapped(uint64_t rd_st, uint64_t rd_en, const std::string &rf_name, uint64_t rf_st, uint64_t rf_en, uint64_t rf_len, bool fwd,
+                    uint16_t matches);
+    void set_ended() { ended_ = true; }
+    void set_int(Tag t, int v) { int_tags_.emplace_back(t, v); }
+    void set_float(Tag t, float v) { float_tags_.emplace_back(t, v); }
+    void set_str(Tag t, const std::string &v) { str_tags_.emplace_back(t, v); }
+    const std::string &get_rd_name() const { return rd_name_; }
+
+private:
+    bool is_mapped_ = false, ended_ = false, fwd_ = false;
+    std::string rd_name_, rf_name_;
+    uint64_t rd_st_ = 0, rd_en_ = 0, rd_len_ = 0, rf_st_ = 0, rf_en_ = 0, rf_len_ = 0;
+    uint16_t matches_ = 0;
+    std::vector<std::pair<Tag, int>> int_tags_;
+    std::vector<std::pair<Tag, float>> float_tags_;
+    std::vector<std::pair<Tag, std::string>> str_tags_;
+};
+
+struct RawRead {   // ReadBuffer of the offline path, samples kept as stored
+    std::string id;
+    uint16_t channel_idx = 0;
+    uint32_t number = 0;
+    uint64_t start_sample = 0;
+    unc_calib_t calib{1.f, 0.f, 1.f};
+    std::vector<int16_t> signal;
+};
+
+class Fast5Reader {
+public:
+    Fast5Reader(const Conf &c);
+    void add_fast5(const std::string &path) { fast5_list_.push_back(path); }
+    bool add_read(const std::string &read_id);
+    bool load_fast5_list(const std::string &fname);
+    bool load_read_list(const std::string &fname);
+    uint32_t fill_buffer();
+    bool empty();
+    RawRead pop_read();
+    uint32_t buffered() const { return (uint32_t)buffered_.size(); }
+    bool all_buffered() const;
+
+private:
+    bool open_next();
+    bool read_one(const std::string &raw_path, const std::string &ch_path, RawRead &out);
+    uint32_t max_reads_, max_buffer_, max_chunks_, chunk_len_, total_buffered_ = 0;
+    std::deque<std::string> fast5_list_, read_paths_;
+    std::unordered_set<std::string> read_filter_;
+    std::deque<RawRead> buffered_;
+    int64_t file_ = -1;   // hid_t
+    bool multi_ = false;
+};
+
+// Writes reads in the two layouts Fast5Reader understands (multi: /read_<id>/{Raw,channel_id}; single: one read under
+// /Raw/Reads/Read_<n> + /UniqueGlobalKey/channel_id).  Used by the simulators and the tests; the reference only reads.
+bool write_fast5(const std::string &path, const std::vector<RawRead> &reads, bool multi, float sample_rate = 4000.0f);
+
+class MapPool {
+public:
+    explicit MapPool(const Conf &conf);
+    ~MapPool();
+    MapPool(const MapPool &) = delete;
+    void add_fast5(const std::string &fname) { reader_.add_fast5(fname); }
+    std::vector<Paf> update();
+    bool running();
+    void stop();
+
+private:
+    Conf conf_;
+    Fast5Reader reader_;
+    unc_index_t *ix_ = nullptr;
+    unc_mapper_t *mapper_ = nullptr;
+    bool stopped_ = false;
+};
+
+}  // namespace unc_host
