@@ -177,6 +177,7 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned acc) {
 template <class T> static inline void __builtin_nontemporal_store(T v, T *p) { *p = v; }
 template <class T> static inline T __builtin_nontemporal_load(const T *p) { return *p; }
 static inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
+static inline long long wall_clock64() { return (long long)__builtin_ia32_rdtsc(); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
@@ -238,6 +239,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     return 0;
 }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 1ull << 33; *t = 1ull << 34; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 100000; return 0; }
 struct hipPointerAttribute_t { int type; };
 constexpr int hipMemoryTypeHost = 0, hipMemoryTypeDevice = 1;
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeDevice; return 0; }

@@ -1,4 +1,7 @@
-"""Dev tool: time k_map of several builds of the library on the same 50k-read E. coli batch."""
+"""Dev tool: time k_map of several builds of the library on the same E. coli batch and check that they agree.
+
+    python tools/dev/ab_libs.py <n_reads> <lib.so> [<lib.so> ...]
+The first library's hits are the reference the others are compared with (all fields, bit for bit)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
@@ -18,15 +21,26 @@ if not Path(str(pre) + ".sa").exists():
     _ix = capi.Index(pre); parameterize(_ix, pre); _ix.close()
 sim = simulate_reads_torch(codes, lens, n, seed=42, device="cuda:0")
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+first = None
 for lib in sys.argv[2:]:
-    L = capi.load(lib)
-    ix = capi.Index(pre, lib=L)
-    m = capi.Mapper(ix)
-    t = []
-    for i in range(3):
-        m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
-        t.append(m.last_timing()[1])
-    pc = m.last_phase_cycles(); tot = float(sum(pc.values())) or 1.0
-    print({k: round(v / tot, 3) for k, v in pc.items()})
-    print(lib, "k_map ms:", [round(x, 1) for x in t], flush=True)
-    m.close(); ix.close()
+    try:
+        L = capi.load(lib)
+        ix = capi.Index(pre, lib=L)
+        m = capi.Mapper(ix)
+        t = []
+        for i in range(2):
+            hits = m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
+            t.append(m.last_timing()[1])
+        busy = m.last_wave_busy() if hasattr(L, "unc_mapper_last_wave_busy") else -1
+        pc = m.last_phase_cycles(); tot = float(sum(pc.values())) or 1.0
+        same = "ref"
+        if first is None:
+            first = hits.copy()
+        else:
+            bad = [f for f in hits.dtype.names if not np.array_equal(hits[f], first[f])]
+            same = "IDENTICAL" if not bad else "MISMATCH in %s (%d reads)" % (bad, int(sum((hits[f] != first[f]).sum() for f in bad)))
+        print({k: round(v / tot, 3) for k, v in pc.items() if v})
+        print(Path(lib).name, "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", same, flush=True)
+        m.close(); ix.close()
+    except Exception as e:   # a bad variant must not hide the others
+        print(Path(lib).name, "FAILED:", repr(e)[:300], flush=True)

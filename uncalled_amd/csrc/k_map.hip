@@ -41,6 +41,7 @@ struct MapArgs {
     uint32_t resume;        // 1: continue the read saved in SlotState (trace / chunked mode)
     const uint32_t *read_list;  // batch mode: the queue hands out read_list[t] instead of t (re-runs of selected reads)
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
+    unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
 };
 
 struct Tracker {
@@ -61,6 +62,16 @@ struct TrackerMem {
     uint32_t max_leaves, max_pay;
 };
 
+#ifdef UNC_NOINLINE_SORT
+#define UNC_SORT_FN __device__ __noinline__
+#else
+#define UNC_SORT_FN __device__
+#endif
+#ifdef UNC_NOINLINE_SEED
+#define UNC_SEED_FN __device__ __noinline__
+#else
+#define UNC_SEED_FN __device__
+#endif
 __device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
     // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
     return k.rstart > r2 || (k.rstart == r2 && k.evt_en > e2);
@@ -177,7 +188,7 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
 }
 
 // SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
-__device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
+UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
                          int lane) {
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
@@ -399,7 +410,7 @@ __device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64
 
 // n <= 64*E: the whole sort in registers
 template <int E>
-__device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+UNC_SORT_FN void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     uint64_t a[E], b[E];
     block_load<E>(a, b, in, 0, n, lane);
     for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages<E>(a, b, 0, k, k >> 1, lane);
@@ -407,7 +418,7 @@ __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane)
 }
 
 // n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
-__device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+UNC_SORT_FN void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -480,7 +491,7 @@ __device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, 
 
 // in: the children's SortKey records (.a = packed key); out: compact sorted uint64 array
 template <int E>
-__device__ void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+UNC_SORT_FN void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
     uint64_t a[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -495,7 +506,7 @@ __device__ void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int la
     }
 }
 
-__device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+UNC_SORT_FN void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -593,15 +604,20 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
-    __shared__ uint64_t s_pstart[WAVE], s_pend[WAVE];
-    __shared__ uint32_t s_pphys[WAVE], s_pmoves[WAVE], s_pmeta[WAVE];
-    __shared__ uint16_t s_cand[CAND_MAX];
-    __shared__ uint64_t s_res[2 * CAND_MAX];          // FM results of a pass; reused as the source list in phase F
-    uint64_t *const s_res_s = s_res, *const s_res_e = s_res + CAND_MAX;
-    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_res);   // NKMER entries
-    __shared__ uint32_t s_cdesc[CHILD_MAX];
+    // one carved buffer for the per-pass staging of phase E (5.5 KB), reused as the source list in phase F: with the
+    // probs table the wavefront stays under 10 KB of LDS, i.e. 16 wavefronts per CU fit the 160 KB
+    constexpr int RES_BITS = 30;                       // packed FM result: start << 30 | row count (0 = empty range)
+    __shared__ uint64_t s_e[CAND_MAX + 2 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4];
+    uint64_t *const s_res = s_e;
+    uint64_t *const s_pstart = s_e + CAND_MAX, *const s_pend = s_pstart + WAVE;
+    uint32_t *const s_pphys = reinterpret_cast<uint32_t *>(s_pend + WAVE), *const s_pmoves = s_pphys + WAVE, *const s_pmeta = s_pmoves + WAVE;
+    uint32_t *const s_cdesc = s_pmeta + WAVE;
+    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
+    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
+    static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
 
     const int lane = lane_id();
+    const uint64_t wave_t0 = (uint64_t)wall_clock64();
     const uint32_t slot = (A.resume && A.slot_map) ? A.slot_map[blockIdx.x] : blockIdx.x;
     const DevIndex &ix = A.ix;
     const unc_params_t &P = A.P;
@@ -764,7 +780,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         const uint32_t cd = s_cand[ci];
                         uint64_t ns, ne;
                         fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
-                        s_res_s[ci] = ns; s_res_e[ci] = ne;
+                        s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
                     }
                 }
                 wave_sync();
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 // children per parent, in the reference's order: stay, then bases 0..3
                 uint32_t vmask = 0;   // bit j: j-th candidate of this lane has a non-empty range
                 for (uint32_t j = 0; j < ncand; ++j)
-                    if (s_res_s[coff + j] <= s_res_e[coff + j]) vmask |= 1u << j;
+                    if (s_res[coff + j] != 0) vmask |= 1u << j;
                 const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
                 uint32_t chtot;
                 const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
@@ -844,7 +860,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         uint64_t cs, ce;
                         uint32_t ck, mv;
                         if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
-                        else { cs = s_res_s[ci]; ce = s_res_e[ci]; ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1; }
+                        else {
+                            const uint64_t pr = s_res[ci];
+                            cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
+                            ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
+                        }
                         if (klb && cs == ce && (cs == ix.kmer_ranges[2 * ck] || cs == ix.kmer_ranges[2 * ck + 1])) bchild = true;
                         SortKey key;
                         const uint32_t gi = nchild + li;
@@ -1121,6 +1141,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         }
         wave_sync();
     }
+    if (A.wave_ticks && lane == 0) atomicAdd(A.wave_ticks, (unsigned long long)((uint64_t)wall_clock64() - wave_t0));
 }
 
 }  // namespace unc
@@ -1129,14 +1150,13 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list) {
+                const uint32_t *read_list, unsigned long long *wave_ticks) {
     MapArgs a;
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
-    a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list;
+    a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
     hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
 }
-// resident single-wave workgroups per CU for the persistent grid: bounded by the kernel's LDS
-// footprint (about 12 KB of the CU's 160 KB) and by 3 waves per SIMD (launch bounds); 12 so that the grid stays well inside what
-// the hardware admits whatever the register allocation turns out to be.
-uint32_t map_kernel_waves_per_cu() { return 12; }
+// resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
+// register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.
+uint32_t map_kernel_waves_per_cu() { return 4 * UNC_LB; }
 }  // namespace unc

@@ -256,7 +256,7 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     HIPCHK(hipMemcpy(ix->kmer_ranges.data(), ix->d_kmer_ranges, 2 * NKMER * 8, hipMemcpyDeviceToHost));
     for (int k = 0; k < NKMER; ++k) {
         uint64_t s = ix->kmer_ranges[2 * k], e = ix->kmer_ranges[2 * k + 1];
-        if (s <= e && e - s >= (1ull << KEY_LEN_BITS)) return fail(UNC_ERR_ARG, "k-mer %d occurs more than 2^30 times: unsupported", k);
+        if (s <= e && e - s + 1 >= (1ull << KEY_LEN_BITS)) return fail(UNC_ERR_ARG, "k-mer %d occurs more than 2^30 times: unsupported", k);
     }
     {
         // narrow sort keys: start | length | 16-bit creation index in 64 bits when the reference allows it
@@ -391,6 +391,7 @@ struct unc_mapper {
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_events = 0, ms_map = 0;
+    double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     uint32_t *d_next = nullptr;
     // per-batch buffers (grown on demand)
     int16_t *d_raw = nullptr; size_t raw_cap = 0;
@@ -604,12 +605,13 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     DevReads rd;
     int rc = stage_batch(m, n_reads, raw, offsets, calib, on_device, st, &rd);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
+    HIPCHK(hipMemsetAsync(m->d_next, 0, 16, st));   // [0] queue head, [2..3] wave-lifetime ticks
     HIPCHK(hipEventRecord(m->ev[0], st));
     launch_events(rd, m->P, st);
     HIPCHK(hipEventRecord(m->ev[1], st));
     const uint32_t grid = n_reads < m->n_slots ? n_reads : m->n_slots;
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, grid, st);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
+               reinterpret_cast<unsigned long long *>(m->d_next + 2));
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
@@ -619,6 +621,13 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));
     HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
+    {
+        unsigned long long ticks = 0;
+        int khz = 0;
+        HIPCHK(hipMemcpy(&ticks, m->d_next + 2, 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->ix->device));
+        m->wave_busy = (grid && m->ms_map > 0 && khz > 0) ? (double)ticks / ((double)grid * (double)m->ms_map * (double)khz) : 0.0;
+    }
     // The reference's SeedTracker is an unbounded std::set.  Reads whose seed clusters outgrew the per-slot array are
     // mapped again, on the device, with 16x the room (a few slots only), until they fit.
     {
@@ -668,6 +677,8 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
         for (int i = 0; i < 12; ++i) out8[i] += r.cyc[i];
     return UNC_OK;
 }
+
+extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 
 extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
     if (ms_events) *ms_events = m->ms_events;
