@@ -245,7 +245,8 @@ def main():
                        "mapped_fraction": float(hits["mapped"].mean()),
                        "mean_events_per_read": float(hits["event_i"].mean()),
                        "kernel_ms": {"k_events": float(np.mean(ms_ev)), "k_map": map_ms},
-                       "k_map_phase_cycle_share": phase_share},
+                       "k_map_phase_cycle_share": phase_share,
+                       "k_map_wave_busy": round(mapper.last_wave_busy(), 4)},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_k_map.json (FETCH_SIZE+WRITE_SIZE per read x reads)",

@@ -4,6 +4,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before any test module loads libuncalled_hip.so: one HIP runtime per process (uncalled_amd/__init__.py)
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))

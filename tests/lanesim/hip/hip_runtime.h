@@ -114,6 +114,7 @@ static inline int __lanesim_lane() { return (int)(threadIdx.x & 63); }
 static inline void __syncthreads() { lanesim::block_barrier(); }
 static inline void __builtin_amdgcn_wave_barrier() { lanesim::wave_exchange(0); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __threadfence() {}
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 
 static inline unsigned long long __ballot(int pred) {
@@ -192,6 +193,10 @@ static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
 template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }

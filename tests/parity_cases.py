@@ -229,3 +229,23 @@ def case_wide_sort_keys(lib, oracle_lib, example, goldens, monkeypatch):
     cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     hits = capi.Mapper(ix, n_slots=3).map_batch(raw, off, cal)
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "wide keys")
+
+
+def case_sliced_scheduler(lib, oracle_lib, example, goldens, max_paths=10000, slice_events=37, n_slots=5, n_waves=2, n_reads=24):
+    """More reads in flight than wavefronts (DevSched): reads are parked after `slice_events` events and resumed later,
+    possibly by another wavefront; answers and work counters must not change (also with the max_paths cut-off, whose
+    stale sources_added_ flags travel with the parked read)."""
+    dev_index = _index(lib, example)
+    p = capi.default_params(dev_index.L)
+    p.max_paths = max_paths
+    off_all = goldens["sim_offsets"]
+    raw = goldens["sim_signal"][:int(off_all[n_reads])]
+    off = off_all[:n_reads + 1].copy()
+    cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    m = capi.Mapper(dev_index, params=p, n_slots=n_slots, n_waves=n_waves, slice_events=slice_events)
+    hits = m.map_batch(raw, off, cal)
+    again = m.map_batch(raw, off, cal)          # the rings are re-initialised per batch
+    for name in hits.dtype.names:
+        assert np.array_equal(again[name], hits[name]), name
+    oix = oracle_lib.Index(example["prefix"])
+    assert_hits_equal(hits, oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True), "sliced")

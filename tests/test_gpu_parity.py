@@ -147,3 +147,8 @@ def test_chr20_scale_batch(hip_lib, oracle_lib, chr20):
     want = oracle_hits(oix, sim["signal"], sim["offsets"], cal)
     assert_hits_equal(hits, want, "chr20")
     assert int(hits["mapped"].sum()) >= 0.5 * n
+
+
+@pytest.mark.parametrize("max_paths,slice_events,n_slots,n_waves", [(10000, 37, 5, 2), (300, 11, 3, 1), (10000, 200, 9, 4)])
+def test_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves):
+    pc.case_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves)

@@ -32,7 +32,7 @@ class Params(C.Structure):
 
 class MapperOpts(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32)]
 
 
 CALIB = np.dtype([("range", "<f4"), ("offset", "<f4"), ("digitisation", "<f4")])
@@ -222,11 +222,11 @@ def hit_paf_cols(h, names):
 class Mapper:
     """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
 
-    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0):
+    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0):
         self.index = index
         self.L = index.L
         self.params = params or default_params(self.L)
-        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, 0)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves)
         h = C.c_void_p()
         _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
         self.h = h

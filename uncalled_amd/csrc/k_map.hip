@@ -42,7 +42,37 @@ struct MapArgs {
     const uint32_t *read_list;  // batch mode: the queue hands out read_list[t] instead of t (re-runs of selected reads)
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
+    DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
 };
+
+// ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
+// == pos + 1: holds the value of that push; a pop at pos leaves pos + cap.  At most n_slots <= cap ids exist, so a push
+// never finds its cell occupied by a live value -- at worst by a pop that has not yet released it.
+constexpr uint32_t SCHED_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t ld_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void sched_push(SchedQueue *q, SchedCell *cells, uint32_t mask, uint32_t v) {
+    const uint32_t pos = atomicAdd(&q->tail, 1u);
+    SchedCell *c = cells + (pos & mask);
+    while (ld_acq(&c->seq) != pos) __builtin_amdgcn_s_sleep(1);
+    c->val = v;
+    st_rel(&c->seq, pos + 1u);
+}
+
+__device__ __forceinline__ uint32_t sched_pop(SchedQueue *q, SchedCell *cells, uint32_t mask) {
+    for (;;) {
+        const uint32_t pos = ld_acq(&q->head);
+        SchedCell *c = cells + (pos & mask);
+        const int32_t dif = (int32_t)(ld_acq(&c->seq) - (pos + 1u));
+        if (dif < 0) return SCHED_EMPTY;
+        if (dif == 0 && atomicCAS(&q->head, pos, pos + 1u) == pos) {
+            const uint32_t v = c->val;
+            st_rel(&c->seq, pos + mask + 1u);
+            return v;
+        }
+    }
+}
 
 struct Tracker {
     uint32_t n, n_pay, n_lens, max1, max2, status, n_leaves, n_alloc;
@@ -618,24 +648,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 
     const int lane = lane_id();
     const uint64_t wave_t0 = (uint64_t)wall_clock64();
-    const uint32_t slot = (A.resume && A.slot_map) ? A.slot_map[blockIdx.x] : blockIdx.x;
     const DevIndex &ix = A.ix;
     const unc_params_t &P = A.P;
     const uint32_t max_paths = A.sc.max_paths;
-
-    PathRec *const buf0 = A.sc.paths + (size_t)slot * 2 * max_paths;
-    uint32_t *const ord0 = A.sc.order + (size_t)slot * 2 * max_paths;
-    SortKey *const ukeys = A.sc.keys + (size_t)slot * 2 * A.sc.keys_cap;
-    SortKey *const skeys = ukeys + A.sc.keys_cap;
-    SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
-    uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
-    TrackerMem TM;
-    TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
-    TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
-    TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
-    TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
-    TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
-    SlotState *const st = A.sc.state + slot;
+    const bool sliced = A.sched.ctl != nullptr;      // batch mode with time slices (see DevSched)
 
     const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
     const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
@@ -644,19 +660,65 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 
     for (;;) {
         // ---------------- fetch or resume a read ----------------
-        uint32_t r, event_i, n_parents, cur;
+        uint32_t r = 0, event_i, n_parents, cur;
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
         uint64_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t slot = (A.resume && A.slot_map) ? A.slot_map[blockIdx.x] : blockIdx.x;
+        bool restore = false;
+        if (sliced) {
+            // task = a new read in a free slot while both exist, else the longest-parked read
+            uint32_t kind = 0, tslot = 0, tread = 0;
+            if (lane == 0) {
+                SchedCtl *const sc = A.sched.ctl;
+                for (int tries = 0; tries < 4096 && !kind; ++tries) {
+                    const bool more = ld_acq(&sc->next_read) < A.rd.n_reads;
+                    if (more) {
+                        const uint32_t fs = sched_pop(&sc->freeq, A.sched.free_cells, A.sched.cap_mask);
+                        if (fs != SCHED_EMPTY) {
+                            const uint32_t t = atomicAdd(&sc->next_read, 1u);
+                            if (t < A.rd.n_reads) { kind = 1; tslot = fs; tread = t; }
+                            else sched_push(&sc->freeq, A.sched.free_cells, A.sched.cap_mask, fs);
+                        }
+                    }
+                    if (!kind) {
+                        const uint32_t ps = sched_pop(&sc->parkq, A.sched.park_cells, A.sched.cap_mask);
+                        if (ps != SCHED_EMPTY) { kind = 2; tslot = ps; }
+                    }
+                    // reads left but every slot is in another wavefront's hands right now: wait for one to come back
+                    if (!kind) { if (!more) break; __builtin_amdgcn_s_sleep(32); }
+                }
+            }
+            kind = bcast32(kind, 0); tslot = bcast32(tslot, 0); tread = bcast32(tread, 0);
+            if (!kind) break;
+            slot = tslot; r = tread; restore = kind == 2;
+            __threadfence();   // the slot may have been parked by a wavefront on another CU
+        }
+
+        PathRec *const buf0 = A.sc.paths + (size_t)slot * 2 * max_paths;
+        uint32_t *const ord0 = A.sc.order + (size_t)slot * 2 * max_paths;
+        SortKey *const ukeys = A.sc.keys + (size_t)slot * 2 * A.sc.keys_cap;
+        SortKey *const skeys = ukeys + A.sc.keys_cap;
+        SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
+        uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
+        TrackerMem TM;
+        TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
+        TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
+        TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
+        TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
+        TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
+        SlotState *const st = A.sc.state + slot;
+
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
-        if (A.resume && !fresh) {
-            r = blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
+        if ((A.resume && !fresh) || restore) {
+            r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
             T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
             event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
-            if (uniform32(st->done)) break;
+            if (restore) { for (int i = 0; i < 12; ++i) cyc[i] = st->cyc[i]; }
+            else if (uniform32(st->done)) break;
         } else if (A.resume) {
             r = blockIdx.x;
             event_i = 0; n_parents = 0; cur = 0;
@@ -664,10 +726,12 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
             if (lane < NKMER / 32) s_flags[lane] = 0;
         } else {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(A.next_read, 1u);
-            r = bcast32(t, 0);
-            if (r >= A.rd.n_reads) break;
+            if (!sliced) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(A.next_read, 1u);
+                r = bcast32(t, 0);
+                if (r >= A.rd.n_reads) break;
+            }
             if (A.read_list) r = uniform32(A.read_list[r]);
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
@@ -1135,9 +1199,19 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
+                if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; }
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
-            break;
+            if (!sliced) break;
+        }
+        if (sliced) {
+            // hand the slot back: to the free ring when the read is finished, else to the end of the parked ring
+            __threadfence();
+            if (lane == 0) {
+                SchedCtl *const sc = A.sched.ctl;
+                if (done) sched_push(&sc->freeq, A.sched.free_cells, A.sched.cap_mask, slot);
+                else sched_push(&sc->parkq, A.sched.park_cells, A.sched.cap_mask, slot);
+            }
         }
         wave_sync();
     }
@@ -1150,11 +1224,32 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list, unsigned long long *wave_ticks) {
+                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched) {
     MapArgs a;
+    if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
     hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
+}
+// every slot free, nothing parked, queue head at the first read
+__global__ void k_sched_init(DevSched S) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = S.cap_mask + 1u;
+    if (i < cap) {
+        SchedCell f; f.seq = i < S.n_slots ? i + 1u : i; f.val = i;
+        S.free_cells[i] = f;
+        SchedCell p; p.seq = i; p.val = 0;
+        S.park_cells[i] = p;
+    }
+    if (i == 0) {
+        SchedCtl c;
+        memset(&c, 0, sizeof c);
+        c.freeq.tail = S.n_slots;
+        *S.ctl = c;
+    }
+}
+void launch_sched_init(const DevSched &S, hipStream_t st) {
+    const uint32_t cap = S.cap_mask + 1u;
+    hipLaunchKernelGGL(k_sched_init, dim3((cap + 255) / 256), dim3(256), 0, st, S);
 }
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
 // register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.

@@ -63,6 +63,25 @@ struct alignas(16) SlotState {
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
     uint32_t sources_added[NKMER / 32];
+    uint64_t cyc[12];        // phase cycle counters of the read so far (sliced batch mode)
+};
+
+// ---- sliced batch scheduler (k_map): more reads in flight than resident wavefronts.  A wavefront maps a read for at
+// most `slice` events, parks it in its slot and takes the next task: a new read while free slots remain, else the
+// longest-parked one.  Long (off-target) reads are thereby discovered early and share the wavefronts until the end,
+// instead of a few of them keeping single wavefronts busy long after the queue has drained.
+// Both queues are bounded multi-producer/multi-consumer rings of slot ids with a sequence number per cell.
+struct SchedCell { uint32_t seq, val; };
+struct alignas(64) SchedQueue { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1[15]; };
+struct alignas(64) SchedCtl {
+    uint32_t next_read, pad0[15];
+    SchedQueue freeq, parkq;
+};
+struct DevSched {
+    SchedCtl *ctl;           // null: scheduler off (one slot per wavefront)
+    SchedCell *free_cells, *park_cells;   // [cap] each
+    uint32_t cap_mask;       // cap - 1, cap = power of two >= n_slots
+    uint32_t n_slots;
 };
 
 struct DevIndex {

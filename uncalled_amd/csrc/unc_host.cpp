@@ -385,7 +385,8 @@ extern "C" int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *l
 struct unc_mapper {
     const unc_index *ix = nullptr;
     unc_params_t P;
-    uint32_t n_slots = 0;
+    uint32_t n_slots = 0, n_waves = 0, slice_events = 1024;
+    DevSched sched{};             // ctl != null: sliced batch scheduler (n_slots > n_waves)
     DevScratch sc;
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
@@ -449,7 +450,8 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     if (!m) return;
     (void)hipSetDevice(m->ix->device);
     free_scratch(m->sc);
-    void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means};
+    void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -470,13 +472,30 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     m->ix = ix;
     m->P = *p;
     memset(&m->sc, 0, sizeof m->sc);
-    uint32_t n_slots = opts ? opts->n_slots : 0;
-    if (n_slots == 0) {
+    uint32_t n_slots = opts ? opts->n_slots : 0, n_waves = opts ? opts->n_waves : 0;
+    if (n_waves == 0) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ix->device));
-        n_slots = (uint32_t)prop.multiProcessorCount * map_kernel_waves_per_cu();
+        n_waves = (uint32_t)prop.multiProcessorCount * map_kernel_waves_per_cu();
+        if (n_slots && n_slots < n_waves) n_waves = n_slots;
     }
+    if (n_slots == 0) {
+        // more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched); about
+        // 7 MB of scratch per slot, bounded by a third of the free HBM
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
+        const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
+        const size_t per_slot = (size_t)p->max_paths * (2 * sizeof(PathRec) + 8 + 4 * sizeof(SortKey)) + (size_t)msp0 * sizeof(SeedPath) +
+                                (size_t)mcl0 * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + (64 << 10);
+        size_t want = (size_t)n_waves * 8 / 3, fit = free_b / 3 / per_slot;
+        n_slots = (uint32_t)(want < fit ? want : fit);
+        if (n_slots < n_waves) n_slots = n_waves;
+    }
+    if (n_slots < n_waves) n_waves = n_slots;
     m->n_slots = n_slots;
+    m->n_waves = n_waves;
+    m->slice_events = (opts && opts->slice_events) ? opts->slice_events : 1024;
     size_t bytes = 0;
     // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
     const uint32_t msp = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
@@ -484,6 +503,15 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
+    if (n_slots > n_waves) {
+        uint32_t cap = 64;
+        while (cap < n_slots) cap <<= 1;
+        m->sched.cap_mask = cap - 1; m->sched.n_slots = n_slots;
+        HIPCHK(hipMalloc((void **)&m->sched.ctl, sizeof(SchedCtl)));
+        HIPCHK(hipMalloc((void **)&m->sched.free_cells, (size_t)cap * sizeof(SchedCell)));
+        HIPCHK(hipMalloc((void **)&m->sched.park_cells, (size_t)cap * sizeof(SchedCell)));
+        bytes += sizeof(SchedCtl) + 2 * (size_t)cap * sizeof(SchedCell);
+    }
     m->device_bytes = bytes;
     HIPCHK(hipStreamCreate(&m->stream));
     for (auto &e : m->ev) HIPCHK(hipEventCreate(&e));
@@ -609,9 +637,11 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     HIPCHK(hipEventRecord(m->ev[0], st));
     launch_events(rd, m->P, st);
     HIPCHK(hipEventRecord(m->ev[1], st));
-    const uint32_t grid = n_reads < m->n_slots ? n_reads : m->n_slots;
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
-               reinterpret_cast<unsigned long long *>(m->d_next + 2));
+    const uint32_t grid = n_reads < m->n_waves ? n_reads : m->n_waves;
+    const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
+    if (sliced) launch_sched_init(m->sched, st);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
+               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
