@@ -55,10 +55,44 @@ __device__ __forceinline__ uint64_t fm_occ(const DevIndex &ix, uint64_t k, uint3
     return fm_block_count(b, c) + fm_block_rank(b, kk, c);
 }
 
-// BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c
+// The part of a block one rank query reads: the count of base c before the block and the symbol words up to the
+// query position.  Every per-lane load instruction costs the CU's vector memory pipeline one cache-line request per
+// active lane whatever its width, so only what is needed is fetched: 8 B + 16 B, + 16 B when the position lies in the
+// upper half of the block.
+struct FmPart { uint64_t cnt; uint4 lo, hi; };
+
+__device__ __forceinline__ FmPart fm_load_part(const DevIndex &ix, uint64_t kk, uint32_t c) {
+    const uint32_t *p = ix.bwt + ((kk >> 7) << 4);
+    FmPart b;
+    b.cnt = *reinterpret_cast<const uint64_t *>(p + 2 * c);
+    b.lo = reinterpret_cast<const uint4 *>(p)[2];
+    b.hi = make_uint4(0u, 0u, 0u, 0u);
+    if (kk & 64) b.hi = reinterpret_cast<const uint4 *>(p)[3];
+    return b;
+}
+
+__device__ __forceinline__ uint64_t fm_part_rank(const FmPart &b, uint64_t kk, uint32_t c) {
+    FmBlock f;
+    f.q0 = f.q1 = make_uint4(0u, 0u, 0u, 0u);
+    f.q2 = b.lo; f.q3 = b.hi;
+    return b.cnt + fm_block_rank(f, kk, c);
+}
+
+// BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c (bwt_2occ).  Like bwt_2occ, the two
+// rank queries share the block when s - 1 and e fall into the same one (nearly always for the short ranges that make
+// up most of the path forest).
 __device__ __forceinline__ void fm_get_neighbor(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c,
                                                 uint64_t *os, uint64_t *oe) {
-    uint64_t ok = fm_occ(ix, s - 1, c), ol = fm_occ(ix, e, c);
+    const uint64_t k = s - 1, l = e;
+    const bool k_plain = k != ix.seq_len && k != ~0ull, l_plain = l != ix.seq_len && l != ~0ull;
+    const uint64_t kk = k - (k >= ix.primary ? 1 : 0), ll = l - (l >= ix.primary ? 1 : 0);
+    uint64_t ok = k == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0, ol = l == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0;
+    FmPart bl;
+    if (l_plain) { bl = fm_load_part(ix, ll, c); ol = fm_part_rank(bl, ll, c); }
+    if (k_plain) {
+        if (l_plain && kk <= ll && (kk >> 7) == (ll >> 7)) ok = fm_part_rank(bl, kk, c);    // its words are loaded
+        else { const FmPart bk = fm_load_part(ix, kk, c); ok = fm_part_rank(bk, kk, c); }
+    }
     *os = ix.L2[c] + ok + 1;
     *oe = ix.L2[c] + ol;
 }

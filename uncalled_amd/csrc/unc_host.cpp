@@ -480,15 +480,15 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         if (n_slots && n_slots < n_waves) n_waves = n_slots;
     }
     if (n_slots == 0) {
-        // more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched); about
-        // 7 MB of scratch per slot, bounded by a third of the free HBM
+        // four times more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched);
+        // about 7 MB of scratch per slot, bounded by a third of the free HBM
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
         const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
         const size_t per_slot = (size_t)p->max_paths * (2 * sizeof(PathRec) + 8 + 4 * sizeof(SortKey)) + (size_t)msp0 * sizeof(SeedPath) +
                                 (size_t)mcl0 * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + (64 << 10);
-        size_t want = (size_t)n_waves * 8 / 3, fit = free_b / 3 / per_slot;
+        size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
         if (n_slots < n_waves) n_slots = n_waves;
     }
