@@ -146,9 +146,8 @@ __device__ __forceinline__ void dir_shift_down(ClusterKey *dir, uint32_t a, uint
     }
 }
 
-// remove entry `slot` of directory position L (leaf id, count c); keeps the directory's first keys right
-__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, int lane) {
-    const uint32_t id = M.dir[L].pidx, c = M.cnt[id];
+// remove entry `slot` of directory position L, whose leaf has id `id` and `c` keys; keeps the directory's first keys right
+__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
     ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
     ClusterKey k;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
@@ -237,35 +236,55 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         lo = nlo;
         hi = nhi;
     }
+    // the last directory window stays in registers (lane l: entry lo + l): leaf ids and first keys are read off it below
     uint32_t d;
+    ClusterKey dk; dk.rstart = 0; dk.evt_en = 0; dk.pidx = 0;
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
-        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
+        if (idx < hi) { dk = M.dir[idx]; less = key_less(dk, r2, e2); }
         d = lo + (uint32_t)__popcll(__ballot(less));
     }
+    // leaf d - 1 (the last one whose first key sorts before the seed), its count and keys in one round trip
     uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
+    uint32_t id0 = 0, c0 = 0;    // leaf id / count of directory position d - 1
+    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.pidx = 0;
     if (d > 0) {
-        const uint32_t id = M.dir[d - 1].pidx, c = M.cnt[id];
-        bool less = false;
-        if ((uint32_t)lane < c) less = key_less(M.leaves[(size_t)id * LEAF + lane], r2, e2);
-        const uint32_t s = (uint32_t)__popcll(__ballot(less));
-        if (s < c) { lbL = d - 1; lbS = s; } else { lbL = d; lbS = 0; }
+        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(M.dir[d - 1].pidx);   // window starts after it
+        lk = M.leaves[(size_t)id0 * LEAF + lane];       // slots past the count hold stale keys: masked by c0
+        c0 = M.cnt[id0];
+        const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
+        const uint32_t sn = (uint32_t)__popcll(__ballot(less));
+        if (sn < c0) { lbL = d - 1; lbS = sn; } else { lbL = d; lbS = 0; }
     }
+    const bool lb_in_leaf0 = d > 0 && lbL == d - 1;
 
     // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
-    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0;
+    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0, m_id = 0, m_c = 0;
+    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.pidx = 0;
+    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
     bool stop = false;
     {
-        uint32_t curL = lbL, curS = lbS;
+        uint32_t curL = lbL;
+        bool first = true;
         while (curL < T.n_leaves && !stop) {
-            const uint32_t id = M.dir[curL].pidx, c = M.cnt[id];
-            const uint32_t e = curS + (uint32_t)lane;
-            const bool have = e < c;
+            uint32_t id, c, from = 0;
+            ClusterKey k;
+            if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
+            else {
+                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(M.dir[curL].pidx);
+                k = M.leaves[(size_t)id * LEAF + lane];
+                c = M.cnt[id];
+            }
+            if (first) {   // the key at the lower bound is the first one this scan looks at
+                const uint64_t kr = bcast64(k.rstart, (int)from);
+                const uint32_t ke = bcast32(k.evt_en, (int)from);
+                exists_at_lb = kr == r2 && ke == e2;
+            }
+            const bool have = (uint32_t)lane >= from && (uint32_t)lane < c;
             uint64_t r1 = 0;
             uint32_t e1 = 0, tl = 0;
             if (have) {
-                ClusterKey k = M.leaves[(size_t)id * LEAF + e];
                 r1 = k.rstart;
                 e1 = k.evt_en;
                 tl = M.pay[k.pidx].total_len;
@@ -280,27 +299,23 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             const bool brk = have && !taken && far;
             uint64_t bm = __ballot(brk), tm = __ballot(taken);
             if (bm) {
-                int first = __ffsll((unsigned long long)bm) - 1;
-                tm &= (1ull << first) - 1ull;
+                int firstb = __ffsll((unsigned long long)bm) - 1;
+                tm &= (1ull << firstb) - 1ull;
                 stop = true;
             }
             const int last = tm ? 63 - __clzll((long long)tm) : 0;
             const uint32_t tl_last = bcast32(tl, last);
-            if (tm) { mL = curL; mS = curS + (uint32_t)last; best_len = tl_last; }
+            if (tm) {
+                mL = curL; mS = (uint32_t)last; best_len = tl_last; m_id = id; m_c = c;
+                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.pidx = bcast32(k.pidx, last);
+            }
             curL++;
-            curS = 0;
+            first = false;
         }
     }
 
-    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
-    if (lbL < T.n_leaves) {
-        const ClusterKey k = M.leaves[(size_t)M.dir[lbL].pidx * LEAF + lbS];
-        exists_at_lb = k.rstart == r2 && k.evt_en == e2;
-    }
-
     if (mL != 0xFFFFFFFFu) {
-        const uint32_t mid = M.dir[mL].pidx;
-        const ClusterKey mk = M.leaves[(size_t)mid * LEAF + mS];
+        const uint32_t mid = m_id;
         const ClusterPay mp = M.pay[mk.pidx];
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
@@ -333,10 +348,10 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             }
             wave_sync();
         } else if (exists_at_lb) {
-            tracker_erase(T, M, mL, mS, lane);     // the re-insert collides: the cluster is dropped
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // the re-insert collides: the cluster is dropped
             T.n--;
         } else {
-            tracker_erase(T, M, mL, mS, lane);     // lb sorts before the match: its position is unaffected
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // lb sorts before the match: its position is unaffected
             if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
         if (lane == 0) {
@@ -388,8 +403,8 @@ __device__ __forceinline__ void merge_stages(uint64_t (&a)[E], uint64_t (&b)[E],
             const bool lower = ((uint32_t)lane & d) == 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
-                uint64_t pb = (uint64_t)__shfl_xor((unsigned long long)b[e], (int)d);
+                uint64_t pa = xor_lane64(a[e], d);
+                uint64_t pb = xor_lane64(b[e], d);
                 uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
                 bool up = (p & k) == 0;
                 bool want_min = lower == up;
@@ -492,7 +507,7 @@ __device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, 
             const bool lower = ((uint32_t)lane & d) == 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const uint64_t pa = (uint64_t)__shfl_xor((unsigned long long)a[e], (int)d);
+                const uint64_t pa = xor_lane64(a[e], d);
                 const uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
                 const bool up = (p & k) == 0;
                 const bool want_min = lower == up;
@@ -632,7 +647,7 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 #define UNC_LB 3
 #endif
 __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
-    __shared__ float s_probs[NKMER];
+    __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
     // one carved buffer for the per-pass staging of phase E (5.5 KB), reused as the source list in phase F: with the
     // probs table the wavefront stays under 10 KB of LDS, i.e. 16 wavefronts per CU fit the 160 KB
@@ -792,12 +807,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             uint32_t nchild = 0, n_seedp = 0;
             bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort below)
             // parent index list and record headers are fetched one / two passes ahead of their use
-            uint32_t phys_cur = (uint32_t)lane < n_parents ? pord[lane] : 0u;
-            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? pord[lane + WAVE] : 0u;
+            uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(pord, (uint32_t)lane << 2) : 0u;
+            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(pord, ((uint32_t)lane + WAVE) << 2) : 0u;
             uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
             if ((uint32_t)lane < n_parents) {
-                const uint4 *q = reinterpret_cast<const uint4 *>(par + phys_cur);
-                q0c = q[0]; q1c = q[1];
+                q0c = gld<uint4>(par, phys_cur << 7); q1c = gld<uint4>(par, (phys_cur << 7) + 16u);
             }
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
                 const uint32_t pi = base + (uint32_t)lane;
@@ -806,10 +820,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 const uint4 q0 = q0c, q1 = q1c;
                 phys_cur = phys_nxt;
                 if (pi + WAVE < n_parents) {
-                    const uint4 *q = reinterpret_cast<const uint4 *>(par + phys_nxt);
-                    q0c = q[0]; q1c = q[1];
+                    q0c = gld<uint4>(par, phys_nxt << 7); q1c = gld<uint4>(par, (phys_nxt << 7) + 16u);
                 }
-                if (pi + 2 * WAVE < n_parents) phys_nxt = pord[pi + 2 * WAVE];
+                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(pord, (pi + 2 * WAVE) << 2);
                 uint32_t pmoves = 0, pmeta = 0;
                 uint64_t pstart = 1, pend = 1;
                 float pprob = 0.0f;
@@ -823,12 +836,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 const uint32_t kmer = pmeta & META_KMER_MASK;
                 const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
                 const bool stay_ok = have && stays < P.max_consec_stay && s_probs[kmer] >= thr;
-                uint32_t mask = 0;
-#pragma unroll
-                for (uint32_t b = 0; b < 4; ++b) {
-                    const uint32_t nk = ((kmer << 2) & KMASK) | b;    // kmer_neighbor, bp.hpp:105-108
-                    if (have && !(s_probs[nk] < thr)) mask |= 1u << b;
-                }
+                // kmer_neighbor (bp.hpp:105-108): the four successors ((kmer << 2) & KMASK) | b are neighbours in the table
+                const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
+                uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
+                if (!have) mask = 0;
                 s_pstart[lane] = pstart; s_pend[lane] = pend; s_pphys[lane] = phys; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta;
                 const uint32_t ncand = (uint32_t)__popc(mask);
                 uint32_t ctot;
@@ -915,16 +926,15 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     if (li < nwrite) {
                         const uint32_t d = s_cdesc[li];
                         const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
-                        const PathRec *pp = par + s_pphys[pl];
+                        const uint32_t po = s_pphys[pl] << 7;     // byte offset of the parent's record
                         const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
                         const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
                         // the parent's ring (6 x 16 B) plus the two sums the child needs, all in one round trip
-                        const uint4 *q = reinterpret_cast<const uint4 *>(pp);
-                        const uint4 r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6],
-                                    r7 = q[7];
+                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
+                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
                         uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
                         uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
-                        const float last = pp->ps[sl], second = pp->ps[s2];
+                        const float last = gld<float>(par, po + 32u + (sl << 2)), second = gld<float>(par, po + 32u + (s2 << 2));
                         const uint32_t pk = pmt & META_KMER_MASK;
                         uint64_t cs, ce;
                         uint32_t ck, mv;
@@ -941,14 +951,13 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         SortKey key;
                         const uint32_t gi = nchild + li;
                         const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
-                        PathRec *cp = chd + gi;
-                        uint4 *w = reinterpret_cast<uint4 *>(cp);
-                        w[0] = (make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
-                        w[1] = (make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
-                        w[2] = (r2); w[3] = (r3); w[4] = (r4); w[5] = (r5); w[6] = (r6);
-                        w[7] = (r7);
-                        cp->ps[c.wslot] = c.appended;   // same lane, same address as the copy above: program order
-                        ukeys[gi] = key;
+                        const uint32_t co = gi << 7;
+                        gst(chd, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
+                        gst(chd, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
+                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
+                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
+                        gst(chd, co + 32u + (c.wslot << 2), c.appended);   // same lane, same address as the copy above: program order
+                        gst(ukeys, gi << 4, key);
                     }
                 }
 #else

@@ -98,6 +98,46 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 // Streaming (write-once / read-once) traffic such as the path records: keep it from evicting the FM index
 // out of the XCD's L2.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Value of lane (lane ^ D).  Distances 1 and 2 stay inside a quad (one DPP move per dword), 4 and 8 inside a 16-lane
+// row (two bank-masked DPP row shifts per dword); none of them touches the LDS crossbar or needs a wait, unlike
+// ds_bpermute, which serves the distances 16 and 32.
+template <int D> __device__ __forceinline__ uint32_t xor_lane32(uint32_t v) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);        // banks 0,2 <- lane + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);     // banks 1,3 <- lane - 4
+    } else if constexpr (D == 8) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0x3, false);        // banks 0,1 <- lane + 8
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xF, 0xC, false);     // banks 2,3 <- lane - 8
+    } else return (uint32_t)__shfl_xor((int)v, D);
+}
+template <int D> __device__ __forceinline__ uint64_t xor_lane64(uint64_t v) {
+    return ((uint64_t)xor_lane32<D>((uint32_t)(v >> 32)) << 32) | xor_lane32<D>((uint32_t)v);
+}
+// runtime distance (uniform): dispatch to the constant-distance forms
+__device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
+    switch (d) {
+        case 1: return xor_lane64<1>(v);
+        case 2: return xor_lane64<2>(v);
+#ifndef UNC_DPP_QUAD_ONLY
+        case 4: return xor_lane64<4>(v);
+        case 8: return xor_lane64<8>(v);
+#endif
+        default: return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
+    }
+}
+
+// Global access as (uniform base, 32-bit byte offset): lets the compiler address with an SGPR base plus one VGPR
+// (global_load ... v_off, s[base]) instead of building a 64-bit address in a VGPR pair per access.  Every per-slot
+// array is far below 4 GB.
+template <class T> __device__ __forceinline__ T gld(const void *base, uint32_t off) {
+    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + off);
+}
+template <class T> __device__ __forceinline__ void gst(void *base, uint32_t off, const T &v) {
+    *reinterpret_cast<T *>(static_cast<char *>(base) + off) = v;
+}
+
 __device__ __forceinline__ void nt_store(uint4 *p, uint4 v) {
     u32x4 w;
     __builtin_memcpy(&w, &v, 16);
