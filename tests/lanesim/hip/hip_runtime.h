@@ -176,6 +176,8 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (ctrl < 0x100) sl = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl >= 0x101 && ctrl <= 0x10F) { sl = l + (ctrl & 15); valid = (sl >> 4) == (l >> 4); }
     else if (ctrl >= 0x111 && ctrl <= 0x11F) { sl = l - (ctrl & 15); valid = sl >= 0 && (sl >> 4) == (l >> 4); }
+    else if (ctrl == 0x140) sl = (l & ~15) | (15 - (l & 15));   // row_mirror
+    else if (ctrl == 0x141) sl = (l & ~7) | (7 - (l & 7));      // row_half_mirror
     const int got = __lanesim_shfl_abs(src, valid ? sl : l);
     const bool en = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
     return (en && valid) ? got : old;

@@ -146,8 +146,9 @@ __device__ __forceinline__ void dir_shift_down(ClusterKey *dir, uint32_t a, uint
     }
 }
 
-// remove entry `slot` of directory position L, whose leaf has id `id` and `c` keys; keeps the directory's first keys right
-__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
+// remove entry `slot` of directory position L (leaf id, count c); keeps the directory's first keys right
+__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, int lane) {
+    const uint32_t id = M.dir[L].pidx, c = M.cnt[id];
     ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
     ClusterKey k;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
@@ -236,55 +237,35 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         lo = nlo;
         hi = nhi;
     }
-    // the last directory window stays in registers (lane l: entry lo + l): leaf ids and first keys are read off it below
     uint32_t d;
-    ClusterKey dk; dk.rstart = 0; dk.evt_en = 0; dk.pidx = 0;
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
-        if (idx < hi) { dk = M.dir[idx]; less = key_less(dk, r2, e2); }
+        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
         d = lo + (uint32_t)__popcll(__ballot(less));
     }
-    // leaf d - 1 (the last one whose first key sorts before the seed), its count and keys in one round trip
     uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
-    uint32_t id0 = 0, c0 = 0;    // leaf id / count of directory position d - 1
-    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.pidx = 0;
     if (d > 0) {
-        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(M.dir[d - 1].pidx);   // window starts after it
-        lk = M.leaves[(size_t)id0 * LEAF + lane];       // slots past the count hold stale keys: masked by c0
-        c0 = M.cnt[id0];
-        const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
-        const uint32_t sn = (uint32_t)__popcll(__ballot(less));
-        if (sn < c0) { lbL = d - 1; lbS = sn; } else { lbL = d; lbS = 0; }
+        const uint32_t id = M.dir[d - 1].pidx, c = M.cnt[id];
+        bool less = false;
+        if ((uint32_t)lane < c) less = key_less(M.leaves[(size_t)id * LEAF + lane], r2, e2);
+        const uint32_t s = (uint32_t)__popcll(__ballot(less));
+        if (s < c) { lbL = d - 1; lbS = s; } else { lbL = d; lbS = 0; }
     }
-    const bool lb_in_leaf0 = d > 0 && lbL == d - 1;
 
     // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
-    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0, m_id = 0, m_c = 0;
-    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.pidx = 0;
-    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
+    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0;
     bool stop = false;
     {
-        uint32_t curL = lbL;
-        bool first = true;
+        uint32_t curL = lbL, curS = lbS;
         while (curL < T.n_leaves && !stop) {
-            uint32_t id, c, from = 0;
-            ClusterKey k;
-            if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
-            else {
-                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(M.dir[curL].pidx);
-                k = M.leaves[(size_t)id * LEAF + lane];
-                c = M.cnt[id];
-            }
-            if (first) {   // the key at the lower bound is the first one this scan looks at
-                const uint64_t kr = bcast64(k.rstart, (int)from);
-                const uint32_t ke = bcast32(k.evt_en, (int)from);
-                exists_at_lb = kr == r2 && ke == e2;
-            }
-            const bool have = (uint32_t)lane >= from && (uint32_t)lane < c;
+            const uint32_t id = M.dir[curL].pidx, c = M.cnt[id];
+            const uint32_t e = curS + (uint32_t)lane;
+            const bool have = e < c;
             uint64_t r1 = 0;
             uint32_t e1 = 0, tl = 0;
             if (have) {
+                ClusterKey k = M.leaves[(size_t)id * LEAF + e];
                 r1 = k.rstart;
                 e1 = k.evt_en;
                 tl = M.pay[k.pidx].total_len;
@@ -299,23 +280,27 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             const bool brk = have && !taken && far;
             uint64_t bm = __ballot(brk), tm = __ballot(taken);
             if (bm) {
-                int firstb = __ffsll((unsigned long long)bm) - 1;
-                tm &= (1ull << firstb) - 1ull;
+                int first = __ffsll((unsigned long long)bm) - 1;
+                tm &= (1ull << first) - 1ull;
                 stop = true;
             }
             const int last = tm ? 63 - __clzll((long long)tm) : 0;
             const uint32_t tl_last = bcast32(tl, last);
-            if (tm) {
-                mL = curL; mS = (uint32_t)last; best_len = tl_last; m_id = id; m_c = c;
-                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.pidx = bcast32(k.pidx, last);
-            }
+            if (tm) { mL = curL; mS = curS + (uint32_t)last; best_len = tl_last; }
             curL++;
-            first = false;
+            curS = 0;
         }
     }
 
+    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
+    if (lbL < T.n_leaves) {
+        const ClusterKey k = M.leaves[(size_t)M.dir[lbL].pidx * LEAF + lbS];
+        exists_at_lb = k.rstart == r2 && k.evt_en == e2;
+    }
+
     if (mL != 0xFFFFFFFFu) {
-        const uint32_t mid = m_id;
+        const uint32_t mid = M.dir[mL].pidx;
+        const ClusterKey mk = M.leaves[(size_t)mid * LEAF + mS];
         const ClusterPay mp = M.pay[mk.pidx];
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
@@ -348,10 +333,10 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             }
             wave_sync();
         } else if (exists_at_lb) {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // the re-insert collides: the cluster is dropped
+            tracker_erase(T, M, mL, mS, lane);     // the re-insert collides: the cluster is dropped
             T.n--;
         } else {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // lb sorts before the match: its position is unaffected
+            tracker_erase(T, M, mL, mS, lane);     // lb sorts before the match: its position is unaffected
             if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
         if (lane == 0) {
@@ -499,8 +484,12 @@ UNC_SORT_FN void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int la
 // ---- narrow mode: start, length and creation index of a child fit one 64-bit key (index-dependent, decided at load:
 // DevIndex::key_len_bits).  Half the data to move per sort stage; the seed_prob
 // ordering inside runs of equal ranges is recovered afterwards by a segmented max over the children's info words.
+// The network is the all-ascending form of the bitonic sorter: a merge of size k starts with the "flip" stage
+// (element q against q ^ (k - 1), the mirror image inside its k-group) and continues with the half-cleaners
+// j = k/4 .. 1 (q against q ^ j); the lower index always keeps the minimum.  Every sorted run is ascending, so the
+// +inf padding behind the n real keys never moves and whole blocks / pairs made of padding are skipped.
 template <int E>
-__device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, uint32_t k, uint32_t j_from, int lane) {
+__device__ __forceinline__ void asc_stages64(uint64_t (&a)[E], uint32_t j_from, int lane) {
     for (uint32_t j = j_from; j > 0; j >>= 1) {
         if (j >= (uint32_t)E) {
             const uint32_t d = j / (uint32_t)E;
@@ -508,11 +497,8 @@ __device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, 
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint64_t pa = xor_lane64(a[e], d);
-                const uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
-                const bool up = (p & k) == 0;
-                const bool want_min = lower == up;
                 const bool gt = a[e] > pa;
-                if (want_min ? gt : !gt) a[e] = pa;
+                if (lower ? gt : !gt) a[e] = pa;
             }
         } else {
 #pragma unroll
@@ -522,15 +508,48 @@ __device__ __forceinline__ void merge_stages64(uint64_t (&a)[E], uint32_t base, 
                     for (int e = 0; e < E; ++e) {
                         if (!(e & jj)) {
                             const int pe = e | jj;
-                            const uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
-                            const bool up = (p & k) == 0;
-                            const bool gt = a[e] > a[pe];
-                            if (up ? gt : !gt) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
+                            if (a[e] > a[pe]) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
                         }
                     }
                 }
             }
         }
+    }
+}
+
+// flip stage of a merge of size k <= 64 * E inside a block
+template <int E>
+__device__ __forceinline__ void flip_stage64(uint64_t (&a)[E], uint32_t k, int lane) {
+    if (k > (uint32_t)E) {
+        const uint32_t kl = k / (uint32_t)E;                 // lanes per k-group; partner lane = lane ^ (kl - 1), register E-1-e
+        const bool lower = ((uint32_t)lane & (kl >> 1)) == 0;
+        uint64_t pa[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) pa[e] = xor_lane64(a[E - 1 - e], kl - 1u);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool gt = a[e] > pa[e];
+            if (lower ? gt : !gt) a[e] = pa[e];
+        }
+    } else {
+#pragma unroll
+        for (int kk = 2; kk <= E; kk <<= 1) {
+            if (k == (uint32_t)kk) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int pe = e ^ (kk - 1);
+                    if (pe > e && a[e] > a[pe]) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void block_sort64(uint64_t (&a)[E], int lane) {
+    for (uint32_t k = 2; k <= 64u * E; k <<= 1) {
+        flip_stage64<E>(a, k, lane);
+        asc_stages64<E>(a, k >> 2, lane);
     }
 }
 
@@ -543,7 +562,7 @@ UNC_SORT_FN void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int l
         const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
         a[e] = i < n ? in[i].a : ~0ull;
     }
-    for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages64<E>(a, 0, k, k >> 1, lane);
+    block_sort64<E>(a, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
@@ -557,32 +576,46 @@ UNC_SORT_FN void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int
     uint32_t N = 2 * B;
     while (N < n) N <<= 1;
     uint64_t a[E];
-    for (uint32_t base = 0; base < N; base += B) {
+    for (uint32_t base = 0; base < n; base += B) {          // blocks that hold real keys
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
             a[e] = i < n ? in[i].a : ~0ull;
         }
-        for (uint32_t k = 2; k <= B; k <<= 1) merge_stages64<E>(a, base, k, k >> 1, lane);
+        block_sort64<E>(a, lane);
 #pragma unroll
         for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
     }
     wave_sync();
     for (uint32_t k = 2 * B; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j >= B; j >>= 1) {
-            for (uint32_t t = (uint32_t)lane; t < N / 2; t += 64) {
+        // flip: i against i ^ (k - 1); a pair whose upper element is padding (>= n) has nothing to exchange
+        for (uint32_t t0 = 0; t0 < N / 2; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint32_t i = ((t & ~((k >> 1) - 1)) << 1) | (t & ((k >> 1) - 1));
+            const uint32_t p = i ^ (k - 1);
+            if (p < n) {
+                const uint64_t x = out[i], y = out[p];
+                if (x > y) { out[i] = y; out[p] = x; }
+            }
+        }
+        wave_sync();
+        for (uint32_t j = k >> 2; j >= B; j >>= 1) {
+            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64) {
+                const uint32_t t = t0 + (uint32_t)lane;
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const uint32_t p = i | j;
-                const uint64_t x = out[i], y = out[p];
-                const bool up = (i & k) == 0;
-                if (up ? x > y : x < y) { out[i] = y; out[p] = x; }
+                if (uniform32(p) >= n) continue;            // p grows with the lane: the whole pass is padding
+                if (p < n) {
+                    const uint64_t x = out[i], y = out[p];
+                    if (x > y) { out[i] = y; out[p] = x; }
+                }
             }
             wave_sync();
         }
-        for (uint32_t base = 0; base < N; base += B) {
+        for (uint32_t base = 0; base < n; base += B) {
 #pragma unroll
             for (int e = 0; e < E; ++e) a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
-            merge_stages64<E>(a, base, k, B >> 1, lane);
+            asc_stages64<E>(a, B >> 1, lane);
 #pragma unroll
             for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
         }

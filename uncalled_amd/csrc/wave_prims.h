@@ -110,13 +110,21 @@ template <int D> __device__ __forceinline__ uint32_t xor_lane32(uint32_t v) {
     } else if constexpr (D == 8) {
         const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0x3, false);        // banks 0,1 <- lane + 8
         return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xF, 0xC, false);     // banks 2,3 <- lane - 8
-    } else return (uint32_t)__shfl_xor((int)v, D);
+    } else if constexpr (D == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+    else if constexpr (D == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+    else if constexpr (D == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    else return (uint32_t)__shfl_xor((int)v, D);
 }
 template <int D> __device__ __forceinline__ uint64_t xor_lane64(uint64_t v) {
     return ((uint64_t)xor_lane32<D>((uint32_t)(v >> 32)) << 32) | xor_lane32<D>((uint32_t)v);
 }
-// runtime distance (uniform): dispatch to the constant-distance forms
+// runtime distance (uniform).  Dispatching to the DPP forms measured SLOWER than plain ds_bpermute in the sort
+// networks (8.32 s against 8.04 s per 50 k reads: the five-way branch per stage and the DPP wait states cost more than
+// the LDS crossbar trips they save), so the dispatch is off unless UNC_DPP_SORT is defined.
 __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
+#ifndef UNC_DPP_SORT
+    return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
+#endif
     switch (d) {
         case 1: return xor_lane64<1>(v);
         case 2: return xor_lane64<2>(v);
@@ -124,6 +132,9 @@ __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
         case 4: return xor_lane64<4>(v);
         case 8: return xor_lane64<8>(v);
 #endif
+        case 3: return xor_lane64<3>(v);
+        case 7: return xor_lane64<7>(v);
+        case 15: return xor_lane64<15>(v);
         default: return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
     }
 }
