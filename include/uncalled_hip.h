@@ -174,6 +174,9 @@ int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_ma
  * [0] match probs, [1] extension (loop overhead), [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed,
  * [7] rest, [8] E1 parent loads + candidates, [9] E2 FM look-ups, [10] E3 child slots, [11] E4 child records */
 int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
+/* the counters above are collected only by batches mapped while profiling is on (off by default: the counting
+ * instantiation of k_map is about 2 % slower) */
+void unc_mapper_set_profile(unc_mapper_t *m, int on);
 /* mean lifetime of the persistent wavefronts of the last batch's k_map launch / the launch duration (both from the
  * device wall clock): 1.0 = every wavefront worked until the end, lower = idle tail behind the longest reads */
 double unc_mapper_last_wave_busy(const unc_mapper_t *m);

@@ -40,6 +40,8 @@ for spec in sys.argv[2:]:
         except TypeError:
             m = capi.Mapper(ix)
         t = []
+        if hasattr(L, "unc_mapper_set_profile"):
+            m.set_profile(True)
         for i in range(2):
             hits = m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
             t.append(m.last_timing()[1])

@@ -65,7 +65,8 @@ def index_cmd(args):
     for tgt in (args.speeds.split(",") if args.speeds else []):
         presets.append(("speed_%s" % tgt, dict(tgt_speed=float(tgt))))
     if not os.path.exists(prefix + ".uncl"):
-        open(prefix + ".uncl", "w").close()   # the loader wants the file; self-align does not read thresholds
+        with open(prefix + ".uncl", "w") as f:   # the loader wants a preset; self-align does not read the thresholds
+            f.write("default\t-10.0\t0.00000\t0.000\n")
     ix = capi.Index(prefix, device=args.device)
     index_params.parameterize(ix, prefix, presets=presets, max_sample_dist=args.max_sample_dist,
                               min_samples=args.min_samples, max_samples=args.max_samples, kmer_len=args.kmer_len,

@@ -146,9 +146,8 @@ __device__ __forceinline__ void dir_shift_down(ClusterKey *dir, uint32_t a, uint
     }
 }
 
-// remove entry `slot` of directory position L (leaf id, count c); keeps the directory's first keys right
-__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, int lane) {
-    const uint32_t id = M.dir[L].pidx, c = M.cnt[id];
+// remove entry `slot` of directory position L, whose leaf has id `id` and `c` keys; keeps the directory's first keys right
+__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
     ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
     ClusterKey k;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
@@ -237,35 +236,55 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         lo = nlo;
         hi = nhi;
     }
+    // the last directory window stays in registers (lane l: entry lo + l): leaf ids and first keys are read off it below
     uint32_t d;
+    ClusterKey dk; dk.rstart = 0; dk.evt_en = 0; dk.pidx = 0;
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
-        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
+        if (idx < hi) { dk = M.dir[idx]; less = key_less(dk, r2, e2); }
         d = lo + (uint32_t)__popcll(__ballot(less));
     }
+    // leaf d - 1 (the last one whose first key sorts before the seed), its count and keys in one round trip
     uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
+    uint32_t id0 = 0, c0 = 0;    // leaf id / count of directory position d - 1
+    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.pidx = 0;
     if (d > 0) {
-        const uint32_t id = M.dir[d - 1].pidx, c = M.cnt[id];
-        bool less = false;
-        if ((uint32_t)lane < c) less = key_less(M.leaves[(size_t)id * LEAF + lane], r2, e2);
-        const uint32_t s = (uint32_t)__popcll(__ballot(less));
-        if (s < c) { lbL = d - 1; lbS = s; } else { lbL = d; lbS = 0; }
+        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(M.dir[d - 1].pidx);   // window starts after it
+        lk = M.leaves[(size_t)id0 * LEAF + lane];       // slots past the count hold stale keys: masked by c0
+        c0 = M.cnt[id0];
+        const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
+        const uint32_t sn = (uint32_t)__popcll(__ballot(less));
+        if (sn < c0) { lbL = d - 1; lbS = sn; } else { lbL = d; lbS = 0; }
     }
+    const bool lb_in_leaf0 = d > 0 && lbL == d - 1;
 
     // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
-    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0;
+    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0, m_id = 0, m_c = 0;
+    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.pidx = 0;
+    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
     bool stop = false;
     {
-        uint32_t curL = lbL, curS = lbS;
+        uint32_t curL = lbL;
+        bool first = true;
         while (curL < T.n_leaves && !stop) {
-            const uint32_t id = M.dir[curL].pidx, c = M.cnt[id];
-            const uint32_t e = curS + (uint32_t)lane;
-            const bool have = e < c;
+            uint32_t id, c, from = 0;
+            ClusterKey k;
+            if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
+            else {
+                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(M.dir[curL].pidx);
+                k = M.leaves[(size_t)id * LEAF + lane];
+                c = M.cnt[id];
+            }
+            if (first) {   // the key at the lower bound is the first one this scan looks at
+                const uint64_t kr = bcast64(k.rstart, (int)from);
+                const uint32_t ke = bcast32(k.evt_en, (int)from);
+                exists_at_lb = kr == r2 && ke == e2;
+            }
+            const bool have = (uint32_t)lane >= from && (uint32_t)lane < c;
             uint64_t r1 = 0;
             uint32_t e1 = 0, tl = 0;
             if (have) {
-                ClusterKey k = M.leaves[(size_t)id * LEAF + e];
                 r1 = k.rstart;
                 e1 = k.evt_en;
                 tl = M.pay[k.pidx].total_len;
@@ -280,27 +299,23 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             const bool brk = have && !taken && far;
             uint64_t bm = __ballot(brk), tm = __ballot(taken);
             if (bm) {
-                int first = __ffsll((unsigned long long)bm) - 1;
-                tm &= (1ull << first) - 1ull;
+                int firstb = __ffsll((unsigned long long)bm) - 1;
+                tm &= (1ull << firstb) - 1ull;
                 stop = true;
             }
             const int last = tm ? 63 - __clzll((long long)tm) : 0;
             const uint32_t tl_last = bcast32(tl, last);
-            if (tm) { mL = curL; mS = curS + (uint32_t)last; best_len = tl_last; }
+            if (tm) {
+                mL = curL; mS = (uint32_t)last; best_len = tl_last; m_id = id; m_c = c;
+                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.pidx = bcast32(k.pidx, last);
+            }
             curL++;
-            curS = 0;
+            first = false;
         }
     }
 
-    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
-    if (lbL < T.n_leaves) {
-        const ClusterKey k = M.leaves[(size_t)M.dir[lbL].pidx * LEAF + lbS];
-        exists_at_lb = k.rstart == r2 && k.evt_en == e2;
-    }
-
     if (mL != 0xFFFFFFFFu) {
-        const uint32_t mid = M.dir[mL].pidx;
-        const ClusterKey mk = M.leaves[(size_t)mid * LEAF + mS];
+        const uint32_t mid = m_id;
         const ClusterPay mp = M.pay[mk.pidx];
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
@@ -333,10 +348,10 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             }
             wave_sync();
         } else if (exists_at_lb) {
-            tracker_erase(T, M, mL, mS, lane);     // the re-insert collides: the cluster is dropped
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // the re-insert collides: the cluster is dropped
             T.n--;
         } else {
-            tracker_erase(T, M, mL, mS, lane);     // lb sorts before the match: its position is unaffected
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // lb sorts before the match: its position is unaffected
             if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
         if (lane == 0) {
@@ -679,6 +694,8 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 #ifndef UNC_LB
 #define UNC_LB 3
 #endif
+// PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
+template <bool PROF>
 __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
@@ -769,7 +786,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
             event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
-            if (restore) { for (int i = 0; i < 12; ++i) cyc[i] = st->cyc[i]; }
+            if (restore) { if constexpr (PROF) { for (int i = 0; i < 12; ++i) cyc[i] = st->cyc[i]; } }
             else if (uniform32(st->done)) break;
         } else if (A.resume) {
             r = blockIdx.x;
@@ -807,12 +824,8 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             ++steps;
 
             // ---------------- P: match log-probs ----------------
-            uint64_t tk = (uint64_t)clock64(), tn;
-#ifdef UNC_NO_PROFILE
-#define PHASE_END(i) (void)tn
-#else
-#define PHASE_END(i) tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn
-#endif
+            uint64_t tk = PROF ? (uint64_t)clock64() : 0ull, tn = 0;
+#define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
 #ifdef UNC_PROFILE_FINE
 #define PHASE_FINE(i) PHASE_END(i)
 #else
@@ -898,9 +911,11 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 wave_sync();
                 PHASE_FINE(9);
                 // children per parent, in the reference's order: stay, then bases 0..3
-                uint32_t vmask = 0;   // bit j: j-th candidate of this lane has a non-empty range
-                for (uint32_t j = 0; j < ncand; ++j)
-                    if (s_res[coff + j] != 0) vmask |= 1u << j;
+                // bit j: j-th candidate of this lane has a non-empty range (four unconditional reads; the staging buffer
+                // extends past the result slots, and whatever lies beyond this lane's candidates is masked off)
+                uint32_t vmask = (s_res[coff] != 0 ? 1u : 0u) | (s_res[coff + 1] != 0 ? 2u : 0u) | (s_res[coff + 2] != 0 ? 4u : 0u) |
+                                 (s_res[coff + 3] != 0 ? 8u : 0u);
+                vmask &= (1u << ncand) - 1u;
                 const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
                 uint32_t chtot;
                 const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
@@ -908,8 +923,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
                 const bool visited = have && choff < room;                // reached before the buffer filled
                 // work counter: the get_neighbor calls the reference makes (it stops at the cut-off)
-                for (uint32_t j = 0; j < ncand; ++j)
-                    if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
+                if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += ncand;   // every call precedes the cut-off
+                else
+                    for (uint32_t j = 0; j < ncand; ++j)
+                        if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
                 {
                     uint32_t w = choff;
                     if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
@@ -1331,7 +1348,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
-            for (int i = 0; i < 12; ++i) res.cyc[i] = cyc[i];
+            for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
         if (A.resume || !done) {
@@ -1341,7 +1358,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
-                if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; }
+                if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
             if (!sliced) break;
@@ -1366,12 +1383,13 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched) {
+                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile) {
     MapArgs a;
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
-    hipLaunchKernelGGL(k_map, dim3(grid), dim3(WAVE), 0, st, a);
+    if (profile) hipLaunchKernelGGL(k_map<true>, dim3(grid), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL(k_map<false>, dim3(grid), dim3(WAVE), 0, st, a);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {

@@ -393,6 +393,7 @@ struct unc_mapper {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
+    bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
     uint32_t *d_next = nullptr;
     // per-batch buffers (grown on demand)
     int16_t *d_raw = nullptr; size_t raw_cap = 0;
@@ -641,7 +642,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
     if (sliced) launch_sched_init(m->sched, st);
     launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
-               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr);
+               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
@@ -709,6 +710,7 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
 }
 
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
+extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
 
 extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
     if (ms_events) *ms_events = m->ms_events;
