@@ -660,17 +660,13 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
     const uint32_t cstay = (pstay + stay) * stay;
     ChildHdr c;
     c.appended = __fadd_rn(last, prob);
-    uint32_t nhead;
-    if (full) {
-        c.seed_prob = __fdiv_rn(__fsub_rn(c.appended, second), (float)SEED_LEN);
-        moves |= PATH_TAIL_MOVE;
-        nhead = head + 1u == PS_RING ? 0u : head + 1u;
-        c.wslot = head;                         // overwrite the dropped prob_sums_[0]
-    } else {
-        c.seed_prob = __fdiv_rn(c.appended, (float)len);
-        nhead = head;
-        c.wslot = head + len;                   // head is 0 until the window fills
-    }
+    // full window: (appended - prob_sums_[1]) / seed_len, and the dropped prob_sums_[0] is overwritten; else appended / len
+    // (head is 0 until the window fills).  One IEEE division serves both cases.
+    const float num = full ? __fsub_rn(c.appended, second) : c.appended;
+    c.seed_prob = __fdiv_rn(num, (float)(full ? (uint32_t)SEED_LEN : len));
+    if (full) moves |= PATH_TAIL_MOVE;
+    const uint32_t nhead = full ? (head + 1u == PS_RING ? 0u : head + 1u) : head;
+    c.wslot = full ? head : head + len;
     c.moves = moves;
     c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (pmeta & META_SA_CHECKED) | (nhead << META_HEAD_SHIFT);
     // is_seed_valid(path_ended = false), mapper.cpp:842-855, known at creation time
@@ -1155,6 +1151,12 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     if ((uint32_t)lane < n) bq0 = ukeys[kq0 & 0xFFFFu].b;
                     if ((uint32_t)lane + WAVE < n) bq1 = ukeys[kq1 & 0xFFFFu].b;
                 }
+                // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
+                ulonglong2 krq = make_ulonglong2(1ull, 0ull);
+                if (kl && (uint32_t)lane < n) {
+                    const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
+                    if (s_probs[km0] >= source_prob) krq = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[km0];
+                }
                 for (uint32_t base = 0; base < n; base += WAVE) {
                     const uint32_t i = base + (uint32_t)lane;
                     const bool have = i < n;
@@ -1162,6 +1164,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     uint64_t start, end, nstart, sb;     // sb: info word of the child that survives at this position
                     uint32_t kmer, nkmer;
                     bool dup;
+                    ulonglong2 krc = make_ulonglong2(1ull, 0ull);
                     if (kl) {
                         const uint64_t ki = kq0, bi = bq0;
                         uint64_t kn = (uint64_t)__shfl((unsigned long long)ki, (lane + 1) & 63);
@@ -1170,6 +1173,12 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         if (lane == WAVE - 1) { kn = kf; bn = bf; }
                         kq0 = kq1; bq0 = bq1;
                         kq1 = i + 2 * WAVE < n ? skeys64[i + 2 * WAVE] : ~0ull;
+                        krc = krq;
+                        krq = make_ulonglong2(1ull, 0ull);
+                        if (i + WAVE < n) {
+                            const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
+                            if (s_probs[kmn] >= source_prob) krq = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[kmn];
+                        }
                         const uint64_t ri = ki >> 16, rn = kn >> 16;
                         start = ri >> kl; end = start + (ri & ((1ull << kl) - 1ull));
                         nstart = rn >> kl;
@@ -1211,8 +1220,13 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
                     if (headless && carry_U > U) U = carry_U;
                     uint64_t kr_s = 1, kr_e = 0;
-                    if (first && psrc) kr_s = ix.kmer_ranges[2 * kmer];
-                    if (have && !dup && psrc && !next_same) kr_e = ix.kmer_ranges[2 * kmer + 1];
+                    if (kl) {
+                        if (first && psrc) kr_s = krc.x;
+                        if (have && !dup && psrc && !next_same) kr_e = krc.y;
+                    } else {
+                        if (first && psrc) kr_s = ix.kmer_ranges[2 * kmer];
+                        if (have && !dup && psrc && !next_same) kr_e = ix.kmer_ranges[2 * kmer + 1];
+                    }
                     const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
                     const uint64_t c_s = U, c_e = next_same ? nstart - 1 : kr_e;                   // :579-589
                     const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
