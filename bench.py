@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("UNC_BENCH_READS", 50000)),
                     help="reads per GPU per step (config: E. coli 4.6 Mb ref, 50k synthetic r9.4.1 reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed pass that collects phase cycle shares")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "realtime"], default="ecoli")
     ap.add_argument("--channels", type=int, default=512)
     a = ap.parse_args()
@@ -226,9 +227,10 @@ def main():
 
     wave_busy = mapper.last_wave_busy()
     # phase shares come from one extra, untimed pass with the cycle-counting instantiation of k_map
-    mapper.set_profile(True)
-    mapper.map_batch_device(raw_ptr, offsets, calib, stream=stream)
-    mapper.set_profile(False)
+    if not a.no_profile_pass:
+        mapper.set_profile(True)
+        mapper.map_batch_device(raw_ptr, offsets, calib, stream=stream)
+        mapper.set_profile(False)
     pc = mapper.last_phase_cycles()
     tot_c = float(sum(pc.values())) or 1.0
     phase_share = {k: round(v / tot_c, 4) for k, v in pc.items()}
