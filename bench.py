@@ -30,6 +30,11 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
     if workload == "chr20":
         prefix = cache / "chr20_syn"
         names, lens, codes, holes, n_ambs = masked_synthetic_genome(1, 64444167, seed=2, name="chr20_syn")
+    elif workload == "hs400":
+        # an eighth of `grch38_syn`: 8 contigs, 400 Mbp, seed 3, 30 % masked -- the largest reference the
+        # GPU suffix-array builder takes (seq_len < 2^31); BWT + Occ 400 MB, i.e. past the 256 MiB Infinity Cache
+        prefix = cache / "hs400_syn"
+        names, lens, codes, holes, n_ambs = masked_synthetic_genome(8, 400000000, seed=3, name="hs400_syn")
     else:
         prefix = cache / "ecoli_syn"
         names, lens, codes = synthetic_genome(1, 4641652, seed=1)
@@ -37,7 +42,7 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
     if rank == 0 and not (Path(str(prefix) + ".sa").exists() and Path(str(prefix) + ".uncl").exists()):
         cache.mkdir(parents=True, exist_ok=True)
         build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs,
-                         sa_device=device if workload == "chr20" else None)
+                         sa_device=device if workload in ("chr20", "hs400") else None)
         # `uncalled index`: thresholds for THIS reference (self-alignment on the GPU + IndexParameterizer, preset
         # "default" = tgt_speed 115, scripts/uncalled:58); build_from_codes left the example's vector as a placeholder
         from uncalled_amd import capi
@@ -165,7 +170,7 @@ def main():
                     help="reads per GPU per step (config: E. coli 4.6 Mb ref, 50k synthetic r9.4.1 reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed pass that collects phase cycle shares")
-    ap.add_argument("--workload", choices=["ecoli", "chr20", "realtime"], default="ecoli")
+    ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "realtime"], default="ecoli")
     ap.add_argument("--channels", type=int, default=512)
     a = ap.parse_args()
 
@@ -189,7 +194,7 @@ def main():
     from uncalled_amd import capi
 
     cache = Path(os.environ.get("UNC_BENCH_CACHE", "/tmp/uncalled_amd_bench"))
-    prefix, codes, lens = ensure_index(cache, rank, world, barrier, "chr20" if a.workload == "chr20" else "ecoli",
+    prefix, codes, lens = ensure_index(cache, rank, world, barrier, a.workload if a.workload in ("chr20", "hs400") else "ecoli",
                                        f"cuda:{local_rank}")
     ix = capi.Index(prefix, device=local_rank)
     if a.workload == "realtime":
@@ -251,7 +256,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32/f64",
             "data": "synthetic",
             "config": {"workload": ("repeat-masked chr20-sized synthetic ref (chr20_syn 64.4 Mb, seed 2, 30% N-runs)" if a.workload == "chr20"
-                                    else "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1)") +
+                                    else "one eighth of a masked GRCh38-sized synthetic ref (hs400_syn: 8 contigs, 400 Mb, seed 3, 30% N-runs)"
+                                    if a.workload == "hs400" else "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1)") +
                                    ", synthetic r9.4.1 reads (3600 bases ~ 32k samples, 10% off-target), all reference defaults",
                        "reads_per_gpu_per_step": a.reads, "parallelism": f"reads sharded over {world} GPU(s), index replicated",
                        "mean_ms_per_read_amortised": 1e3 * dt / (a.reads * a.steps),
