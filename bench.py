@@ -231,6 +231,7 @@ def main():
         dt = float(t.item())
 
     wave_busy = mapper.last_wave_busy()
+    remap_n, remap_ms = mapper.last_remap()
     # phase shares come from one extra, untimed pass with the cycle-counting instantiation of k_map
     if not a.no_profile_pass:
         mapper.set_profile(True)
@@ -267,6 +268,8 @@ def main():
                        "k_map_phase_cycle_share": phase_share,
                        "k_map_phase_cycle_share_source": "extra untimed pass, profiling instantiation of k_map",
                        "k_map_wave_busy": round(wave_busy, 4),
+                       "remapped_reads": {"n": remap_n, "ms": round(remap_ms, 1),
+                                          "note": "reads whose seed-cluster set outgrew its slot, mapped again with 16x the room (inside the step)"},
                        "reads_in_flight": mapper_slots(mapper)},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

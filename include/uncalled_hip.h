@@ -177,6 +177,9 @@ int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
 /* the counters above are collected only by batches mapped while profiling is on (off by default: the counting
  * instantiation of k_map is about 2 % slower) */
 void unc_mapper_set_profile(unc_mapper_t *m, int on);
+/* reads of the last batch whose seed-cluster set outgrew its slot and that were mapped again with 16x (256x ..) the
+ * room, and the wall-clock milliseconds that took (part of the batch, not of unc_mapper_last_timing) */
+void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms);
 /* mean lifetime of the persistent wavefronts of the last batch's k_map launch / the launch duration (both from the
  * device wall clock): 1.0 = every wavefront worked until the end, lower = idle tail behind the longest reads */
 double unc_mapper_last_wave_busy(const unc_mapper_t *m);

@@ -100,6 +100,8 @@ def load(path=None):
     L.unc_map_batch.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp, vp]
     L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
+    L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.unc_mapper_last_remap.restype = None
     L.unc_mapper_set_profile.argtypes = [vp, C.c_int]
     L.unc_mapper_set_profile.restype = None
     L.unc_mapper_last_wave_busy.argtypes = [vp]
@@ -269,6 +271,11 @@ class Mapper:
         a, b = C.c_float(), C.c_float()
         self.L.unc_mapper_last_timing(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def last_remap(self):
+        n, ms = C.c_uint32(), C.c_float()
+        self.L.unc_mapper_last_remap(self.h, C.byref(n), C.byref(ms))
+        return int(n.value), float(ms.value)
 
     def set_profile(self, on=True):
         self.L.unc_mapper_set_profile(self.h, 1 if on else 0)

@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <string>
+#include <chrono>
+#include <algorithm>
 #include <vector>
 
 #include "r94_model_table.h"
@@ -394,6 +396,12 @@ struct unc_mapper {
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
+    DevScratch big{};              // scratch with more seed-cluster room for the reads that outgrew a slot (kept between batches)
+    uint64_t big_cap = 0;
+    size_t big_slots = 0;
+    bool big_at_limit = false;     // big_slots is all the free HBM allowed
+    uint32_t remap_reads = 0;      // reads of the last batch that were mapped again with more room, and what that cost
+    float remap_ms = 0;
     uint32_t *d_next = nullptr;
     // per-batch buffers (grown on demand)
     int16_t *d_raw = nullptr; size_t raw_cap = 0;
@@ -451,6 +459,7 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     if (!m) return;
     (void)hipSetDevice(m->ix->device);
     free_scratch(m->sc);
+    free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
                     m->sched.ctl, m->sched.free_cells, m->sched.park_cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -660,27 +669,39 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         m->wave_busy = (grid && m->ms_map > 0 && khz > 0) ? (double)ticks / ((double)grid * (double)m->ms_map * (double)khz) : 0.0;
     }
     // The reference's SeedTracker is an unbounded std::set.  Reads whose seed clusters outgrew the per-slot array are
-    // mapped again, on the device, with 16x the room (a few slots only), until they fit.
+    // mapped again, on the device, with 16x the room, until they fit.  The larger scratch is sized so that every such
+    // read gets a wavefront at once (within a quarter of the free HBM) and is kept for the following batches.
     {
         std::vector<uint32_t> redo;
         for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) redo.push_back(i);
+        m->remap_reads = (uint32_t)redo.size();
+        m->remap_ms = 0;
+        const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
         while (!redo.empty() && cap < (1ull << 26)) {
             cap *= 16;
-            size_t slots = (size_t)(8ull << 30) / (cap * (4 * sizeof(ClusterKey) + sizeof(ClusterPay) + 2));
-            if (slots > redo.size()) slots = redo.size();
-            if (slots > 1024) slots = 1024;
-            if (slots == 0) slots = 1;
-            DevScratch big;
-            int rc2 = alloc_scratch(big, m->P, slots, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
-            if (rc2) { free_scratch(big); return rc2; }
+            const size_t want = std::min<size_t>(std::max<size_t>(redo.size(), 256), m->n_waves);
+            if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
+                free_scratch(m->big);
+                m->big_cap = 0; m->big_slots = 0;
+                size_t free_b = 0, total_b = 0;
+                HIPCHK(hipMemGetInfo(&free_b, &total_b));
+                const size_t per_slot = (size_t)m->P.max_paths * (2 * sizeof(PathRec) + 8 + 4 * sizeof(SortKey)) +
+                                        (size_t)m->sc.max_seed_paths * sizeof(SeedPath) + cap * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + (64 << 10);
+                const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
+                const size_t slots = std::min(want, fit);
+                int rc2 = alloc_scratch(m->big, m->P, slots, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
+                if (rc2) { free_scratch(m->big); return rc2; }
+                m->big_cap = cap; m->big_slots = slots; m->big_at_limit = slots == fit;
+            }
+            const size_t slots = std::min(m->big_slots, redo.size());
             uint32_t *d_list = nullptr;
             HIPCHK(hipMalloc((void **)&d_list, redo.size() * 4));
             HIPCHK(hipMemcpyAsync(d_list, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
             DevReads rd2 = rd;
             rd2.n_reads = (uint32_t)redo.size();
-            launch_map(m->ix->dev, big, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, d_list);
+            launch_map(m->ix->dev, m->big, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, d_list);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
             std::vector<uint32_t> still;
@@ -689,9 +710,9 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                 if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) still.push_back(i);
             }
             (void)hipFree(d_list);
-            free_scratch(big);
             redo.swap(still);
         }
+        m->remap_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_redo).count();
     }
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
@@ -711,6 +732,10 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
 
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
+extern "C" void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms) {
+    if (n_reads) *n_reads = m ? m->remap_reads : 0;
+    if (ms) *ms = m ? m->remap_ms : 0.0f;
+}
 
 extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
     if (ms_events) *ms_events = m->ms_events;
