@@ -233,6 +233,15 @@ def main():
     wave_busy = mapper.last_wave_busy()
     remap_n, remap_ms = mapper.last_remap()
     # phase shares come from one extra, untimed pass with the cycle-counting instantiation of k_map
+    # the boundary also takes host buffers (unc_map_batch on_device = 0): one extra, untimed step from pageable host
+    # memory gives the PCIe-inclusive rate (never `value`)
+    pcie = None
+    if rank == 0 and world == 1 and not a.no_profile_pass:
+        host_raw = sim["signal"].cpu().numpy()
+        t1 = time.perf_counter()
+        mapper.map_batch(host_raw, offsets, calib)
+        pcie = a.reads / (time.perf_counter() - t1)
+        del host_raw
     if not a.no_profile_pass:
         mapper.set_profile(True)
         mapper.map_batch_device(raw_ptr, offsets, calib, stream=stream)
@@ -268,6 +277,7 @@ def main():
                        "k_map_phase_cycle_share": phase_share,
                        "k_map_phase_cycle_share_source": "extra untimed pass, profiling instantiation of k_map",
                        "k_map_wave_busy": round(wave_busy, 4),
+                       "pcie_inclusive_reads_per_sec": pcie,
                        "remapped_reads": {"n": remap_n, "ms": round(remap_ms, 1),
                                           "note": "reads whose seed-cluster set outgrew its slot, mapped again with 16x the room (inside the step)"},
                        "reads_in_flight": mapper_slots(mapper)},

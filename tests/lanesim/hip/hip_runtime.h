@@ -166,22 +166,6 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     return __lanesim_shfl_abs(v, __lanesim_lane() ^ mask);
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __lanesim_shfl_abs(v, 0); }
-// v_mov_b32_dpp / update_dpp: quad_perm (ctrl < 0x100), row_shl:n (0x101..0x10F), row_shr:n (0x111..0x11F); lanes whose
-// bank (4 lanes, 4 banks per 16-lane row) is masked off, or whose source falls outside the row, keep `old`
-static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-    (void)bound_ctrl;
-    const int l = __lanesim_lane();
-    int sl = l;
-    bool valid = true;
-    if (ctrl < 0x100) sl = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
-    else if (ctrl >= 0x101 && ctrl <= 0x10F) { sl = l + (ctrl & 15); valid = (sl >> 4) == (l >> 4); }
-    else if (ctrl >= 0x111 && ctrl <= 0x11F) { sl = l - (ctrl & 15); valid = sl >= 0 && (sl >> 4) == (l >> 4); }
-    else if (ctrl == 0x140) sl = (l & ~15) | (15 - (l & 15));   // row_mirror
-    else if (ctrl == 0x141) sl = (l & ~7) | (7 - (l & 7));      // row_half_mirror
-    const int got = __lanesim_shfl_abs(src, valid ? sl : l);
-    const bool en = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
-    return (en && valid) ? got : old;
-}
 
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned acc) {
     int l = __lanesim_lane();

@@ -705,10 +705,6 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     uint32_t *const s_cdesc = s_pmeta + WAVE;
     uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
     uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
-#ifdef UNC_E4_COOP
-    __shared__ uint4 s_hdr0[WAVE], s_hdr1[WAVE];     // child headers on their way from the computing lane to the storing group
-    __shared__ float s_app[WAVE];
-#endif
     static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
 
     const int lane = lane_id();
@@ -965,7 +961,6 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 }
                 wave_sync();
                 PHASE_FINE(10);
-#ifndef UNC_E4_COOP
                 // one lane per child
                 for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
                     const uint32_t li = l0 + (uint32_t)lane;
@@ -1006,83 +1001,6 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                         gst(ukeys, gi << 4, key);
                     }
                 }
-#else
-                // (measured slower than the lane-per-child copy above: 8.30 s against 8.09 s per 50 k reads)
-                // Child records.  A 128-byte record moved by one lane costs the vector memory pipeline a cache-line request
-                // per 16 bytes; moved by eight neighbouring lanes (16 bytes each) it costs one per record.  So the parent
-                // records are fetched and the child records stored by groups of 8 lanes, round r serving children 8r + g,
-                // and only the header arithmetic runs one lane per child in between, through LDS.
-                for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
-                    const uint32_t nb = nwrite - l0 < WAVE ? nwrite - l0 : WAVE;
-                    const uint32_t g = (uint32_t)lane >> 3, j = (uint32_t)lane & 7u;
-                    uint4 piece[8];
-#pragma unroll
-                    for (uint32_t rr = 0; rr < 8; ++rr) {
-                        const uint32_t ch = 8u * rr + g;
-                        piece[rr] = make_uint4(0u, 0u, 0u, 0u);
-                        if (ch < nb) {
-                            const uint32_t pl = s_cdesc[l0 + ch] & 63u;
-                            piece[rr] = reinterpret_cast<const uint4 *>(par + s_pphys[pl])[j];
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t rr = 0; rr < 8; ++rr) {
-                        const uint32_t ch = 8u * rr + g;
-                        if (ch < nb && j >= 2u) {
-                            // prob sums i = 4 (j - 2) .. + 3 sit in this lane's piece: hand over the two the child needs
-                            const uint32_t pmt = s_pmeta[s_cdesc[l0 + ch] & 63u];
-                            const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
-                            uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
-                            uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
-                            const uint4 v = piece[rr];
-                            if ((sl >> 2) == j - 2u) s_hdr0[ch].x = (sl & 2u) ? ((sl & 1u) ? v.w : v.z) : ((sl & 1u) ? v.y : v.x);
-                            if ((s2 >> 2) == j - 2u) s_hdr0[ch].y = (s2 & 2u) ? ((s2 & 1u) ? v.w : v.z) : ((s2 & 1u) ? v.y : v.x);
-                        }
-                    }
-                    wave_sync();
-                    if ((uint32_t)lane < nb) {
-                        const uint32_t li = l0 + (uint32_t)lane;
-                        const uint32_t d = s_cdesc[li];
-                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
-                        const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
-                        const float last = __uint_as_float(s_hdr0[lane].x), second = __uint_as_float(s_hdr0[lane].y);
-                        const uint32_t pk = pmt & META_KMER_MASK;
-                        uint64_t cs, ce;
-                        uint32_t ck, mv;
-                        if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
-                        else {
-                            const uint64_t pr = s_res[ci];
-                            cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
-                            ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
-                        }
-                        if (klb && cs == ce && (cs == ix.kmer_ranges[2 * ck] || cs == ix.kmer_ranges[2 * ck + 1])) bchild = true;
-                        SortKey key;
-                        const uint32_t gi = nchild + li;
-                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
-                        s_hdr0[lane] = make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32));
-                        s_hdr1[lane] = make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, c.wslot);   // .w: slot, stored as 0
-                        s_app[lane] = c.appended;
-                        ukeys[gi] = key;
-                    }
-                    wave_sync();
-#pragma unroll
-                    for (uint32_t rr = 0; rr < 8; ++rr) {
-                        const uint32_t ch = 8u * rr + g;
-                        if (ch < nb) {
-                            uint4 v = piece[rr];
-                            const uint4 h1 = s_hdr1[ch];
-                            if (j == 0u) v = s_hdr0[ch];
-                            else if (j == 1u) v = make_uint4(h1.x, h1.y, h1.z, 0u);
-                            else if ((h1.w >> 2) == j - 2u) {
-                                const uint32_t a = __float_as_uint(s_app[ch]), e = h1.w & 3u;
-                                if (e == 0u) v.x = a; else if (e == 1u) v.y = a; else if (e == 2u) v.z = a; else v.w = a;
-                            }
-                            reinterpret_cast<uint4 *>(chd + nchild + l0 + ch)[j] = v;
-                        }
-                    }
-                    wave_sync();
-                }
-#endif
                 nchild += nwrite;
                 wave_sync();
                 PHASE_FINE(11);

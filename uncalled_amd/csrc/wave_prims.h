@@ -97,46 +97,10 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 
 // Streaming (write-once / read-once) traffic such as the path records: keep it from evicting the FM index
 // out of the XCD's L2.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// Value of lane (lane ^ D).  Distances 1 and 2 stay inside a quad (one DPP move per dword), 4 and 8 inside a 16-lane
-// row (two bank-masked DPP row shifts per dword); none of them touches the LDS crossbar or needs a wait, unlike
-// ds_bpermute, which serves the distances 16 and 32.
-template <int D> __device__ __forceinline__ uint32_t xor_lane32(uint32_t v) {
-    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    else if constexpr (D == 4) {
-        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);        // banks 0,2 <- lane + 4
-        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);     // banks 1,3 <- lane - 4
-    } else if constexpr (D == 8) {
-        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0x3, false);        // banks 0,1 <- lane + 8
-        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xF, 0xC, false);     // banks 2,3 <- lane - 8
-    } else if constexpr (D == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
-    else if constexpr (D == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);    // row_half_mirror
-    else if constexpr (D == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
-    else return (uint32_t)__shfl_xor((int)v, D);
-}
-template <int D> __device__ __forceinline__ uint64_t xor_lane64(uint64_t v) {
-    return ((uint64_t)xor_lane32<D>((uint32_t)(v >> 32)) << 32) | xor_lane32<D>((uint32_t)v);
-}
-// runtime distance (uniform).  Dispatching to the DPP forms measured SLOWER than plain ds_bpermute in the sort
-// networks (8.32 s against 8.04 s per 50 k reads: the five-way branch per stage and the DPP wait states cost more than
-// the LDS crossbar trips they save), so the dispatch is off unless UNC_DPP_SORT is defined.
+// Value of lane (lane ^ d), d uniform.  (DPP forms of the short distances were tried in the sort networks and measured
+// slower than ds_bpermute there: the per-stage dispatch on d and the DPP wait states cost more than the crossbar trips.)
 __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
-#ifndef UNC_DPP_SORT
     return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
-#endif
-    switch (d) {
-        case 1: return xor_lane64<1>(v);
-        case 2: return xor_lane64<2>(v);
-#ifndef UNC_DPP_QUAD_ONLY
-        case 4: return xor_lane64<4>(v);
-        case 8: return xor_lane64<8>(v);
-#endif
-        case 3: return xor_lane64<3>(v);
-        case 7: return xor_lane64<7>(v);
-        case 15: return xor_lane64<15>(v);
-        default: return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
-    }
 }
 
 // Global access as (uniform base, 32-bit byte offset): lets the compiler address with an SGPR base plus one VGPR
@@ -147,18 +111,6 @@ template <class T> __device__ __forceinline__ T gld(const void *base, uint32_t o
 }
 template <class T> __device__ __forceinline__ void gst(void *base, uint32_t off, const T &v) {
     *reinterpret_cast<T *>(static_cast<char *>(base) + off) = v;
-}
-
-__device__ __forceinline__ void nt_store(uint4 *p, uint4 v) {
-    u32x4 w;
-    __builtin_memcpy(&w, &v, 16);
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));   // global_store_dwordx4 ... nt
-}
-__device__ __forceinline__ uint4 nt_load(const uint4 *p) {
-    const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));   // global_load_dwordx4 ... nt
-    uint4 v;
-    __builtin_memcpy(&v, &w, 16);
-    return v;
 }
 
 }  // namespace unc
