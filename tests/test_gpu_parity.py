@@ -152,3 +152,8 @@ def test_chr20_scale_batch(hip_lib, oracle_lib, chr20):
 @pytest.mark.parametrize("max_paths,slice_events,n_slots,n_waves", [(10000, 37, 5, 2), (300, 11, 3, 1), (10000, 200, 9, 4)])
 def test_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves):
     pc.case_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves)
+
+
+@pytest.mark.parametrize("n_big,n_waves", [(2, 2), (1, 1)])
+def test_big_cluster_buffers(hip_lib, oracle_lib, example, goldens, n_big, n_waves):
+    pc.case_big_cluster_buffers(hip_lib, oracle_lib, example, goldens, n_big, n_waves)

@@ -53,3 +53,8 @@ def test_wide_sort_keys(sim_lib, oracle_lib, example, goldens, monkeypatch):
 @pytest.mark.parametrize("max_paths,slice_events,n_slots,n_waves", [(10000, 37, 5, 2), (300, 11, 3, 1)])
 def test_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves):
     pc.case_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves, n_reads=8)
+
+
+@pytest.mark.parametrize("n_big,n_waves", [(2, 2), (1, 1)])
+def test_big_cluster_buffers(sim_lib, oracle_lib, example, goldens, n_big, n_waves):
+    pc.case_big_cluster_buffers(sim_lib, oracle_lib, example, goldens, n_big, n_waves, n_reads=8)

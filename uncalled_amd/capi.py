@@ -32,7 +32,7 @@ class Params(C.Structure):
 
 class MapperOpts(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
-                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32)]
+                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("n_big", C.c_uint32), ("big_clusters", C.c_uint32)]
 
 
 CALIB = np.dtype([("range", "<f4"), ("offset", "<f4"), ("digitisation", "<f4")])
@@ -226,11 +226,12 @@ def hit_paf_cols(h, names):
 class Mapper:
     """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
 
-    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0):
+    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0, n_big=0,
+                 big_clusters=0):
         self.index = index
         self.L = index.L
         self.params = params or default_params(self.L)
-        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, n_big, big_clusters)
         h = C.c_void_p()
         _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
         self.h = h

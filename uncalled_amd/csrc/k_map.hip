@@ -43,6 +43,7 @@ struct MapArgs {
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
     DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
+    DevBig big;                 // batch mode with big.n_big != 0: larger seed-cluster buffers on demand
 };
 
 // ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
@@ -762,13 +763,23 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         SortKey *const skeys = ukeys + A.sc.keys_cap;
         SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
         uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
-        TrackerMem TM;
-        TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
-        TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
-        TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
-        TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
-        TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
         SlotState *const st = A.sc.state + slot;
+        uint32_t big = restore ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
+        TrackerMem TM;
+        if (big) {
+            const uint32_t bi = big - 1u;
+            TM.max_leaves = A.big.max_clusters / 16; TM.max_pay = A.big.max_clusters;
+            TM.leaves = A.big.keys + (size_t)bi * TM.max_leaves * LEAF;
+            TM.dir = A.big.dir + (size_t)bi * TM.max_leaves;
+            TM.cnt = A.big.cnt + (size_t)bi * TM.max_leaves;
+            TM.pay = A.big.pay + (size_t)bi * A.big.max_clusters;
+        } else {
+            TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
+            TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
+            TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
+            TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
+            TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
+        }
 
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if ((A.resume && !fresh) || restore) {
@@ -813,6 +824,29 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
             if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
+            // seed-cluster buffer three quarters full: move into a larger one (DevBig) before the next event
+            if (A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
+                uint32_t id = SCHED_EMPTY;
+                if (lane == 0) id = sched_pop(A.big.q, A.big.cells, A.big.cap_mask);
+                id = bcast32(id, 0);
+                if (id != SCHED_EMPTY) {
+                    TrackerMem B;
+                    B.max_leaves = A.big.max_clusters / 16; B.max_pay = A.big.max_clusters;
+                    B.leaves = A.big.keys + (size_t)id * B.max_leaves * LEAF;
+                    B.dir = A.big.dir + (size_t)id * B.max_leaves;
+                    B.cnt = A.big.cnt + (size_t)id * B.max_leaves;
+                    B.pay = A.big.pay + (size_t)id * A.big.max_clusters;
+                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc * LEAF; i += WAVE) B.leaves[i] = TM.leaves[i];
+                    for (uint32_t i = (uint32_t)lane; i < T.n_leaves; i += WAVE) B.dir[i] = TM.dir[i];
+                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc; i += WAVE) B.cnt[i] = TM.cnt[i];
+                    for (uint32_t i = (uint32_t)lane; i < T.n_pay; i += WAVE) B.pay[i] = TM.pay[i];
+                    TM = B;
+                    big = id + 1u;
+                    wave_sync();
+                } else if (sliced && (T.n_pay * 16u >= TM.max_pay * 15u || T.n_alloc * 16u >= TM.max_leaves * 15u)) {
+                    break;   // none free and hardly any room left: wait parked, the owners hand theirs back when done
+                }
+            }
             ++steps;
 
             // ---------------- P: match log-probs ----------------
@@ -1283,12 +1317,16 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
+        if (done && big) {   // hand the larger seed-cluster buffer back
+            if (lane == 0) sched_push(A.big.q, A.big.cells, A.big.cap_mask, big - 1u);
+            big = 0;
+        }
         if (A.resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
                 st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
-                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
+                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc; st->big_id = big;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
             }
@@ -1315,8 +1353,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile) {
+                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big) {
     MapArgs a;
+    if (big) a.big = *big; else a.big = DevBig{};
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
@@ -1342,6 +1381,24 @@ __global__ void k_sched_init(DevSched S) {
 void launch_sched_init(const DevSched &S, hipStream_t st) {
     const uint32_t cap = S.cap_mask + 1u;
     hipLaunchKernelGGL(k_sched_init, dim3((cap + 255) / 256), dim3(256), 0, st, S);
+}
+// every larger seed-cluster buffer free
+__global__ void k_big_init(DevBig B) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = B.cap_mask + 1u;
+    if (i < cap) {
+        SchedCell f; f.seq = i < B.n_big ? i + 1u : i; f.val = i;
+        B.cells[i] = f;
+    }
+    if (i == 0) {
+        SchedQueue q;
+        memset(&q, 0, sizeof q);
+        q.tail = B.n_big;
+        *B.q = q;
+    }
+}
+void launch_big_init(const DevBig &B, hipStream_t st) {
+    const uint32_t cap = B.cap_mask + 1u;
+    hipLaunchKernelGGL(k_big_init, dim3((cap + 255) / 256), dim3(256), 0, st, B);
 }
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
 // register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.

@@ -58,7 +58,8 @@ struct alignas(16) SlotState {
     uint32_t cur;            // which of the two path buffers holds the parents
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
-    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2, n_leaves, n_alloc, pad0;
+    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2, n_leaves, n_alloc;
+    uint32_t big_id;         // 0, or 1 + the larger seed-cluster buffer this read has moved into (DevBig)
     float len_sum;
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
@@ -77,6 +78,19 @@ struct alignas(64) SchedCtl {
     uint32_t next_read, pad0[15];
     SchedQueue freeq, parkq;
 };
+// Larger seed-cluster buffers for the reads that fill the one of their slot (off-target reads on a large reference collect
+// tens of thousands of clusters).  A read moves into a free one at an event boundary when its slot's buffer is three
+// quarters full and hands it back when it is done; ids travel through a ring like the slots'.  When none is free, a
+// time-sliced read waits parked; otherwise it carries on and, should it overflow after all, is re-mapped by the host.
+struct DevBig {
+    ClusterKey *keys, *dir;      // [n_big][max_clusters / 16][64], [n_big][max_clusters / 16]
+    uint32_t *cnt;               // [n_big][max_clusters / 16]
+    ClusterPay *pay;             // [n_big][max_clusters]
+    SchedQueue *q;
+    SchedCell *cells;
+    uint32_t cap_mask, n_big, max_clusters, pad;
+};
+
 struct DevSched {
     SchedCtl *ctl;           // null: scheduler off (one slot per wavefront)
     SchedCell *free_cells, *park_cells;   // [cap] each

@@ -396,6 +396,7 @@ struct unc_mapper {
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
+    DevBig bigbuf{};               // larger seed-cluster buffers handed out by k_map (n_big = 0: none)
     DevScratch big{};              // scratch with more seed-cluster room for the reads that outgrew a slot (kept between batches)
     uint64_t big_cap = 0;
     size_t big_slots = 0;
@@ -461,7 +462,8 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     free_scratch(m->sc);
     free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
-                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells};
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells,
+                    m->bigbuf.keys, m->bigbuf.dir, m->bigbuf.cnt, m->bigbuf.pay, m->bigbuf.q, m->bigbuf.cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -513,6 +515,34 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
+    {
+        // larger seed-cluster buffers: a quarter of what is left of the HBM, at most one per wavefront
+        uint32_t n_big = opts ? opts->n_big : 0;
+        const uint64_t bc = (opts && opts->big_clusters) ? opts->big_clusters : 16ull * mcl;
+        if (n_big != 0xFFFFFFFFu && bc <= (1ull << 26)) {
+            const size_t per_big = (size_t)bc * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + 64;
+            if (n_big == 0) {
+                size_t free_b = 0, total_b = 0;
+                HIPCHK(hipMemGetInfo(&free_b, &total_b));
+                n_big = (uint32_t)std::min<size_t>(n_waves, free_b / 4 / per_big);
+                if (n_slots <= n_waves || n_big < 8) n_big = 0;     // small mappers (tests, traces) re-map instead
+            }
+            if (n_big) {
+                uint32_t cap = 64;
+                while (cap < n_big) cap <<= 1;
+                DevBig &B = m->bigbuf;
+                B.cap_mask = cap - 1; B.n_big = n_big; B.max_clusters = (uint32_t)bc;
+                const size_t leaves = (size_t)(bc / 16);
+                HIPCHK(hipMalloc((void **)&B.keys, (size_t)n_big * leaves * 64 * sizeof(ClusterKey)));
+                HIPCHK(hipMalloc((void **)&B.dir, (size_t)n_big * leaves * sizeof(ClusterKey)));
+                HIPCHK(hipMalloc((void **)&B.cnt, (size_t)n_big * leaves * 4));
+                HIPCHK(hipMalloc((void **)&B.pay, (size_t)n_big * bc * sizeof(ClusterPay)));
+                HIPCHK(hipMalloc((void **)&B.q, sizeof(SchedQueue)));
+                HIPCHK(hipMalloc((void **)&B.cells, (size_t)cap * sizeof(SchedCell)));
+                bytes += (size_t)n_big * per_big + (size_t)cap * sizeof(SchedCell);
+            }
+        }
+    }
     if (n_slots > n_waves) {
         uint32_t cap = 64;
         while (cap < n_slots) cap <<= 1;
@@ -650,8 +680,10 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     const uint32_t grid = n_reads < m->n_waves ? n_reads : m->n_waves;
     const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
     if (sliced) launch_sched_init(m->sched, st);
+    if (m->bigbuf.n_big) launch_big_init(m->bigbuf, st);
     launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
-               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile);
+               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile,
+               m->bigbuf.n_big ? &m->bigbuf : nullptr);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
