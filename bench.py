@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("UNC_BENCH_READS", 50000)),
                     help="reads per GPU per step (config: E. coli 4.6 Mb ref, 50k synthetic r9.4.1 reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-big", type=int, default=0, help="larger seed-cluster buffers (0 = library default)")
+    ap.add_argument("--big-clusters", type=int, default=0, help="clusters per larger buffer (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed pass that collects phase cycle shares")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "realtime"], default="ecoli")
     ap.add_argument("--channels", type=int, default=512)
@@ -202,7 +204,7 @@ def main():
         if rank == 0:
             print(json.dumps(out))
         return
-    mapper = capi.Mapper(ix)
+    mapper = capi.Mapper(ix, n_big=a.n_big, big_clusters=a.big_clusters)
     # this rank's shard of the read set: reads are independent units, sharded by rank with distinct seeds
     sim = simulate_reads_torch(codes, lens, a.reads, seed=42 + rank, device=f"cuda:{local_rank}")
     offsets = sim["offsets"]

@@ -158,7 +158,7 @@ typedef struct {
     uint32_t n_waves;        /* resident wavefronts of the persistent k_map grid (0 = 12 per CU) */
     uint32_t n_big;          /* larger seed-cluster buffers, handed to the reads that fill their slot's (0 = as many as a
                               * quarter of the remaining HBM holds, at most n_waves; 0xFFFFFFFF = none) */
-    uint32_t big_clusters;   /* seed clusters per larger buffer (0 = 16 x max_clusters) */
+    uint32_t big_clusters;   /* seed clusters per larger buffer (0 = 4 x max_clusters) */
 } unc_mapper_opts_t;
 
 int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out);

@@ -516,9 +516,10 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     {
-        // larger seed-cluster buffers: a quarter of what is left of the HBM, at most one per wavefront
+        // larger seed-cluster buffers (4x a slot's; 2x / 8x / 16x measured worse on the 400 Mb reference): a quarter of
+        // what is left of the HBM, at most one per wavefront
         uint32_t n_big = opts ? opts->n_big : 0;
-        const uint64_t bc = (opts && opts->big_clusters) ? opts->big_clusters : 16ull * mcl;
+        const uint64_t bc = (opts && opts->big_clusters) ? opts->big_clusters : 4ull * mcl;
         if (n_big != 0xFFFFFFFFu && bc <= (1ull << 26)) {
             const size_t per_big = (size_t)bc * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + 64;
             if (n_big == 0) {
