@@ -156,8 +156,9 @@ typedef struct {
     uint32_t slice_events;   /* with n_slots > n_waves a wavefront parks a read after this many events and takes the
                               * next task (a new read while a slot is free, else the longest-parked read); 0 = 1024 */
     uint32_t n_waves;        /* resident wavefronts of the persistent k_map grid (0 = 12 per CU) */
-    uint32_t n_big;          /* larger seed-cluster buffers, handed to the reads that fill their slot's (0 = as many as a
-                              * quarter of the remaining HBM holds, at most n_waves; 0xFFFFFFFF = none) */
+    uint32_t n_big;          /* larger seed-cluster buffers, handed to the reads that fill their slot's (0 = none for references below 2^28
+                              * index rows, else as many as a quarter of the remaining HBM holds, at most n_waves;
+                              * 0xFFFFFFFF = none) */
     uint32_t big_clusters;   /* seed clusters per larger buffer (0 = 4 x max_clusters) */
 } unc_mapper_opts_t;
 

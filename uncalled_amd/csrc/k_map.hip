@@ -692,7 +692,9 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 #define UNC_LB 3
 #endif
 // PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
-template <bool PROF>
+// BIG: the code that moves reads into larger seed-cluster buffers (DevBig); kept out of the plain instantiation, whose
+// register allocation it would otherwise disturb (5 % on the E. coli workload)
+template <bool PROF, bool BIG>
 __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
@@ -764,9 +766,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
         uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
         SlotState *const st = A.sc.state + slot;
-        uint32_t big = restore ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
+        uint32_t big = (BIG && restore) ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
         TrackerMem TM;
-        if (big) {
+        if (BIG && big) {
             const uint32_t bi = big - 1u;
             TM.max_leaves = A.big.max_clusters / 16; TM.max_pay = A.big.max_clusters;
             TM.leaves = A.big.keys + (size_t)bi * TM.max_leaves * LEAF;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
             // seed-cluster buffer three quarters full: move into a larger one (DevBig) before the next event
-            if (A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
+            if (BIG && A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
                 uint32_t id = SCHED_EMPTY;
                 if (lane == 0) id = sched_pop(A.big.q, A.big.cells, A.big.cap_mask);
                 id = bcast32(id, 0);
@@ -1317,7 +1319,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
-        if (done && big) {   // hand the larger seed-cluster buffer back
+        if (BIG && done && big) {   // hand the larger seed-cluster buffer back
             if (lane == 0) sched_push(A.big.q, A.big.cells, A.big.cap_mask, big - 1u);
             big = 0;
         }
@@ -1326,7 +1328,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
                 st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
-                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc; st->big_id = big;
+                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc; st->big_id = BIG ? big : 0u;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
             }
@@ -1359,8 +1361,11 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
-    if (profile) hipLaunchKernelGGL(k_map<true>, dim3(grid), dim3(WAVE), 0, st, a);
-    else hipLaunchKernelGGL(k_map<false>, dim3(grid), dim3(WAVE), 0, st, a);
+    const bool bigk = a.big.n_big != 0;
+    if (profile && bigk) hipLaunchKernelGGL((k_map<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (profile) hipLaunchKernelGGL((k_map<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (bigk) hipLaunchKernelGGL((k_map<false, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL((k_map<false, false>), dim3(grid), dim3(WAVE), 0, st, a);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {
