@@ -25,12 +25,25 @@
 #include "unc_dev_types.h"
 #include "wave_prims.h"
 
+// This file is compiled twice (see k_map_big.hip): plain, and with UNC_BIG, which adds the code that moves reads into
+// larger seed-cluster buffers (DevBig).  Two translation units rather than one template parameter: whatever is added to
+// the plain kernel, even dead, moves its register allocation (measured: 4-5 % on the E. coli workload).
+#ifdef UNC_BIG
+#define UNC_KMAP k_map_big
+#define UNC_MAPARGS MapArgsBig
+#define UNC_LAUNCH launch_map_big
+#else
+#define UNC_KMAP k_map
+#define UNC_MAPARGS MapArgs
+#define UNC_LAUNCH launch_map_plain
+#endif
+
 namespace unc {
 
 constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
 constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
 
-struct MapArgs {
+struct UNC_MAPARGS {
     DevIndex ix;
     DevScratch sc;
     DevReads rd;
@@ -43,7 +56,9 @@ struct MapArgs {
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
     DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
-    DevBig big;                 // batch mode with big.n_big != 0: larger seed-cluster buffers on demand
+#ifdef UNC_BIG
+    DevBig big;                 // batch mode: larger seed-cluster buffers on demand
+#endif
 };
 
 // ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
@@ -94,14 +109,14 @@ struct TrackerMem {
 };
 
 #ifdef UNC_NOINLINE_SORT
-#define UNC_SORT_FN __device__ __noinline__
+#define UNC_SORT_FN static __device__ __noinline__
 #else
-#define UNC_SORT_FN __device__
+#define UNC_SORT_FN static __device__
 #endif
 #ifdef UNC_NOINLINE_SEED
-#define UNC_SEED_FN __device__ __noinline__
+#define UNC_SEED_FN static __device__ __noinline__
 #else
-#define UNC_SEED_FN __device__
+#define UNC_SEED_FN static __device__
 #endif
 __device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
     // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
@@ -692,10 +707,8 @@ __device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t 
 #define UNC_LB 3
 #endif
 // PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
-// BIG: the code that moves reads into larger seed-cluster buffers (DevBig); kept out of the plain instantiation, whose
-// register allocation it would otherwise disturb (5 % on the E. coli workload)
-template <bool PROF, bool BIG>
-__global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
+template <bool PROF>
+__global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
     // one carved buffer for the per-pass staging of phase E (5.5 KB), reused as the source list in phase F: with the
@@ -766,22 +779,23 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
         SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
         uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
         SlotState *const st = A.sc.state + slot;
-        uint32_t big = (BIG && restore) ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
         TrackerMem TM;
-        if (BIG && big) {
+        TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
+        TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
+        TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
+        TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
+        TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
+#ifdef UNC_BIG
+        uint32_t big = restore ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
+        if (big) {
             const uint32_t bi = big - 1u;
             TM.max_leaves = A.big.max_clusters / 16; TM.max_pay = A.big.max_clusters;
             TM.leaves = A.big.keys + (size_t)bi * TM.max_leaves * LEAF;
             TM.dir = A.big.dir + (size_t)bi * TM.max_leaves;
             TM.cnt = A.big.cnt + (size_t)bi * TM.max_leaves;
             TM.pay = A.big.pay + (size_t)bi * A.big.max_clusters;
-        } else {
-            TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
-            TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
-            TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
-            TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
-            TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
         }
+#endif
 
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if ((A.resume && !fresh) || restore) {
@@ -826,8 +840,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
             if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
+#ifdef UNC_BIG
             // seed-cluster buffer three quarters full: move into a larger one (DevBig) before the next event
-            if (BIG && A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
+            if (A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
                 uint32_t id = SCHED_EMPTY;
                 if (lane == 0) id = sched_pop(A.big.q, A.big.cells, A.big.cap_mask);
                 id = bcast32(id, 0);
@@ -849,6 +864,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
                     break;   // none free and hardly any room left: wait parked, the owners hand theirs back when done
                 }
             }
+#endif
             ++steps;
 
             // ---------------- P: match log-probs ----------------
@@ -1319,16 +1335,21 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
-        if (BIG && done && big) {   // hand the larger seed-cluster buffer back
+#ifdef UNC_BIG
+        if (done && big) {   // hand the larger seed-cluster buffer back
             if (lane == 0) sched_push(A.big.q, A.big.cells, A.big.cap_mask, big - 1u);
             big = 0;
         }
+#endif
         if (A.resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
                 st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
-                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc; st->big_id = BIG ? big : 0u;
+                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
+#ifdef UNC_BIG
+                st->big_id = big;
+#endif
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
             }
@@ -1353,19 +1374,27 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs A) {
 
 #include "unc_kernels.h"
 namespace unc {
-void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
+void UNC_LAUNCH(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
                 const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big) {
-    MapArgs a;
-    if (big) a.big = *big; else a.big = DevBig{};
+    UNC_MAPARGS a;
+#ifdef UNC_BIG
+    a.big = *big;
+#else
+    (void)big;
+#endif
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
-    const bool bigk = a.big.n_big != 0;
-    if (profile && bigk) hipLaunchKernelGGL((k_map<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
-    else if (profile) hipLaunchKernelGGL((k_map<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
-    else if (bigk) hipLaunchKernelGGL((k_map<false, true>), dim3(grid), dim3(WAVE), 0, st, a);
-    else hipLaunchKernelGGL((k_map<false, false>), dim3(grid), dim3(WAVE), 0, st, a);
+    if (profile) hipLaunchKernelGGL(UNC_KMAP<true>, dim3(grid), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL(UNC_KMAP<false>, dim3(grid), dim3(WAVE), 0, st, a);
+}
+#ifndef UNC_BIG
+void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
+                uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
+                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big) {
+    if (big && big->n_big) launch_map_big(ix, sc, rd, P, results, next_read, max_steps, resume, slot_map, grid, st, read_list, wave_ticks, sched, profile, big);
+    else launch_map_plain(ix, sc, rd, P, results, next_read, max_steps, resume, slot_map, grid, st, read_list, wave_ticks, sched, profile, big);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {
@@ -1408,4 +1437,5 @@ void launch_big_init(const DevBig &B, hipStream_t st) {
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
 // register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.
 uint32_t map_kernel_waves_per_cu() { return 4 * UNC_LB; }
+#endif
 }  // namespace unc
