@@ -55,9 +55,11 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
 
 
 def mapper_slots(mapper):
-    """slots (reads in flight) / resident wavefronts / slice length of the time-sliced k_map scheduler"""
-    return {"note": "k_map parks a read after `slice_events` events while more reads than wavefronts are in flight",
-            "default": "4 x wavefronts slots, 1024-event slices"}
+    """resident wavefronts / reads in flight / slice length / larger seed-cluster buffers of the k_map scheduler"""
+    try:
+        return mapper.geometry()
+    except Exception as e:      # never let a diagnostic field break the bench line
+        return {"error": repr(e)}
 
 
 def algorithmic_bytes(hits, offsets):

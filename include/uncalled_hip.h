@@ -181,6 +181,9 @@ int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
 /* the counters above are collected only by batches mapped while profiling is on (off by default: the counting
  * instantiation of k_map is about 2 % slower) */
 void unc_mapper_set_profile(unc_mapper_t *m, int on);
+/* what unc_mapper_create settled on: [0] resident wavefronts, [1] reads in flight (slots), [2] events per time slice
+ * (0: one read per wavefront until it is done), [3] larger seed-cluster buffers, [4] clusters in each of them */
+void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5);
 /* reads of the last batch whose seed-cluster set outgrew its slot and that were mapped again with 16x (256x ..) the
  * room, and the wall-clock milliseconds that took (part of the batch, not of unc_mapper_last_timing) */
 void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms);

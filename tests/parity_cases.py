@@ -260,6 +260,7 @@ def case_big_cluster_buffers(lib, oracle_lib, example, goldens, n_big=2, n_waves
     off = off_all[:n_reads + 1].copy()
     cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     m = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, max_clusters=64, n_big=n_big, big_clusters=4096)
+    assert m.geometry() == dict(n_waves=n_waves, n_slots=3 * n_waves, slice_events=60, n_big=n_big, big_clusters=4096)
     hits = m.map_batch(raw, off, cal)
     assert m.last_remap()[0] == 0
     oix = oracle_lib.Index(example["prefix"])

@@ -102,6 +102,8 @@ def load(path=None):
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.unc_mapper_last_remap.restype = None
+    L.unc_mapper_geometry.argtypes = [vp, vp]
+    L.unc_mapper_geometry.restype = None
     L.unc_mapper_set_profile.argtypes = [vp, C.c_int]
     L.unc_mapper_set_profile.restype = None
     L.unc_mapper_last_wave_busy.argtypes = [vp]
@@ -277,6 +279,11 @@ class Mapper:
         n, ms = C.c_uint32(), C.c_float()
         self.L.unc_mapper_last_remap(self.h, C.byref(n), C.byref(ms))
         return int(n.value), float(ms.value)
+
+    def geometry(self):
+        out = np.zeros(5, dtype=np.uint32)
+        self.L.unc_mapper_geometry(self.h, out.ctypes.data)
+        return dict(zip(("n_waves", "n_slots", "slice_events", "n_big", "big_clusters"), (int(x) for x in out)))
 
     def set_profile(self, on=True):
         self.L.unc_mapper_set_profile(self.h, 1 if on else 0)

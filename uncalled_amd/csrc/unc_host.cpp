@@ -767,6 +767,10 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
 
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
+extern "C" void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5) {
+    out5[0] = m->n_waves; out5[1] = m->n_slots; out5[2] = m->sched.ctl ? m->slice_events : 0u;
+    out5[3] = m->bigbuf.n_big; out5[4] = m->bigbuf.max_clusters;
+}
 extern "C" void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms) {
     if (n_reads) *n_reads = m ? m->remap_reads : 0;
     if (ms) *ms = m ? m->remap_ms : 0.0f;
