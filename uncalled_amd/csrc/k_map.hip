@@ -714,14 +714,28 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     // one carved buffer for the per-pass staging of phase E (5.5 KB), reused as the source list in phase F: with the
     // probs table the wavefront stays under 10 KB of LDS, i.e. 16 wavefronts per CU fit the 160 KB
     constexpr int RES_BITS = 30;                       // packed FM result: start << 30 | row count (0 = empty range)
+#ifndef UNC_E_OVERLAP
     __shared__ uint64_t s_e[CAND_MAX + 2 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4];
     uint64_t *const s_res = s_e;
     uint64_t *const s_pstart = s_e + CAND_MAX, *const s_pend = s_pstart + WAVE;
     uint32_t *const s_pphys = reinterpret_cast<uint32_t *>(s_pend + WAVE), *const s_pmoves = s_pphys + WAVE, *const s_pmeta = s_pmoves + WAVE;
     uint32_t *const s_cdesc = s_pmeta + WAVE;
     uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
+#else
+    __shared__ uint64_t s_e[NKMER / 2];                // results | child descriptors | candidates (per-parent staging: o_* below)
+    uint64_t *const s_res = s_e;
+    uint32_t *const s_cdesc = reinterpret_cast<uint32_t *>(s_e + CAND_MAX);
+    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
+    static_assert(CAND_MAX * 8 + CHILD_MAX * 4 + CAND_MAX * 2 <= NKMER * 4, "staging must fit");
+#endif
     uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
     static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
+#ifdef UNC_E_OVERLAP
+    // experiment (off by default, not yet measured on the GPU): the FM loads of pass i are in flight while the children of
+    // pass i - 1 are written, so the per-parent staging of two passes is alive at once
+    __shared__ uint64_t o_pstart[2][WAVE], o_pend[2][WAVE];
+    __shared__ uint32_t o_pphys[2][WAVE], o_pmoves[2][WAVE], o_pmeta[2][WAVE], o_pprob[2][WAVE];
+#endif
 
     const int lane = lane_id();
     const uint64_t wave_t0 = (uint64_t)wall_clock64();
@@ -903,6 +917,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             if ((uint32_t)lane < n_parents) {
                 q0c = gld<uint4>(par, phys_cur << 7); q1c = gld<uint4>(par, (phys_cur << 7) + 16u);
             }
+#ifndef UNC_E_OVERLAP
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
                 const uint32_t pi = base + (uint32_t)lane;
                 const bool have = pi < n_parents;
@@ -1057,6 +1072,186 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 wave_sync();
                 PHASE_FINE(11);
             }
+#else
+            // children of a finished pass: one lane per child (shared by both loop forms below through the macro-free lambda)
+            uint32_t pend_n = 0, pend_base = 0, pend_buf = 0;
+            auto emit_children = [&](uint32_t nwr, uint32_t cbase, uint32_t pb) {
+                for (uint32_t l0 = 0; l0 < nwr; l0 += WAVE) {
+                    const uint32_t li = l0 + (uint32_t)lane;
+                    if (li < nwr) {
+                        const uint32_t d = s_cdesc[li];
+                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
+                        const uint32_t po = o_pphys[pb][pl] << 7;
+                        const uint32_t pmt = o_pmeta[pb][pl], pmv = o_pmoves[pb][pl];
+                        const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
+                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
+                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
+                        uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
+                        uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
+                        const float last = gld<float>(par, po + 32u + (sl << 2)), second = gld<float>(par, po + 32u + (s2 << 2));
+                        const uint32_t pk = pmt & META_KMER_MASK;
+                        uint64_t cs, ce;
+                        uint32_t ck, mv;
+                        if (type == 0) { cs = o_pstart[pb][pl]; ce = o_pend[pb][pl]; ck = pk; mv = 0; }
+                        else {
+                            const uint64_t pr = s_res[ci];
+                            cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
+                            ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
+                        }
+                        if (klb && cs == ce) {
+                            const ulonglong2 kr = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[ck];
+                            if (cs == kr.x || cs == kr.y) bchild = true;
+                        }
+                        SortKey key;
+                        const uint32_t gi = cbase + li;
+                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
+                        const uint32_t co = gi << 7;
+                        gst(chd, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
+                        gst(chd, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
+                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
+                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
+                        gst(chd, co + 32u + (c.wslot << 2), c.appended);
+                        gst(ukeys, gi << 4, key);
+                    }
+                }
+            };
+            uint32_t obuf = 0;
+            for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
+                const uint32_t pi = base + (uint32_t)lane;
+                const bool have = pi < n_parents;
+                const uint32_t phys = phys_cur;
+                const uint4 q0 = q0c, q1 = q1c;
+                phys_cur = phys_nxt;
+                if (pi + WAVE < n_parents) {
+                    q0c = gld<uint4>(par, phys_nxt << 7); q1c = gld<uint4>(par, (phys_nxt << 7) + 16u);
+                }
+                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(pord, (pi + 2 * WAVE) << 2);
+                // ---- A: candidates of this pass
+                uint32_t pmoves = 0, pmeta = 0;
+                uint64_t pstart = 1, pend = 1;
+                float pprob = 0.0f;
+                if (have) {
+                    pstart = ((uint64_t)q0.y << 32) | q0.x;
+                    pend = ((uint64_t)q0.w << 32) | q0.z;
+                    pmoves = q1.x; pprob = __uint_as_float(q1.y); pmeta = q1.z;
+                }
+                const float thr = __shfl(thr_lane, __clzll((long long)(pend - pstart + 1)));
+                const uint32_t kmer = pmeta & META_KMER_MASK;
+                const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
+                const bool stay_ok = have && stays < P.max_consec_stay && s_probs[kmer] >= thr;
+                const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
+                uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
+                if (!have) mask = 0;
+                o_pstart[obuf][lane] = pstart; o_pend[obuf][lane] = pend; o_pphys[obuf][lane] = phys; o_pmoves[obuf][lane] = pmoves;
+                o_pmeta[obuf][lane] = pmeta; o_pprob[obuf][lane] = __float_as_uint(pprob);
+                const uint32_t ncand = (uint32_t)__popc(mask);
+                uint32_t ctot;
+                const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
+                {
+                    uint32_t w = coff;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b)
+                        if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
+                }
+                // everything the slot assignment needs later travels in one word (the rest is re-read from the staging)
+                const uint32_t pinfo = mask | (stay_ok ? 16u : 0u) | (have ? 32u : 0u) | (coff << 8);
+                wave_sync();
+                // ---- B: first round of FM look-ups issued ...
+                FmPending fp;
+                fp.fl = 0; fp.c = 0; fp.kk = fp.ll = 0;
+                fp.bl.cnt = 0; fp.bl.lo = fp.bl.hi = make_uint4(0u, 0u, 0u, 0u);
+                fp.bk = fp.bl;
+                const bool fm0 = (uint32_t)lane < ctot;
+                if (fm0) {
+                    const uint32_t cd = s_cand[lane];
+                    fp = fm_issue(ix, o_pstart[obuf][cd >> 2], o_pend[obuf][cd >> 2], cd & 3u);
+                }
+                // ---- C: ... while the previous pass's children are written
+                if (pend_n) emit_children(pend_n, pend_base, pend_buf);
+                pend_n = 0;
+                wave_sync();
+                // ---- D: ranges of this pass
+                if (fm0) {
+                    uint64_t ns, ne;
+                    fm_finish(ix, fp, &ns, &ne);
+                    s_res[lane] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
+                }
+                for (uint32_t c0 = WAVE; c0 < ctot; c0 += WAVE) {
+                    const uint32_t ci = c0 + (uint32_t)lane;
+                    if (ci < ctot) {
+                        const uint32_t cd = s_cand[ci];
+                        uint64_t ns, ne;
+                        fm_get_neighbor(ix, o_pstart[obuf][cd >> 2], o_pend[obuf][cd >> 2], cd & 3u, &ns, &ne);
+                        s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
+                    }
+                }
+                wave_sync();
+                // ---- E: child slots of this pass (same rules as the plain loop)
+                {
+                    const uint32_t emask = pinfo & 15u, ecoff = pinfo >> 8, encand = (uint32_t)__popc(emask);
+                    const bool ehave = (pinfo & 32u) != 0, estay = (pinfo & 16u) != 0;
+                    uint32_t vmask = (s_res[ecoff] != 0 ? 1u : 0u) | (s_res[ecoff + 1] != 0 ? 2u : 0u) | (s_res[ecoff + 2] != 0 ? 4u : 0u) |
+                                     (s_res[ecoff + 3] != 0 ? 8u : 0u);
+                    vmask &= (1u << encand) - 1u;
+                    const uint32_t nch = (estay ? 1u : 0u) + (uint32_t)__popc(vmask);
+                    uint32_t chtot;
+                    const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
+                    const uint32_t room = max_paths - nchild;
+                    const uint32_t nwrite = chtot < room ? chtot : room;
+                    const bool visited = ehave && choff < room;
+                    if (choff + (estay ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += encand;
+                    else
+                        for (uint32_t j = 0; j < encand; ++j)
+                            if (choff + (estay ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
+                    {
+                        uint32_t w = choff;
+                        if (estay) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
+                        uint32_t jj = 0;
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            if (emask & (1u << b)) {
+                                if (vmask & (1u << jj)) {
+                                    if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((ecoff + jj) << 9);
+                                    ++w;
+                                }
+                                ++jj;
+                            }
+                        }
+                    }
+                    const uint32_t emeta = o_pmeta[obuf][lane];
+                    bool ended_seed = false;
+                    uint32_t e_count = 0, e_mc = 0;
+                    const uint64_t estart = o_pstart[obuf][lane];
+                    if (visited && nch == 0 && !(emeta & META_SA_CHECKED)) {
+                        const uint64_t eplen_fm = o_pend[obuf][lane] - estart + 1;
+                        const uint32_t emoves = o_pmoves[obuf][lane];
+                        const float eprob = __uint_as_float(o_pprob[obuf][lane]);
+                        const uint32_t plen = (emeta >> META_LEN_SHIFT) & 31u;
+                        const uint32_t mc = (uint32_t)__popc(emoves);
+                        const bool base_ok = plen == P.seed_len && eprob >= P.min_seed_prob;
+                        const bool uniq = eplen_fm == 1 && (emoves & 1u) == 1u &&
+                                          (float)(plen - mc) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
+                        const bool rep = eplen_fm <= (uint64_t)P.max_rep_copy && mc >= P.min_rep_len;
+                        ended_seed = base_ok && (uniq || rep);
+                        e_count = (uint32_t)eplen_fm;
+                        e_mc = mc;
+                    }
+                    const uint64_t em = __ballot(ended_seed);
+                    const uint32_t pos = n_seedp + (uint32_t)prefix_popc(em);
+                    if (ended_seed && pos < A.sc.max_seed_paths) {
+                        SeedPath sp; sp.start = estart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
+                        seedp[pos] = sp;
+                    }
+                    n_seedp += (uint32_t)__popcll(em);
+                    pend_n = nwrite; pend_base = nchild; pend_buf = obuf;
+                    nchild += nwrite;
+                }
+                obuf ^= 1u;
+                wave_sync();
+            }
+            if (pend_n) emit_children(pend_n, pend_base, pend_buf);
+            wave_sync();
+#endif
             if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
 
