@@ -35,14 +35,24 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
         # GPU suffix-array builder takes (seq_len < 2^31); BWT + Occ 400 MB, i.e. past the 256 MiB Infinity Cache
         prefix = cache / "hs400_syn"
         names, lens, codes, holes, n_ambs = masked_synthetic_genome(8, 400000000, seed=3, name="hs400_syn")
+    elif workload == "grch38":
+        # SURVEY 8(d) `grch38_syn`: 24 contigs, 3.1 Gbp, seed 3, 30 % masked -- seq_len 6.2 G, past the 2^31 limit of the
+        # other builders: tools/build_index_big.py (chunked suffix sort on the GPU).  NOT YET RUN on the GPU (round 1).
+        from tools.build_index_big import big_masked_genome
+        prefix = cache / "grch38_syn"
+        names, lens, codes, holes, n_ambs = big_masked_genome(24, 3100000000, seed=3, name="grch38_syn")
     else:
         prefix = cache / "ecoli_syn"
         names, lens, codes = synthetic_genome(1, 4641652, seed=1)
         holes, n_ambs = (), None
     if rank == 0 and not (Path(str(prefix) + ".sa").exists() and Path(str(prefix) + ".uncl").exists()):
         cache.mkdir(parents=True, exist_ok=True)
-        build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs,
-                         sa_device=device if workload in ("chr20", "hs400") else None)
+        if workload == "grch38":
+            from tools.build_index_big import build_from_codes_big
+            build_from_codes_big(prefix, names, [""] * len(names), lens, codes, holes, n_ambs, device=device, verbose=True)
+        else:
+            build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs,
+                             sa_device=device if workload in ("chr20", "hs400") else None)
         # `uncalled index`: thresholds for THIS reference (self-alignment on the GPU + IndexParameterizer, preset
         # "default" = tgt_speed 115, scripts/uncalled:58); build_from_codes left the example's vector as a placeholder
         from uncalled_amd import capi
@@ -174,7 +184,7 @@ def main():
     ap.add_argument("--n-big", type=int, default=0, help="larger seed-cluster buffers (0 = library default)")
     ap.add_argument("--big-clusters", type=int, default=0, help="clusters per larger buffer (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed pass that collects phase cycle shares")
-    ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "realtime"], default="ecoli")
+    ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "grch38", "realtime"], default="ecoli")
     ap.add_argument("--channels", type=int, default=512)
     a = ap.parse_args()
 
@@ -198,7 +208,7 @@ def main():
     from uncalled_amd import capi
 
     cache = Path(os.environ.get("UNC_BENCH_CACHE", "/tmp/uncalled_amd_bench"))
-    prefix, codes, lens = ensure_index(cache, rank, world, barrier, a.workload if a.workload in ("chr20", "hs400") else "ecoli",
+    prefix, codes, lens = ensure_index(cache, rank, world, barrier, a.workload if a.workload in ("chr20", "hs400", "grch38") else "ecoli",
                                        f"cuda:{local_rank}")
     ix = capi.Index(prefix, device=local_rank)
     if a.workload == "realtime":
@@ -271,7 +281,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("repeat-masked chr20-sized synthetic ref (chr20_syn 64.4 Mb, seed 2, 30% N-runs)" if a.workload == "chr20"
                                     else "one eighth of a masked GRCh38-sized synthetic ref (hs400_syn: 8 contigs, 400 Mb, seed 3, 30% N-runs)"
-                                    if a.workload == "hs400" else "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1)") +
+                                    if a.workload == "hs400" else "masked GRCh38-sized synthetic ref (grch38_syn: 24 contigs, 3.1 Gb, seed 3, 30% N-runs)"
+                                    if a.workload == "grch38" else "E. coli 4.6 Mb synthetic ref (ecoli_syn seed 1)") +
                                    ", synthetic r9.4.1 reads (3600 bases ~ 32k samples, 10% off-target), all reference defaults",
                        "reads_per_gpu_per_step": a.reads, "parallelism": f"reads sharded over {world} GPU(s), index replicated",
                        "mean_ms_per_read_amortised": 1e3 * dt / (a.reads * a.steps),
