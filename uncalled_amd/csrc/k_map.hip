@@ -28,6 +28,9 @@
 // This file is compiled twice (see k_map_big.hip): plain, and with UNC_BIG, which adds the code that moves reads into
 // larger seed-cluster buffers (DevBig).  Two translation units rather than one template parameter: whatever is added to
 // the plain kernel, even dead, moves its register allocation (measured: 4-5 % on the E. coli workload).
+#if defined(UNC_E_OVERLAP) && defined(UNC_LAZY_CHILD)
+#error "UNC_E_OVERLAP and UNC_LAZY_CHILD are separate experiments"
+#endif
 #ifdef UNC_BIG
 #define UNC_KMAP k_map_big
 #define UNC_MAPARGS MapArgsBig
@@ -1037,9 +1040,11 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         const uint32_t po = s_pphys[pl] << 7;     // byte offset of the parent's record
                         const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
                         const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
+#ifndef UNC_LAZY_CHILD
                         // the parent's ring (6 x 16 B) plus the two sums the child needs, all in one round trip
                         const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
                                     r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
+#endif
                         uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
                         uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
                         const float last = gld<float>(par, po + 32u + (sl << 2)), second = gld<float>(par, po + 32u + (s2 << 2));
@@ -1062,9 +1067,15 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         const uint32_t co = gi << 7;
                         gst(chd, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
                         gst(chd, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
+#ifndef UNC_LAZY_CHILD
                         gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
                         gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
                         gst(chd, co + 32u + (c.wslot << 2), c.appended);   // same lane, same address as the copy above: program order
+#else
+                        // only what the walk needs; the ring is copied for the survivors after it (phase M): where the parent's
+                        // ring is, which slot takes the new sum, and the sum
+                        gst(chd, co + 32u, make_uint4(po, c.wslot, __float_as_uint(c.appended), 0u));
+#endif
                         gst(ukeys, gi << 4, key);
                     }
                 }
@@ -1432,6 +1443,32 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             }
             wave_sync();
+#ifdef UNC_LAZY_CHILD
+            // ---------------- M: the survivors' records get their parents' rings (experiment, off by default) ----------------
+            {
+                uint32_t id0 = (uint32_t)lane < n_surv ? nord[lane] : 0u;
+                uint32_t id1 = (uint32_t)lane + WAVE < n_surv ? nord[lane + WAVE] : 0u;
+                uint4 d0 = make_uint4(0u, 0u, 0u, 0u);
+                if ((uint32_t)lane < n_surv) d0 = gld<uint4>(chd, (id0 << 7) + 32u);
+                for (uint32_t k0 = 0; k0 < n_surv; k0 += WAVE) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const uint32_t idx = id0;
+                    const uint4 d = d0;
+                    id0 = id1;
+                    if (k + WAVE < n_surv) d0 = gld<uint4>(chd, (id1 << 7) + 32u);
+                    if (k + 2 * WAVE < n_surv) id1 = nord[k + 2 * WAVE];
+                    if (k < n_surv) {
+                        const uint32_t po = d.x, co = idx << 7;
+                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
+                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
+                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
+                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
+                        gst(chd, co + 32u + (d.y << 2), d.z);          // same lane, after the copy: program order
+                    }
+                }
+            }
+            wave_sync();
+#endif
 
             PHASE_END(3);
             // ---------------- F: remaining full-range sources, :605-624 ----------------
