@@ -116,3 +116,28 @@ def test_conf_defaults_and_cli_parser():
     assert (a.bwa_prefix, a.fast5s, a.max_reads, a.max_events, a.read_list, a.threads) == ("ref/prefix", ["dir1", "x.fast5"], 5, 100, "ids.txt", 8)
     a = get_parser().parse_args(["index", "g.fa", "--probs", "0.1,0.2"])
     assert a.bwa_prefix is None and a.probs == "0.1,0.2" and a.max_sample_dist == 100
+
+
+def test_multi_gpu_file_sharding():
+    from uncalled_amd.__main__ import get_parser, shard_files
+    files = ["f%02d.fast5" % i for i in range(11)] + [None]
+    shards = shard_files(files, 4)
+    assert [len(x) for x in shards] == [3, 3, 3, 2] and sorted(sum(shards, [])) == files[:-1]
+    assert shards[1] == ["f01.fast5", "f05.fast5", "f09.fast5"]
+    assert shard_files(["a"], 8)[0] == ["a"] and all(not x for x in shard_files(["a"], 8)[1:])
+    a = get_parser().parse_args(["map", "ref", "reads/", "--gpus", "8"])
+    assert a.gpus == 8 and a.device == 0
+
+
+def test_multi_gpu_launcher_reports_failed_workers(tmp_path):
+    """No GPU here, so both workers die in MapPool's constructor: the launcher must say so and exit non-zero."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "uncalled_amd", "map", str(G / "example_index" / "example_ref"), str(G / "example_read.fast5"),
+                        str(G / "example_read.fast5"), "--gpus", "2"], cwd=str(root), capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and len([l for l in r.stdout.splitlines() if l]) == 2
+    elif not torch.cuda.is_available():
+        assert r.returncode == 1 and "worker exit codes" in r.stderr and r.stdout == ""

@@ -75,7 +75,59 @@ def index_cmd(args):
     sys.stderr.write("Done\n")
 
 
+def shard_files(files, n_shards):
+    """fast5 files of shard i = every n-th file starting at i: files (reads) are independent units, no exchange"""
+    files = [f for f in files if f is not None]
+    return [files[i::n_shards] for i in range(n_shards)]
+
+
+def map_multi_gpu(args, argv):
+    """`map --gpus N`: one worker process per GPU (index replicated, fast5 files dealt round-robin), PAF lines of all
+    workers forwarded to stdout as they come.  SURVEY 8(e): no collective, no data-path communication."""
+    import subprocess
+    import tempfile
+    import threading
+    shards = shard_files(list(load_fast5s(args.fast5s, args.recursive)), args.gpus)
+    procs, lists = [], []
+    for dev, files in enumerate(shards):
+        if not files:
+            continue
+        lst = tempfile.NamedTemporaryFile("w", suffix=".fast5s.txt", delete=False)
+        lst.write("\n".join(files) + "\n")
+        lst.close()
+        lists.append(lst.name)
+        cmd = [sys.executable, "-m", "uncalled_amd", "map", args.bwa_prefix, lst.name, "--device", str(dev), "--gpus", "1"]
+        per_worker = None if args.max_reads is None else -(-args.max_reads // max(1, sum(1 for x in shards if x)))
+        for opt, val in (("-p", args.idx_preset), ("-l", args.read_list), ("-n", per_worker), ("-e", args.max_events),
+                         ("-c", args.max_chunks), ("--chunk-time", args.chunk_time), ("--batch-reads", args.batch_reads)):
+            if val is not None:
+                cmd += [opt, str(val)]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1))
+    lock = threading.Lock()
+
+    def pump(p):
+        for line in p.stdout:
+            with lock:
+                sys.stdout.write(line)
+        p.stdout.close()
+
+    threads = [threading.Thread(target=pump, args=(p,)) for p in procs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    codes = [p.wait() for p in procs]
+    for name in lists:
+        os.unlink(name)
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write("Error: worker exit codes %s\n" % codes)
+        sys.exit(1)
+
+
 def map_cmd(args):
+    if getattr(args, "gpus", 1) > 1:
+        return map_multi_gpu(args, sys.argv)
     from . import _uncalled_amd as unc
     conf = unc.Conf()
     for k, v in vars(args).items():
@@ -142,6 +194,7 @@ def get_parser():
     p.add_argument("--chunk-time", type=float, default=1, help="Length of chunks in seconds")
     p.add_argument("--device", type=int, default=0, help="GPU ordinal")
     p.add_argument("--batch-reads", type=int, default=4096, help="Reads per GPU batch")
+    p.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use: one worker process each, fast5 files dealt round-robin")
 
     p = sp.add_parser("pafstats", help="Computes speed and accuracy of UNCALLED mappings")
     pafstats.add_opts(p)
