@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
     """SURVEY 8(d) `ecoli_syn`: 1 contig, 4 641 652 bp, i.i.d. ACGT, GC 0.508, seed 1 -> BWA-format index.
     `chr20`: 64 444 167 bp, seed 2, 30 % in N-runs (suffix array built on the GPU)."""
-    from tools.build_index import build_from_codes, masked_synthetic_genome, synthetic_genome
+    from uncalled_amd.build_index import build_from_codes, masked_synthetic_genome, synthetic_genome
     if workload == "chr20":
         prefix = cache / "chr20_syn"
         names, lens, codes, holes, n_ambs = masked_synthetic_genome(1, 64444167, seed=2, name="chr20_syn")
@@ -37,8 +37,8 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
         names, lens, codes, holes, n_ambs = masked_synthetic_genome(8, 400000000, seed=3, name="hs400_syn")
     elif workload == "grch38":
         # SURVEY 8(d) `grch38_syn`: 24 contigs, 3.1 Gbp, seed 3, 30 % masked -- seq_len 6.2 G, past the 2^31 limit of the
-        # other builders: tools/build_index_big.py (chunked suffix sort on the GPU).  NOT YET RUN on the GPU (round 1).
-        from tools.build_index_big import big_masked_genome
+        # other builders: uncalled_amd/build_index_big.py (chunked suffix sort on the GPU).  NOT YET RUN on the GPU (round 1).
+        from uncalled_amd.build_index_big import big_masked_genome
         prefix = cache / "grch38_syn"
         names, lens, codes, holes, n_ambs = big_masked_genome(24, 3100000000, seed=3, name="grch38_syn")
     else:
@@ -48,7 +48,7 @@ def ensure_index(cache, rank, world, barrier, workload="ecoli", device=None):
     if rank == 0 and not (Path(str(prefix) + ".sa").exists() and Path(str(prefix) + ".uncl").exists()):
         cache.mkdir(parents=True, exist_ok=True)
         if workload == "grch38":
-            from tools.build_index_big import build_from_codes_big
+            from uncalled_amd.build_index_big import build_from_codes_big
             build_from_codes_big(prefix, names, [""] * len(names), lens, codes, holes, n_ambs, device=device, verbose=True)
         else:
             build_from_codes(prefix, names, [""] * len(names), lens, codes, holes, n_ambs,

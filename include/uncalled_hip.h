@@ -167,8 +167,9 @@ void unc_mapper_free(unc_mapper_t *m);
 uint64_t unc_mapper_device_bytes(const unc_mapper_t *m);
 
 /* Map a batch.  raw = concatenated int16 samples, read i = raw[offsets[i] .. offsets[i+1]);
- * calib[i] per read.  When on_device != 0 the three input pointers are device pointers (inputs
- * already resident in HBM); otherwise they are host pointers and are copied first.  `stream` is a
+ * calib[i] per read.  `offsets` (n_reads + 1) and `calib` (n_reads) are ALWAYS host arrays (a few bytes per read;
+ * they are validated on the host and copied).  `raw` is a host pointer when on_device == 0 (the samples are copied
+ * first) and a device pointer when on_device != 0 (samples already resident in HBM).  `stream` is a
  * hipStream_t (NULL = the mapper's own stream).  hits (host, n_reads) receives one record per read. */
 int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
                   const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits);

@@ -14,7 +14,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import pyref  # noqa: E402
-from tools.build_index import encode_contigs, read_fasta  # noqa: E402
+from uncalled_amd.build_index import encode_contigs, read_fasta  # noqa: E402
 from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE, simulate_reads  # noqa: E402
 
 G = Path(__file__).resolve().parent

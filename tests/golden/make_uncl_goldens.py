@@ -16,7 +16,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import pyref  # noqa: E402
-from tools.build_index import build_from_codes, synthetic_genome  # noqa: E402
+from uncalled_amd.build_index import build_from_codes, synthetic_genome  # noqa: E402
 
 REF_INDEX_PY = Path("/root/reference/uncalled/index.py")
 

@@ -1,5 +1,5 @@
-"""tools/build_index_big.py (chunked suffix sort for references past 2^31 symbols) against the bundled `bwa index` files
-and against tools/build_index.py on repeat-rich synthetic genomes, with chunks and pieces small enough to exercise every
+"""uncalled_amd/build_index_big.py (chunked suffix sort for references past 2^31 symbols) against the bundled `bwa index` files
+and against uncalled_amd/build_index.py on repeat-rich synthetic genomes, with chunks and pieces small enough to exercise every
 boundary (torch on the CPU here; the same code runs on the GPU)."""
 import filecmp
 import sys
@@ -9,9 +9,9 @@ import numpy as np
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-sys.path.insert(0, str(ROOT / "tools"))
-import build_index as small   # noqa: E402
-import build_index_big as big   # noqa: E402
+sys.path.insert(0, str(ROOT))
+from uncalled_amd import build_index as small   # noqa: E402
+from uncalled_amd import build_index_big as big   # noqa: E402
 
 EX = ROOT / "tests" / "golden" / "example_index"
 SUFS = (".pac", ".ann", ".amb", ".bwt", ".sa")

@@ -59,8 +59,8 @@ def test_wide_sort_keys(hip_lib, oracle_lib, example, goldens, monkeypatch):
 
 @pytest.fixture(scope="module")
 def ecoli(tmp_path_factory):
-    """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (tools/build_index.py)."""
-    from tools.build_index import build_from_codes, synthetic_genome
+    """SURVEY 8(d) `ecoli_syn`: 4 641 652 bp i.i.d. genome, seed 1, index in BWA format (uncalled_amd/build_index.py)."""
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
     d = tmp_path_factory.mktemp("ecoli")
     names, lens, codes = synthetic_genome(1, 4641652, seed=1)
     prefix = d / "ecoli_syn"
@@ -122,8 +122,8 @@ def test_batch_order_and_slot_independence(hip_lib, oracle_lib, example, goldens
 @pytest.fixture(scope="module")
 def chr20(tmp_path_factory):
     """SURVEY 8(d) `chr20_syn`: 64 444 167 bp, seed 2, 30 % of the length in N-runs (filled with seeded random bases and
-    recorded in .amb), BWA-format index with the suffix array built on the GPU (tools/build_index.py)."""
-    from tools.build_index import build_from_codes, masked_synthetic_genome
+    recorded in .amb), BWA-format index with the suffix array built on the GPU (uncalled_amd/build_index.py)."""
+    from uncalled_amd.build_index import build_from_codes, masked_synthetic_genome
     d = tmp_path_factory.mktemp("chr20")
     names, lens, codes, holes, n_ambs = masked_synthetic_genome(1, 64444167, seed=2, name="chr20_syn")
     prefix = d / "chr20_syn"

@@ -141,3 +141,34 @@ def test_multi_gpu_launcher_reports_failed_workers(tmp_path):
         assert r.returncode == 0 and len([l for l in r.stdout.splitlines() if l]) == 2
     elif not torch.cuda.is_available():
         assert r.returncode == 1 and "worker exit codes" in r.stderr and r.stdout == ""
+
+
+def test_multi_gpu_max_reads_and_read_list(tmp_path, capsys):
+    """`map --gpus 2 -n K -l list`: every worker gets the whole read list and no `-n`; the cap is applied once, by the
+    launcher, on the forwarded PAF lines (per-worker cuts mapped at most K/N reads)."""
+    import glob
+    import sys
+    import tempfile
+    from uncalled_amd.__main__ import get_parser, map_multi_gpu, worker_cmd
+    files = []
+    for i in range(4):
+        f = tmp_path / ("r%d.fast5" % i)
+        f.write_bytes(b"")
+        files.append(str(f))
+    ids = tmp_path / "ids.txt"
+    ids.write_text("a\nb\nc\n")
+    a = get_parser().parse_args(["map", "ref", *files, "--gpus", "2", "-n", "5", "-l", str(ids)])
+    cmd = worker_cmd(a, "list.txt", 1)
+    assert "-n" not in cmd and cmd[cmd.index("-l") + 1] == str(ids) and cmd[cmd.index("--device") + 1] == "1"
+    before = set(glob.glob(tempfile.gettempdir() + "/*.fast5s.txt"))
+
+    def fake(args, list_name, dev):   # a worker that "maps" four reads per fast5 file of its shard
+        return [sys.executable, "-c", "import sys\nfor f in open(sys.argv[1]):\n  [print('read-%s-%d' % (f.strip()[-8:], j), flush=True) for j in range(4)]", list_name]
+
+    map_multi_gpu(a, None, make_cmd=fake)
+    out = [l for l in capsys.readouterr().out.splitlines() if l]
+    assert len(out) == 5 and len(set(out)) == 5                      # exactly -n lines of the 16 produced
+    a.max_reads = None
+    map_multi_gpu(a, None, make_cmd=fake)
+    assert len([l for l in capsys.readouterr().out.splitlines() if l]) == 16
+    assert set(glob.glob(tempfile.gettempdir() + "/*.fast5s.txt")) == before   # list files are removed

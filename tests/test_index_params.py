@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tools.build_index import build_from_codes, synthetic_genome
+from uncalled_amd.build_index import build_from_codes, synthetic_genome
 from uncalled_amd import capi
 from uncalled_amd.index_params import choose_sample_dist, parameterize
 

@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import numpy as np
 from uncalled_amd import capi
-from tools.build_index import build_from_codes, synthetic_genome
+from uncalled_amd.build_index import build_from_codes, synthetic_genome
 from tools.simulate_reads_torch import simulate_reads_torch
 from tools.simulate_reads import CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION
 

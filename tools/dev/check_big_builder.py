@@ -1,9 +1,9 @@
-"""Dev tool (GPU box): tools/build_index_big.py against tools/build_index.py on a chr20-sized masked reference, both on the GPU."""
+"""Dev tool (GPU box): uncalled_amd/build_index_big.py against uncalled_amd/build_index.py on a chr20-sized masked reference, both on the GPU."""
 import filecmp, sys, tempfile, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
-sys.path.insert(0, str(ROOT / "tools"))
-import build_index as small, build_index_big as big
+sys.path.insert(0, str(ROOT))
+from uncalled_amd import build_index as small, build_index_big as big
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64444167
 names, lens, codes, holes, n_ambs = small.masked_synthetic_genome(3, n, seed=2, name="x")
 d = tempfile.mkdtemp()

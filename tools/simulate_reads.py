@@ -83,7 +83,7 @@ if __name__ == "__main__":
     import argparse
     import sys
     sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-    from tools.build_index import read_fasta, encode_contigs
+    from uncalled_amd.build_index import read_fasta, encode_contigs
     ap = argparse.ArgumentParser()
     ap.add_argument("fasta")
     ap.add_argument("out_npz")

@@ -55,8 +55,7 @@ def index_cmd(args):
         sys.stderr.write("Using previously built BWA index.\nNote: to fully re-build the index delete files with the "
                          "\"%s.*\" prefix.\n" % prefix)
     else:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-        import build_index
+        from . import build_index
         build_index.build_from_fasta(args.fasta_filename, prefix, verbose=True)
     sys.stderr.write("Initializing parameter search\n")
     presets = [("default", dict(tgt_speed=115))]
@@ -64,14 +63,23 @@ def index_cmd(args):
         presets.append(("prob_%s" % tgt, dict(tgt_prob=float(tgt))))
     for tgt in (args.speeds.split(",") if args.speeds else []):
         presets.append(("speed_%s" % tgt, dict(tgt_speed=float(tgt))))
-    if not os.path.exists(prefix + ".uncl"):
-        with open(prefix + ".uncl", "w") as f:   # the loader wants a preset; self-align does not read the thresholds
+    # the loader wants a preset (self-alignment does not read the thresholds): a placeholder .uncl lives only for the
+    # duration of the search and never survives a failed or interrupted one -- `map` would load it silently
+    placeholder = not os.path.exists(prefix + ".uncl")
+    if placeholder:
+        with open(prefix + ".uncl", "w") as f:
             f.write("default\t-10.0\t0.00000\t0.000\n")
-    ix = capi.Index(prefix, device=args.device)
-    index_params.parameterize(ix, prefix, presets=presets, max_sample_dist=args.max_sample_dist,
-                              min_samples=args.min_samples, max_samples=args.max_samples, kmer_len=args.kmer_len,
-                              matchpr1=args.matchpr1, matchpr2=args.matchpr2,
-                              pathlen_percentile=args.pathlen_percentile, max_replen=args.max_replen)
+    done = False
+    try:
+        ix = capi.Index(prefix, device=args.device)
+        index_params.parameterize(ix, prefix, presets=presets, max_sample_dist=args.max_sample_dist,
+                                  min_samples=args.min_samples, max_samples=args.max_samples, kmer_len=args.kmer_len,
+                                  matchpr1=args.matchpr1, matchpr2=args.matchpr2,
+                                  pathlen_percentile=args.pathlen_percentile, max_replen=args.max_replen)
+        done = True
+    finally:
+        if placeholder and not done and os.path.exists(prefix + ".uncl"):
+            os.unlink(prefix + ".uncl")
     sys.stderr.write("Done\n")
 
 
@@ -81,46 +89,66 @@ def shard_files(files, n_shards):
     return [files[i::n_shards] for i in range(n_shards)]
 
 
-def map_multi_gpu(args, argv):
+def worker_cmd(args, list_name, dev):
+    """command line of one `--gpus N` worker: everything but `-n`, which is a cap on the whole job (see map_multi_gpu)"""
+    cmd = [sys.executable, "-m", "uncalled_amd", "map", args.bwa_prefix, list_name, "--device", str(dev), "--gpus", "1"]
+    for opt, val in (("-p", args.idx_preset), ("-l", args.read_list), ("-e", args.max_events),
+                     ("-c", args.max_chunks), ("--chunk-time", args.chunk_time), ("--batch-reads", args.batch_reads)):
+        if val is not None:
+            cmd += [opt, str(val)]
+    return cmd
+
+
+def map_multi_gpu(args, argv, make_cmd=worker_cmd):
     """`map --gpus N`: one worker process per GPU (index replicated, fast5 files dealt round-robin), PAF lines of all
-    workers forwarded to stdout as they come.  SURVEY 8(e): no collective, no data-path communication."""
+    workers forwarded to stdout as they come.  SURVEY 8(e): no collective, no data-path communication.
+    `-l` goes to every worker in full (a worker only sees its own files, so each read id matches in one of them);
+    `-n` is a cap on the whole job and is applied HERE, on the forwarded lines: workers are stopped once it is reached."""
     import subprocess
     import tempfile
     import threading
-    shards = shard_files(list(load_fast5s(args.fast5s, args.recursive)), args.gpus)
+    shards = [x for x in shard_files(list(load_fast5s(args.fast5s, args.recursive)), args.gpus) if x]
     procs, lists = [], []
-    for dev, files in enumerate(shards):
-        if not files:
-            continue
-        lst = tempfile.NamedTemporaryFile("w", suffix=".fast5s.txt", delete=False)
-        lst.write("\n".join(files) + "\n")
-        lst.close()
-        lists.append(lst.name)
-        cmd = [sys.executable, "-m", "uncalled_amd", "map", args.bwa_prefix, lst.name, "--device", str(dev), "--gpus", "1"]
-        per_worker = None if args.max_reads is None else -(-args.max_reads // max(1, sum(1 for x in shards if x)))
-        for opt, val in (("-p", args.idx_preset), ("-l", args.read_list), ("-n", per_worker), ("-e", args.max_events),
-                         ("-c", args.max_chunks), ("--chunk-time", args.chunk_time), ("--batch-reads", args.batch_reads)):
-            if val is not None:
-                cmd += [opt, str(val)]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1))
     lock = threading.Lock()
+    state = {"n": 0, "full": False}
+    limit = args.max_reads
 
     def pump(p):
         for line in p.stdout:
             with lock:
+                if limit is not None and state["n"] >= limit:
+                    state["full"] = True
+                    break
                 sys.stdout.write(line)
+                state["n"] += 1
         p.stdout.close()
 
-    threads = [threading.Thread(target=pump, args=(p,)) for p in procs]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    codes = [p.wait() for p in procs]
-    for name in lists:
-        os.unlink(name)
+    try:
+        for dev, files in enumerate(shards):
+            lst = tempfile.NamedTemporaryFile("w", suffix=".fast5s.txt", delete=False)
+            lists.append(lst.name)
+            lst.write("\n".join(files) + "\n")
+            lst.close()
+            procs.append(subprocess.Popen(make_cmd(args, lst.name, dev), stdout=subprocess.PIPE, text=True, bufsize=1))
+        threads = [threading.Thread(target=pump, args=(p,)) for p in procs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if state["full"]:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        codes = [p.wait() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for name in lists:
+            if os.path.exists(name):
+                os.unlink(name)
     sys.stdout.flush()
-    if any(codes):
+    if any(codes) and not state["full"]:
         sys.stderr.write("Error: worker exit codes %s\n" % codes)
         sys.exit(1)
 

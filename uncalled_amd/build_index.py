@@ -12,7 +12,7 @@ documented in SURVEY.md section 8c), plus `<prefix>.uncl` thresholds:
   .pac    forward strand, 4 bases/byte (base i at bits (~i & 3) << 1), [0x00 if l_pac%4==0], l_pac%4
 
 The suffix array is built by prefix doubling on packed keys; fine up to a few hundred Mbp.
-Self-check: `python tools/build_index.py --selftest` rebuilds the reference's bundled example
+Self-check: `python uncalled_amd/build_index.py --selftest` rebuilds the reference's bundled example
 index from example_ref.fa and compares every file byte-for-byte.
 """
 import argparse

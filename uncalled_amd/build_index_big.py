@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""BWA-format index builder for references past the 2^31-symbol limit of tools/build_index.py (GRCh38: 6.2 G symbols).
+"""BWA-format index builder for references past the 2^31-symbol limit of uncalled_amd/build_index.py (GRCh38: 6.2 G symbols).
 
-Same files, byte for byte, as `bwa index` / tools/build_index.py (tests/test_build_index_big.py compares them on the
+Same files, byte for byte, as `bwa index` / uncalled_amd/build_index.py (tests/test_build_index_big.py compares them on the
 bundled example and on repeat-rich synthetic genomes); the difference is how the suffix array comes about:
 
   * suffixes are bucketed by their first 8 symbols (3 bits each: 0 = past the end, 1..4 = ACGT; 2^24 buckets whose order
@@ -20,8 +20,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent))
-from build_index import DEFAULT_UNCL, pack2   # noqa: E402
+from .build_index import DEFAULT_UNCL, pack2
 
 K = 21            # symbols per 63-bit key
 B = 8             # symbols of the bucket id

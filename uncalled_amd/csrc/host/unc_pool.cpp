@@ -224,6 +224,8 @@ uint32_t Fast5Reader::fill_buffer() {
 }
 
 RawRead Fast5Reader::pop_read() {
+    if (buffered_.empty()) fill_buffer();             // fast5_reader.cpp:236-238
+    if (buffered_.empty()) return RawRead();          // exhausted: an empty read (id "", no samples), never UB
     RawRead r = std::move(buffered_.front());
     buffered_.pop_front();
     return r;
