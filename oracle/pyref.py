@@ -150,12 +150,18 @@ class Mapper:
         return hit
 
 
-def map_batch(signals_f32, offsets_u64, n_threads):
+def map_batch(signals_f32, offsets_u64, n_threads, pool=False):
+    """tight new_read -> map_read loop on n_threads (SURVEY 8d "B1"); pool=True: through the as-shipped MapPool hand-shake
+    with its 10 ms polling sleeps ("B2")"""
     sig = np.ascontiguousarray(signals_f32, dtype=np.float32)
     off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
     n = off.size - 1
     hits = (RefHit * n)()
-    secs = lib().ref_map_batch(n_threads, n, sig.ctypes.data, off.ctypes.data, C.cast(hits, C.c_void_p))
+    L = lib()
+    fn = L.ref_map_batch_pool if pool else L.ref_map_batch
+    fn.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_double
+    secs = fn(n_threads, n, sig.ctypes.data, off.ctypes.data, C.cast(hits, C.c_void_p))
     return list(hits), secs
 
 

@@ -19,6 +19,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <memory>
 #include <thread>
 #include <unordered_set>
 #include <utility>
@@ -123,6 +124,61 @@ double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, cons
     auto t1 = std::chrono::steady_clock::now();
     for (auto *m : mappers) delete m;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// SURVEY 8(d) baseline "B2": the same reads through the as-shipped MapPool hand-shake (map_pool.cpp:45-69,130-158 driven by
+// the polling loop of scripts/uncalled:127-167): every worker waits for its next read and for its result slot to be
+// emptied in 10 ms sleeps, and the main thread visits the workers once per <= 10 ms round.  The fast5 reader is left out
+// (signals are already in memory); the flags are the reference's unsynchronised bools, atomics here.
+double ref_map_batch_pool(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out) {
+    if (n_threads < 1) n_threads = 1;
+    struct Worker {
+        Mapper mapper;
+        std::atomic<bool> running{true}, finished{false}, in_buffered{false}, out_buffered{false};
+        uint32_t next = 0, done = 0;
+        ref_hit_t hit;
+        std::thread th;
+    };
+    std::vector<std::unique_ptr<Worker>> ws;
+    for (int t = 0; t < n_threads; ++t) ws.emplace_back(new Worker());
+    auto t0 = std::chrono::steady_clock::now();
+    for (auto &wp : ws) {
+        Worker *w = wp.get();
+        w->th = std::thread([w, signals, offsets]() {
+            while (!w->finished) {
+                while (!w->in_buffered && !w->finished) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                if (w->finished) break;
+                const uint32_t i = w->next;
+                w->in_buffered = false;
+                ref_hit_t h;
+                ref_map_read(&w->mapper, signals + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), &h);
+                while (w->out_buffered) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                w->hit = h; w->done = i;
+                w->out_buffered = true;
+            }
+            while (w->out_buffered) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            w->running = false;
+        });
+    }
+    uint32_t handed = 0;
+    for (;;) {
+        auto r0 = std::chrono::steady_clock::now();
+        bool any = false;
+        for (auto &wp : ws) {                       // MapPool::update
+            Worker *w = wp.get();
+            if (w->out_buffered) { out[w->done] = w->hit; w->out_buffered = false; }
+            if (!w->in_buffered) {
+                if (handed >= n_reads) w->finished = true;
+                else { w->next = handed++; w->in_buffered = true; }
+            }
+            any = any || w->running;
+        }
+        if (!any) break;
+        const auto dt = std::chrono::steady_clock::now() - r0;   // scripts/uncalled:156-160: sleep out the rest of 10 ms
+        if (dt < std::chrono::milliseconds(10)) std::this_thread::sleep_for(std::chrono::milliseconds(10) - dt);
+    }
+    for (auto &wp : ws) wp->th.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // One read through the Mapper's chunk API the way MapPoolOrd drives it (map_pool_ord.cpp:61-112 ->

@@ -54,6 +54,8 @@ int ref_map_read(void *m, const float *signal, uint32_t n, ref_hit_t *out);
 /* N threads, one Mapper each, tight new_read->map_read loop over an interleaved shard
  * (BASELINE.md "B1").  Returns wall seconds of the mapping loop. */
 double ref_map_batch(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out);
+/* the same through the as-shipped MapPool hand-shake with its 10 ms polling sleeps (SURVEY 8d "B2") */
+double ref_map_batch_pool(int n_threads, uint32_t n_reads, const float *signals, const uint64_t *offsets, ref_hit_t *out);
 
 /* chunked path: one read through new_read(Chunk)/add_chunk/process_chunk/map_chunk on this Mapper (= channel) */
 int ref_chunk_read(void *m, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,

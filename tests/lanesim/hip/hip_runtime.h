@@ -41,6 +41,7 @@ struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct float4 { float x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct alignas(16) ulonglong2 { unsigned long long x, y; };
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
@@ -222,6 +223,14 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return 0; }
+static inline hipError_t hipMemset2D(void *d, size_t pitch, int v, size_t w, size_t h) {
+    for (size_t i = 0; i < h; ++i) std::memset(static_cast<char *>(d) + i * pitch, v, w);
+    return 0;
+}
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t i = 0; i < h; ++i) std::memcpy(static_cast<char *>(d) + i * dp, static_cast<const char *>(s) + i * sp, w);
+    return 0;
+}
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

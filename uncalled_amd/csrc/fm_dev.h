@@ -123,34 +123,6 @@ __device__ __forceinline__ void fm_get_neighbor(const DevIndex &ix, uint64_t s, 
     *oe = ix.L2[c] + ol;
 }
 
-// The same look-up split in two, for callers that put other work between the loads and their use (k_map with
-// UNC_E_OVERLAP): fm_issue starts the block loads, fm_finish turns them into the new range.
-struct FmPending { FmPart bl, bk; uint64_t kk, ll; uint32_t c, fl; };   // fl: 1 k plain, 2 l plain, 4 shared block, 8 k = seq_len, 16 l = seq_len
-
-__device__ __forceinline__ FmPending fm_issue(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c) {
-    FmPending f;
-    const uint64_t k = s - 1, l = e;
-    const bool k_plain = k != ix.seq_len && k != ~0ull, l_plain = l != ix.seq_len && l != ~0ull;
-    f.kk = k - (k >= ix.primary ? 1 : 0); f.ll = l - (l >= ix.primary ? 1 : 0);
-    const bool share = k_plain && l_plain && f.kk <= f.ll && (f.kk >> 7) == (f.ll >> 7);
-    f.c = c;
-    f.fl = (k_plain ? 1u : 0u) | (l_plain ? 2u : 0u) | (share ? 4u : 0u) | (k == ix.seq_len ? 8u : 0u) | (l == ix.seq_len ? 16u : 0u);
-    f.bl.cnt = 0; f.bl.lo = f.bl.hi = make_uint4(0u, 0u, 0u, 0u);
-    f.bk = f.bl;
-    if (l_plain) f.bl = fm_load_part(ix, f.ll, c);
-    if (k_plain && !share) f.bk = fm_load_part(ix, f.kk, c);
-    return f;
-}
-
-__device__ __forceinline__ void fm_finish(const DevIndex &ix, const FmPending &f, uint64_t *os, uint64_t *oe) {
-    const uint64_t whole = ix.L2[f.c + 1] - ix.L2[f.c];
-    uint64_t ok = (f.fl & 8u) ? whole : 0, ol = (f.fl & 16u) ? whole : 0;
-    if (f.fl & 2u) ol = fm_part_rank(f.bl, f.ll, f.c);
-    if (f.fl & 1u) ok = (f.fl & 4u) ? fm_part_rank(f.bl, f.kk, f.c) : fm_part_rank(f.bk, f.kk, f.c);
-    *os = ix.L2[f.c] + ok + 1;
-    *oe = ix.L2[f.c] + ol;
-}
-
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps
 __device__ __forceinline__ uint64_t fm_sa(const DevIndex &ix, uint64_t k, uint32_t *steps) {
     uint32_t n = 0;

@@ -7,8 +7,8 @@
 //   P  1024 match log-probs of the normalised event (pore_model.hpp:163-165) -> LDS
 //   E  parents, 64 per pass in the reference's visiting order: thresholds -> candidate (parent,base)
 //      pairs compacted through LDS -> FM get_neighbor with every lane busy -> child slots by prefix
-//      sum (honouring the max_paths cut-off) -> one lane per child copies the parent's 128-byte
-//      record, slides the prob-sum window and emits a 16-byte sort key
+//      sum (honouring the max_paths cut-off) -> one lane per child writes a 64-byte record (the
+//      parent's staged in LDS: no global read) and a 16-byte sort key
 //   S  wavefront bitonic sort of the keys in registers (global-memory network beyond 512 children)
 //   W  walk in sorted order: duplicate-range pruning, per-k-mer gap sources from a segmented
 //      prefix-max, survivors -> next parent list, seed-valid survivors -> seed list
@@ -16,6 +16,7 @@
 //   T  SA look-ups for all seeds in parallel (<=31 dependent LF steps each), then the SeedTracker
 //      update in the reference's order on a sorted 16-byte key array + append-only payload pool
 //   G  confidence test (get_final / check_map_conf) -> SUCCESS, or next event
+//   M  every 4th event: the prob-sum rings of the paths still alive are brought up to date (PathRec)
 //
 // Integer/range results are bit-exact with the reference; float expressions are written one IEEE
 // operation at a time (compile with -ffp-contract=off; the reference is built without FMA).
@@ -28,9 +29,6 @@
 // This file is compiled twice (see k_map_big.hip): plain, and with UNC_BIG, which adds the code that moves reads into
 // larger seed-cluster buffers (DevBig).  Two translation units rather than one template parameter: whatever is added to
 // the plain kernel, even dead, moves its register allocation (measured: 4-5 % on the E. coli workload).
-#if defined(UNC_E_OVERLAP) && defined(UNC_LAZY_CHILD)
-#error "UNC_E_OVERLAP and UNC_LAZY_CHILD are separate experiments"
-#endif
 #ifdef UNC_BIG
 #define UNC_KMAP k_map_big
 #define UNC_MAPARGS MapArgsBig
@@ -103,24 +101,26 @@ struct Tracker {
 // kept sorted) over leaves of up to 64 keys each (one lane per key).  Insert / erase touch one leaf (a lane-parallel
 // shift inside 64 entries) plus, once every ~32 inserts, a leaf split; nothing is ever O(#clusters).
 constexpr uint32_t LEAF = 64;
+// All four regions hang off ONE uniform base pointer (the slot's, or a larger buffer's) at 32-bit byte offsets.
 struct TrackerMem {
-    ClusterKey *leaves;   // [max_leaves][LEAF]
-    ClusterKey *dir;      // [max_leaves]: first key of the leaf, .pidx = leaf id
-    uint32_t *cnt;        // [max_leaves] by leaf id
-    ClusterPay *pay;      // append-only payload pool
+    char *base;
+    uint32_t off_leaves;  // ClusterKey [max_leaves][LEAF]
+    uint32_t off_dir;     // ClusterKey [max_leaves]: first key of the leaf, .pidx = leaf id
+    uint32_t off_cnt;     // u32 [max_leaves] by leaf id
+    uint32_t off_pay;     // ClusterPay, append-only payload pool
     uint32_t max_leaves, max_pay;
 };
+__device__ __forceinline__ ClusterKey tm_leaf(const TrackerMem &M, uint32_t id, uint32_t slot) { return gld<ClusterKey>(M.base, M.off_leaves + ((id * LEAF + slot) << 4)); }
+__device__ __forceinline__ void tm_leaf_st(const TrackerMem &M, uint32_t id, uint32_t slot, const ClusterKey &k) { gst(M.base, M.off_leaves + ((id * LEAF + slot) << 4), k); }
+__device__ __forceinline__ ClusterKey tm_dir(const TrackerMem &M, uint32_t i) { return gld<ClusterKey>(M.base, M.off_dir + (i << 4)); }
+__device__ __forceinline__ void tm_dir_st(const TrackerMem &M, uint32_t i, const ClusterKey &k) { gst(M.base, M.off_dir + (i << 4), k); }
+__device__ __forceinline__ uint32_t tm_cnt(const TrackerMem &M, uint32_t id) { return gld<uint32_t>(M.base, M.off_cnt + (id << 2)); }
+__device__ __forceinline__ void tm_cnt_st(const TrackerMem &M, uint32_t id, uint32_t c) { gst(M.base, M.off_cnt + (id << 2), c); }
+__device__ __forceinline__ ClusterPay tm_pay(const TrackerMem &M, uint32_t i) { return gld<ClusterPay>(M.base, M.off_pay + (i << 5)); }
+__device__ __forceinline__ void tm_pay_st(const TrackerMem &M, uint32_t i, const ClusterPay &v) { gst(M.base, M.off_pay + (i << 5), v); }
+__device__ __forceinline__ uint32_t tm_pay_len(const TrackerMem &M, uint32_t i) { return gld<uint32_t>(M.base, M.off_pay + (i << 5) + 20u); }
+static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterPay) == 32 && offsetof(ClusterPay, total_len) == 20, "seed-cluster record layout");
 
-#ifdef UNC_NOINLINE_SORT
-#define UNC_SORT_FN static __device__ __noinline__
-#else
-#define UNC_SORT_FN static __device__
-#endif
-#ifdef UNC_NOINLINE_SEED
-#define UNC_SEED_FN static __device__ __noinline__
-#else
-#define UNC_SEED_FN static __device__
-#endif
 __device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
     // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
     return k.rstart > r2 || (k.rstart == r2 && k.evt_en > e2);
@@ -140,48 +140,47 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
 }
 
 // move directory entries [a,b) one slot up / down
-__device__ __forceinline__ void dir_shift_up(ClusterKey *dir, uint32_t a, uint32_t b, int lane) {
+__device__ __forceinline__ void dir_shift_up(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
     for (uint32_t hi = b; hi > a;) {
         uint32_t lo = hi - a > 64 ? hi - 64 : a;
         uint32_t idx = lo + lane;
         ClusterKey k;
         bool have = idx < hi;
-        if (have) k = dir[idx];
+        if (have) k = tm_dir(M, idx);
         wave_sync();
-        if (have) dir[idx + 1] = k;
+        if (have) tm_dir_st(M, idx + 1, k);
         wave_sync();
         hi = lo;
     }
 }
-__device__ __forceinline__ void dir_shift_down(ClusterKey *dir, uint32_t a, uint32_t b, int lane) {
+__device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
     for (uint32_t lo = a; lo < b; lo += 64) {
         uint32_t idx = lo + lane;
         ClusterKey k;
         bool have = idx < b;
-        if (have) k = dir[idx];
+        if (have) k = tm_dir(M, idx);
         wave_sync();
-        if (have) dir[idx - 1] = k;
+        if (have) tm_dir_st(M, idx - 1, k);
         wave_sync();
     }
 }
 
 // remove entry `slot` of directory position L, whose leaf has id `id` and `c` keys; keeps the directory's first keys right
 __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
-    ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
     ClusterKey k;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
-    if (mv) k = leaf[lane];
+    if (mv) k = tm_leaf(M, id, lane);
     wave_sync();
-    if (mv) leaf[lane - 1] = k;
+    if (mv) tm_leaf_st(M, id, lane - 1, k);
     wave_sync();
     if (c == 1) {
-        dir_shift_down(M.dir, L + 1, T.n_leaves, lane);
+        dir_shift_down(M, L + 1, T.n_leaves, lane);
         T.n_leaves--;
-        if (lane == 0) M.cnt[id] = 0;
+        if (lane == 0) tm_cnt_st(M, id, 0);
     } else {
         if (lane == 0) {
-            M.cnt[id] = c - 1;
-            if (slot == 0) { ClusterKey f = leaf[0]; f.pidx = id; M.dir[L] = f; }
+            tm_cnt_st(M, id, c - 1);
+            if (slot == 0) { ClusterKey f = tm_leaf(M, id, 0); f.pidx = id; tm_dir_st(M, L, f); }
         }
     }
     wave_sync();
@@ -193,51 +192,49 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
         if (T.n_alloc >= M.max_leaves) return false;
         const uint32_t id = T.n_alloc++;
         if (lane == 0) {
-            M.leaves[(size_t)id * LEAF] = nk;
-            M.cnt[id] = 1;
-            ClusterKey f = nk; f.pidx = id; M.dir[0] = f;
+            tm_leaf_st(M, id, 0, nk);
+            tm_cnt_st(M, id, 1);
+            ClusterKey f = nk; f.pidx = id; tm_dir_st(M, 0, f);
         }
         T.n_leaves = 1;
         wave_sync();
         return true;
     }
-    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = M.cnt[M.dir[L].pidx]; }   // append to the last leaf
-    uint32_t id = M.dir[L].pidx, c = M.cnt[id];
+    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = tm_cnt(M, tm_dir(M, L).pidx); }   // append to the last leaf
+    uint32_t id = tm_dir(M, L).pidx, c = tm_cnt(M, id);
     if (c == LEAF) {
         // split: the upper half moves to a fresh leaf that follows this one in the directory
         if (T.n_alloc >= M.max_leaves) return false;
         const uint32_t nid = T.n_alloc++;
-        ClusterKey *src = M.leaves + (size_t)id * LEAF, *dst = M.leaves + (size_t)nid * LEAF;
-        if (lane >= (int)(LEAF / 2)) dst[lane - LEAF / 2] = src[lane];
+        if (lane >= (int)(LEAF / 2)) tm_leaf_st(M, nid, lane - LEAF / 2, tm_leaf(M, id, lane));
         wave_sync();
-        dir_shift_up(M.dir, L + 1, T.n_leaves, lane);
+        dir_shift_up(M, L + 1, T.n_leaves, lane);
         if (lane == 0) {
-            ClusterKey f = dst[0]; f.pidx = nid; M.dir[L + 1] = f;
-            M.cnt[id] = LEAF / 2; M.cnt[nid] = LEAF / 2;
+            ClusterKey f = tm_leaf(M, nid, 0); f.pidx = nid; tm_dir_st(M, L + 1, f);
+            tm_cnt_st(M, id, LEAF / 2); tm_cnt_st(M, nid, LEAF / 2);
         }
         T.n_leaves++;
         wave_sync();
         if (slot > LEAF / 2) { L = L + 1; slot -= LEAF / 2; id = nid; }
         c = LEAF / 2;
     }
-    ClusterKey *leaf = M.leaves + (size_t)id * LEAF;
     ClusterKey k;
     const bool mv = (uint32_t)lane >= slot && (uint32_t)lane < c;
-    if (mv) k = leaf[lane];
+    if (mv) k = tm_leaf(M, id, lane);
     wave_sync();
-    if (mv) leaf[lane + 1] = k;
+    if (mv) tm_leaf_st(M, id, lane + 1, k);
     if (lane == 0) {
-        leaf[slot] = nk;
-        M.cnt[id] = c + 1;
-        if (slot == 0) { ClusterKey f = nk; f.pidx = id; M.dir[L] = f; }
+        tm_leaf_st(M, id, slot, nk);
+        tm_cnt_st(M, id, c + 1);
+        if (slot == 0) { ClusterKey f = nk; f.pidx = id; tm_dir_st(M, L, f); }
     }
     wave_sync();
     return true;
 }
 
 // SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
-UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
-                         int lane) {
+static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
+                                int lane) {
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
     const uint32_t e2 = evt;
@@ -248,7 +245,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         uint32_t step = (hi - lo + 63) / 64;
         uint32_t idx = lo + (uint32_t)lane * step;
         bool less = false;
-        if (idx < hi) less = key_less(M.dir[idx], r2, e2);
+        if (idx < hi) less = key_less(tm_dir(M, idx), r2, e2);
         uint32_t c = (uint32_t)__popcll(__ballot(less));
         uint32_t nlo = c ? lo + (c - 1) * step + 1 : lo;
         uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
@@ -261,7 +258,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
-        if (idx < hi) { dk = M.dir[idx]; less = key_less(dk, r2, e2); }
+        if (idx < hi) { dk = tm_dir(M, idx); less = key_less(dk, r2, e2); }
         d = lo + (uint32_t)__popcll(__ballot(less));
     }
     // leaf d - 1 (the last one whose first key sorts before the seed), its count and keys in one round trip
@@ -269,9 +266,9 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
     uint32_t id0 = 0, c0 = 0;    // leaf id / count of directory position d - 1
     ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.pidx = 0;
     if (d > 0) {
-        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(M.dir[d - 1].pidx);   // window starts after it
-        lk = M.leaves[(size_t)id0 * LEAF + lane];       // slots past the count hold stale keys: masked by c0
-        c0 = M.cnt[id0];
+        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).pidx);   // window starts after it
+        lk = tm_leaf(M, id0, lane);       // slots past the count hold stale keys: masked by c0
+        c0 = tm_cnt(M, id0);
         const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
         const uint32_t sn = (uint32_t)__popcll(__ballot(less));
         if (sn < c0) { lbL = d - 1; lbS = sn; } else { lbL = d; lbS = 0; }
@@ -291,9 +288,9 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             ClusterKey k;
             if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
             else {
-                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(M.dir[curL].pidx);
-                k = M.leaves[(size_t)id * LEAF + lane];
-                c = M.cnt[id];
+                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(tm_dir(M, curL).pidx);
+                k = tm_leaf(M, id, lane);
+                c = tm_cnt(M, id);
             }
             if (first) {   // the key at the lower bound is the first one this scan looks at
                 const uint64_t kr = bcast64(k.rstart, (int)from);
@@ -306,7 +303,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             if (have) {
                 r1 = k.rstart;
                 e1 = k.evt_en;
-                tl = M.pay[k.pidx].total_len;
+                tl = tm_pay_len(M, k.pidx);
             }
             const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
             const bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
@@ -335,7 +332,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
 
     if (mL != 0xFFFFFFFFu) {
         const uint32_t mid = m_id;
-        const ClusterPay mp = M.pay[mk.pidx];
+        const ClusterPay mp = tm_pay(M, mk.pidx);
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
         a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mp.total_len;
@@ -362,8 +359,8 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         wave_sync();
         if (lbL == mL && lbS == mS) {
             if (lane == 0) {
-                M.leaves[(size_t)mid * LEAF + mS] = nk;
-                if (mS == 0) { ClusterKey f = nk; f.pidx = mid; M.dir[mL] = f; }
+                tm_leaf_st(M, mid, mS, nk);
+                if (mS == 0) { ClusterKey f = nk; f.pidx = mid; tm_dir_st(M, mL, f); }
             }
             wave_sync();
         } else if (exists_at_lb) {
@@ -376,7 +373,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
         if (lane == 0) {
             ClusterPay np; np.ref_st = a.ref_st; np.rend = a.rend; np.evt_st = a.evt_st; np.total_len = a.total_len;
             np.pad[0] = np.pad[1] = 0;
-            M.pay[mk.pidx] = np;
+            tm_pay_st(M, mk.pidx, np);
         }
         wave_sync();
     } else {
@@ -395,7 +392,7 @@ UNC_SEED_FN void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len,
             if (lane == 0) {
                 ClusterPay np; np.ref_st = r2; np.rend = ref_en; np.evt_st = e2; np.total_len = ref_len;
                 np.pad[0] = np.pad[1] = 0;
-                M.pay[T.n_pay] = np;
+                tm_pay_st(M, T.n_pay, np);
             }
             T.n++;
             T.n_pay++;
@@ -474,7 +471,7 @@ __device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64
 
 // n <= 64*E: the whole sort in registers
 template <int E>
-UNC_SORT_FN void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+static __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     uint64_t a[E], b[E];
     block_load<E>(a, b, in, 0, n, lane);
     for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages<E>(a, b, 0, k, k >> 1, lane);
@@ -482,7 +479,7 @@ UNC_SORT_FN void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane
 }
 
 // n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
-UNC_SORT_FN void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+static __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -589,7 +586,7 @@ __device__ __forceinline__ void block_sort64(uint64_t (&a)[E], int lane) {
 
 // in: the children's SortKey records (.a = packed key); out: compact sorted uint64 array
 template <int E>
-UNC_SORT_FN void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+static __device__ void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
     uint64_t a[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -604,7 +601,7 @@ UNC_SORT_FN void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int l
     }
 }
 
-UNC_SORT_FN void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+static __device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -662,16 +659,14 @@ __device__ __forceinline__ uint32_t float_orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// PathBuffer::make_child, mapper.cpp:775-807.  The 23 prob sums are kept as a ring in the record, so a
-// child is the parent's ring copied verbatim plus ONE float appended (the slot of the dropped oldest sum
-// once the window is full): no shifting.  `last` = prob_sums_[length_], `second` = prob_sums_[1].
-struct ChildHdr { uint32_t moves, meta, wslot; float seed_prob, appended; };
+// PathBuffer::make_child, mapper.cpp:775-807.  The prob sums are not copied (see PathRec): a child needs its parent's
+// newest sum `last` = prob_sums_[length_] and, once the window is full, `second` = prob_sums_[1].
+struct ChildHdr { uint32_t moves, meta; float seed_prob, appended; };
 __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, float last, float second, uint64_t s, uint64_t e,
                                                uint32_t kmer, float prob, uint32_t move, const unc_params_t &P,
                                                uint32_t child_idx, uint32_t key_len_bits, SortKey &key) {
     const uint32_t PATH_MASK = (1u << SEED_LEN) - 1u, PATH_TAIL_MOVE = 1u << (SEED_LEN - 1);
     const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u, pstay = (pmeta >> META_STAY_SHIFT) & 255u;
-    const uint32_t head = (pmeta >> META_HEAD_SHIFT) & 31u;
     const uint32_t stay = 1u - move;
     const bool full = plen == (uint32_t)SEED_LEN;
     const uint32_t len = plen + (full ? 0u : 1u);
@@ -679,15 +674,13 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
     const uint32_t cstay = (pstay + stay) * stay;
     ChildHdr c;
     c.appended = __fadd_rn(last, prob);
-    // full window: (appended - prob_sums_[1]) / seed_len, and the dropped prob_sums_[0] is overwritten; else appended / len
-    // (head is 0 until the window fills).  One IEEE division serves both cases.
+    // full window: (appended - prob_sums_[1]) / seed_len, else appended / len.  One IEEE division serves both cases.
     const float num = full ? __fsub_rn(c.appended, second) : c.appended;
     c.seed_prob = __fdiv_rn(num, (float)(full ? (uint32_t)SEED_LEN : len));
     if (full) moves |= PATH_TAIL_MOVE;
-    const uint32_t nhead = full ? (head + 1u == PS_RING ? 0u : head + 1u) : head;
-    c.wslot = full ? head : head + len;
     c.moves = moves;
-    c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (pmeta & META_SA_CHECKED) | (nhead << META_HEAD_SHIFT);
+    c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (pmeta & META_SA_CHECKED) |
+             ((!full && len == (uint32_t)SEED_LEN) ? META_FIRST_FULL : 0u);
     // is_seed_valid(path_ended = false), mapper.cpp:842-855, known at creation time
     const uint32_t move_count = (uint32_t)__popc(moves);
     const bool seed_ok = len == P.seed_len && c.seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
@@ -698,13 +691,18 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
     return c;
 }
 
-// PathBuffer::make_source, mapper.cpp:751-772: only the fields a length-1 path ever reads
-__device__ __forceinline__ void write_source(PathRec *dst, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
-    uint4 *q = reinterpret_cast<uint4 *>(dst);
-    q[0] = (make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32)));
-    q[1] = (make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), 0u));
-    q[2] = (make_uint4(0u, __float_as_uint(prob), 0u, 0u));   // prob_sums_ = {0, prob}
+// PathBuffer::make_source, mapper.cpp:751-772: prob_sums_ = {0, prob}; the path has no ring yet and its newest sum is prob
+// (every slot of recent[] gets it: only the creating event's slot is ever read before it is overwritten)
+__device__ __forceinline__ void write_source(void *buf, uint32_t idx, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
+    const uint32_t o = idx << 6;
+    gst(buf, o, make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32)));
+    gst(buf, o + 16u, make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), RING_NONE));
+    gst(buf, o + 32u, make_float4(prob, prob, prob, prob));
 }
+
+// component j (uniform) of a float4
+__device__ __forceinline__ float f4_get(const float4 &v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+__device__ __forceinline__ void f4_set(float4 &v, uint32_t j, float x) { if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x; }
 
 #ifndef UNC_LB
 #define UNC_LB 3
@@ -714,31 +712,18 @@ template <bool PROF>
 __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
-    // one carved buffer for the per-pass staging of phase E (5.5 KB), reused as the source list in phase F: with the
-    // probs table the wavefront stays under 10 KB of LDS, i.e. 16 wavefronts per CU fit the 160 KB
+    // one carved buffer for the per-pass staging of phase E (7.5 KB), reused as the source list in phase F: with the
+    // probs table the wavefront stays under 12 KB of LDS, i.e. 13 wavefronts per CU fit the 160 KB (12 are resident)
     constexpr int RES_BITS = 30;                       // packed FM result: start << 30 | row count (0 = empty range)
-#ifndef UNC_E_OVERLAP
-    __shared__ uint64_t s_e[CAND_MAX + 2 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4];
+    __shared__ __attribute__((aligned(16))) uint64_t s_e[CAND_MAX + 2 * WAVE + 4 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4];
     uint64_t *const s_res = s_e;
     uint64_t *const s_pstart = s_e + CAND_MAX, *const s_pend = s_pstart + WAVE;
-    uint32_t *const s_pphys = reinterpret_cast<uint32_t *>(s_pend + WAVE), *const s_pmoves = s_pphys + WAVE, *const s_pmeta = s_pmoves + WAVE;
-    uint32_t *const s_cdesc = s_pmeta + WAVE;
+    float4 *const s_prec = reinterpret_cast<float4 *>(s_pend + WAVE), *const s_psec = s_prec + WAVE;   // parents' recent[] / second[]
+    uint32_t *const s_pmoves = reinterpret_cast<uint32_t *>(s_psec + WAVE), *const s_pmeta = s_pmoves + WAVE, *const s_pring = s_pmeta + WAVE;
+    uint32_t *const s_cdesc = s_pring + WAVE;
     uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
-#else
-    __shared__ uint64_t s_e[NKMER / 2];                // results | child descriptors | candidates (per-parent staging: o_* below)
-    uint64_t *const s_res = s_e;
-    uint32_t *const s_cdesc = reinterpret_cast<uint32_t *>(s_e + CAND_MAX);
-    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
-    static_assert(CAND_MAX * 8 + CHILD_MAX * 4 + CAND_MAX * 2 <= NKMER * 4, "staging must fit");
-#endif
     uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
     static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
-#ifdef UNC_E_OVERLAP
-    // experiment (off by default, not yet measured on the GPU): the FM loads of pass i are in flight while the children of
-    // pass i - 1 are written, so the per-parent staging of two passes is alive at once
-    __shared__ uint64_t o_pstart[2][WAVE], o_pend[2][WAVE];
-    __shared__ uint32_t o_pphys[2][WAVE], o_pmoves[2][WAVE], o_pmeta[2][WAVE], o_pprob[2][WAVE];
-#endif
 
     const int lane = lane_id();
     const uint64_t wave_t0 = (uint64_t)wall_clock64();
@@ -789,28 +774,21 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             __threadfence();   // the slot may have been parked by a wavefront on another CU
         }
 
-        PathRec *const buf0 = A.sc.paths + (size_t)slot * 2 * max_paths;
-        uint32_t *const ord0 = A.sc.order + (size_t)slot * 2 * max_paths;
-        SortKey *const ukeys = A.sc.keys + (size_t)slot * 2 * A.sc.keys_cap;
-        SortKey *const skeys = ukeys + A.sc.keys_cap;
-        SeedPath *const seedp = A.sc.seedp + (size_t)slot * A.sc.max_seed_paths;
-        uint64_t *const tasks = A.sc.sa_tasks + (size_t)slot * (WAVE * MAX_REP_COPY_LIMIT);
-        SlotState *const st = A.sc.state + slot;
+        // everything this read owns hangs off ONE uniform pointer; regions are 32-bit byte offsets (DevScratch)
+        char *const sb = A.sc.base + (size_t)slot * A.sc.slot_bytes;
+        const uint32_t ukeys_off = A.sc.off_keys, skeys_off = A.sc.off_keys + A.sc.keys_cap * (uint32_t)sizeof(SortKey);
+        const uint32_t seedp_off = A.sc.off_seedp, tasks_off = A.sc.off_tasks;
+        SlotState *const st = reinterpret_cast<SlotState *>(sb + A.sc.off_state);
         TrackerMem TM;
+        TM.base = sb;
+        TM.off_leaves = A.sc.off_cl_keys; TM.off_dir = A.sc.off_cl_dir; TM.off_cnt = A.sc.off_cl_cnt; TM.off_pay = A.sc.off_cl_pay;
         TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
-        TM.leaves = A.sc.cl_keys + (size_t)slot * TM.max_leaves * LEAF;
-        TM.dir = A.sc.cl_dir + (size_t)slot * TM.max_leaves;
-        TM.cnt = A.sc.cl_cnt + (size_t)slot * TM.max_leaves;
-        TM.pay = A.sc.cl_pay + (size_t)slot * A.sc.max_clusters;
 #ifdef UNC_BIG
         uint32_t big = restore ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
         if (big) {
-            const uint32_t bi = big - 1u;
+            TM.base = A.big.base + (size_t)(big - 1u) * A.big.buf_bytes;
+            TM.off_leaves = 0; TM.off_dir = A.big.off_dir; TM.off_cnt = A.big.off_cnt; TM.off_pay = A.big.off_pay;
             TM.max_leaves = A.big.max_clusters / 16; TM.max_pay = A.big.max_clusters;
-            TM.leaves = A.big.keys + (size_t)bi * TM.max_leaves * LEAF;
-            TM.dir = A.big.dir + (size_t)bi * TM.max_leaves;
-            TM.cnt = A.big.cnt + (size_t)bi * TM.max_leaves;
-            TM.pay = A.big.pay + (size_t)bi * A.big.max_clusters;
         }
 #endif
 
@@ -865,15 +843,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 id = bcast32(id, 0);
                 if (id != SCHED_EMPTY) {
                     TrackerMem B;
+                    B.base = A.big.base + (size_t)id * A.big.buf_bytes;
+                    B.off_leaves = 0; B.off_dir = A.big.off_dir; B.off_cnt = A.big.off_cnt; B.off_pay = A.big.off_pay;
                     B.max_leaves = A.big.max_clusters / 16; B.max_pay = A.big.max_clusters;
-                    B.leaves = A.big.keys + (size_t)id * B.max_leaves * LEAF;
-                    B.dir = A.big.dir + (size_t)id * B.max_leaves;
-                    B.cnt = A.big.cnt + (size_t)id * B.max_leaves;
-                    B.pay = A.big.pay + (size_t)id * A.big.max_clusters;
-                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc * LEAF; i += WAVE) B.leaves[i] = TM.leaves[i];
-                    for (uint32_t i = (uint32_t)lane; i < T.n_leaves; i += WAVE) B.dir[i] = TM.dir[i];
-                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc; i += WAVE) B.cnt[i] = TM.cnt[i];
-                    for (uint32_t i = (uint32_t)lane; i < T.n_pay; i += WAVE) B.pay[i] = TM.pay[i];
+                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc * LEAF; i += WAVE) gst(B.base, B.off_leaves + (i << 4), gld<ClusterKey>(TM.base, TM.off_leaves + (i << 4)));
+                    for (uint32_t i = (uint32_t)lane; i < T.n_leaves; i += WAVE) tm_dir_st(B, i, tm_dir(TM, i));
+                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc; i += WAVE) tm_cnt_st(B, i, tm_cnt(TM, i));
+                    for (uint32_t i = (uint32_t)lane; i < T.n_pay; i += WAVE) tm_pay_st(B, i, tm_pay(TM, i));
                     TM = B;
                     big = id + 1u;
                     wave_sync();
@@ -887,11 +863,6 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             // ---------------- P: match log-probs ----------------
             uint64_t tk = PROF ? (uint64_t)clock64() : 0ull, tn = 0;
 #define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
-#ifdef UNC_PROFILE_FINE
-#define PHASE_FINE(i) PHASE_END(i)
-#else
-#define PHASE_FINE(i) (void)tn
-#endif
             const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
             if (event_i + 1 < n_events) next_mean = MEAN_AT(event_i + 1);
 #pragma unroll 4
@@ -904,33 +875,34 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             }
             wave_sync();
 
-            const PathRec *par = buf0 + (size_t)cur * max_paths;
-            PathRec *chd = buf0 + (size_t)(cur ^ 1u) * max_paths;
-            const uint32_t *pord = ord0 + (size_t)cur * max_paths;
-            uint32_t *nord = ord0 + (size_t)(cur ^ 1u) * max_paths;
+            // byte offsets (inside the slot) of this event's parent / child records and parent-order lists
+            const uint32_t par_off = A.sc.off_paths + cur * (max_paths << 6), chd_off = A.sc.off_paths + (cur ^ 1u) * (max_paths << 6);
+            const uint32_t pord_off = A.sc.off_order + cur * (max_paths << 2), nord_off = A.sc.off_order + (cur ^ 1u) * (max_paths << 2);
+            const uint32_t g_sl = event_i & (MAT_PERIOD - 1u), p_sl = (event_i - 1u) & (MAT_PERIOD - 1u);   // recent[] / second[] slots
 
             PHASE_END(0);
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
             bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort below)
             // parent index list and record headers are fetched one / two passes ahead of their use
-            uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(pord, (uint32_t)lane << 2) : 0u;
-            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(pord, ((uint32_t)lane + WAVE) << 2) : 0u;
+            uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
+            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
             uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
             if ((uint32_t)lane < n_parents) {
-                q0c = gld<uint4>(par, phys_cur << 7); q1c = gld<uint4>(par, (phys_cur << 7) + 16u);
+                q0c = gld<uint4>(sb, par_off + (phys_cur << 6)); q1c = gld<uint4>(sb, par_off + (phys_cur << 6) + 16u);
             }
-#ifndef UNC_E_OVERLAP
             for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
                 const uint32_t pi = base + (uint32_t)lane;
                 const bool have = pi < n_parents;
-                const uint32_t phys = phys_cur;
                 const uint4 q0 = q0c, q1 = q1c;
+                // the sums this parent hands down: needed only when its children are written, after the FM round trip
+                float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f), q3 = q2;
+                if (have) { q2 = gld<float4>(sb, par_off + (phys_cur << 6) + 32u); q3 = gld<float4>(sb, par_off + (phys_cur << 6) + 48u); }
                 phys_cur = phys_nxt;
                 if (pi + WAVE < n_parents) {
-                    q0c = gld<uint4>(par, phys_nxt << 7); q1c = gld<uint4>(par, (phys_nxt << 7) + 16u);
+                    q0c = gld<uint4>(sb, par_off + (phys_nxt << 6)); q1c = gld<uint4>(sb, par_off + (phys_nxt << 6) + 16u);
                 }
-                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(pord, (pi + 2 * WAVE) << 2);
+                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * WAVE) << 2));
                 uint32_t pmoves = 0, pmeta = 0;
                 uint64_t pstart = 1, pend = 1;
                 float pprob = 0.0f;
@@ -948,7 +920,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
                 uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
                 if (!have) mask = 0;
-                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pphys[lane] = phys; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta;
+                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta; s_pring[lane] = q1.w;
                 const uint32_t ncand = (uint32_t)__popc(mask);
                 uint32_t ctot;
                 const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
@@ -959,7 +931,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
                 }
                 wave_sync();
-                PHASE_FINE(8);
+                PHASE_END(8);
                 // FM look-ups, every lane busy
                 for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
                     const uint32_t ci = c0 + (uint32_t)lane;
@@ -971,7 +943,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     }
                 }
                 wave_sync();
-                PHASE_FINE(9);
+                PHASE_END(9);
                 // children per parent, in the reference's order: stay, then bases 0..3
                 // bit j: j-th candidate of this lane has a non-empty range (four unconditional reads; the staging buffer
                 // extends past the result slots, and whatever lies beyond this lane's candidates is masked off)
@@ -1004,6 +976,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         }
                     }
                 }
+                s_prec[lane] = q2; s_psec[lane] = q3;
                 // dead ends -> update_seeds(prev_path, true), :513-519 / is_seed_valid :842-863
                 bool ended_seed = false;
                 uint32_t e_count = 0, e_mc = 0;
@@ -1024,30 +997,23 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     if (ended_seed) {
                         if (pos < A.sc.max_seed_paths) {
                             SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
-                            seedp[pos] = sp;
+                            gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
                         }
                     }
                     n_seedp += (uint32_t)__popcll(em);
                 }
                 wave_sync();
-                PHASE_FINE(10);
-                // one lane per child
+                PHASE_END(10);
+                // one lane per child: everything it needs of its parent sits in LDS, the 64-byte record and the sort key go out
                 for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
                     const uint32_t li = l0 + (uint32_t)lane;
                     if (li < nwrite) {
                         const uint32_t d = s_cdesc[li];
                         const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
-                        const uint32_t po = s_pphys[pl] << 7;     // byte offset of the parent's record
                         const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
-                        const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
-#ifndef UNC_LAZY_CHILD
-                        // the parent's ring (6 x 16 B) plus the two sums the child needs, all in one round trip
-                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
-                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
-#endif
-                        uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
-                        uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
-                        const float last = gld<float>(par, po + 32u + (sl << 2)), second = gld<float>(par, po + 32u + (s2 << 2));
+                        float4 rec = s_prec[pl];
+                        const float4 sec = s_psec[pl];
+                        const float last = f4_get(rec, p_sl), second = f4_get(sec, g_sl);
                         const uint32_t pk = pmt & META_KMER_MASK;
                         uint64_t cs, ce;
                         uint32_t ck, mv;
@@ -1064,205 +1030,19 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         SortKey key;
                         const uint32_t gi = nchild + li;
                         const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
-                        const uint32_t co = gi << 7;
-                        gst(chd, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
-                        gst(chd, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
-#ifndef UNC_LAZY_CHILD
-                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
-                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
-                        gst(chd, co + 32u + (c.wslot << 2), c.appended);   // same lane, same address as the copy above: program order
-#else
-                        // only what the walk needs; the ring is copied for the survivors after it (phase M): where the parent's
-                        // ring is, which slot takes the new sum, and the sum
-                        gst(chd, co + 32u, make_uint4(po, c.wslot, __float_as_uint(c.appended), 0u));
-#endif
-                        gst(ukeys, gi << 4, key);
+                        f4_set(rec, g_sl, c.appended);
+                        const uint32_t co = chd_off + (gi << 6);
+                        gst(sb, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
+                        gst(sb, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, s_pring[pl]));
+                        gst(sb, co + 32u, rec);
+                        gst(sb, co + 48u, sec);
+                        gst(sb, ukeys_off + (gi << 4), key);
                     }
                 }
                 nchild += nwrite;
                 wave_sync();
-                PHASE_FINE(11);
+                PHASE_END(11);
             }
-#else
-            // children of a finished pass: one lane per child (shared by both loop forms below through the macro-free lambda)
-            uint32_t pend_n = 0, pend_base = 0, pend_buf = 0;
-            auto emit_children = [&](uint32_t nwr, uint32_t cbase, uint32_t pb) {
-                for (uint32_t l0 = 0; l0 < nwr; l0 += WAVE) {
-                    const uint32_t li = l0 + (uint32_t)lane;
-                    if (li < nwr) {
-                        const uint32_t d = s_cdesc[li];
-                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
-                        const uint32_t po = o_pphys[pb][pl] << 7;
-                        const uint32_t pmt = o_pmeta[pb][pl], pmv = o_pmoves[pb][pl];
-                        const uint32_t plen = (pmt >> META_LEN_SHIFT) & 31u, head = (pmt >> META_HEAD_SHIFT) & 31u;
-                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
-                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
-                        uint32_t sl = head + plen; if (sl >= PS_RING) sl -= PS_RING;
-                        uint32_t s2 = head + 1u; if (s2 >= PS_RING) s2 -= PS_RING;
-                        const float last = gld<float>(par, po + 32u + (sl << 2)), second = gld<float>(par, po + 32u + (s2 << 2));
-                        const uint32_t pk = pmt & META_KMER_MASK;
-                        uint64_t cs, ce;
-                        uint32_t ck, mv;
-                        if (type == 0) { cs = o_pstart[pb][pl]; ce = o_pend[pb][pl]; ck = pk; mv = 0; }
-                        else {
-                            const uint64_t pr = s_res[ci];
-                            cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
-                            ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
-                        }
-                        if (klb && cs == ce) {
-                            const ulonglong2 kr = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[ck];
-                            if (cs == kr.x || cs == kr.y) bchild = true;
-                        }
-                        SortKey key;
-                        const uint32_t gi = cbase + li;
-                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
-                        const uint32_t co = gi << 7;
-                        gst(chd, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
-                        gst(chd, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, 0u));
-                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
-                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
-                        gst(chd, co + 32u + (c.wslot << 2), c.appended);
-                        gst(ukeys, gi << 4, key);
-                    }
-                }
-            };
-            uint32_t obuf = 0;
-            for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
-                const uint32_t pi = base + (uint32_t)lane;
-                const bool have = pi < n_parents;
-                const uint32_t phys = phys_cur;
-                const uint4 q0 = q0c, q1 = q1c;
-                phys_cur = phys_nxt;
-                if (pi + WAVE < n_parents) {
-                    q0c = gld<uint4>(par, phys_nxt << 7); q1c = gld<uint4>(par, (phys_nxt << 7) + 16u);
-                }
-                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(pord, (pi + 2 * WAVE) << 2);
-                // ---- A: candidates of this pass
-                uint32_t pmoves = 0, pmeta = 0;
-                uint64_t pstart = 1, pend = 1;
-                float pprob = 0.0f;
-                if (have) {
-                    pstart = ((uint64_t)q0.y << 32) | q0.x;
-                    pend = ((uint64_t)q0.w << 32) | q0.z;
-                    pmoves = q1.x; pprob = __uint_as_float(q1.y); pmeta = q1.z;
-                }
-                const float thr = __shfl(thr_lane, __clzll((long long)(pend - pstart + 1)));
-                const uint32_t kmer = pmeta & META_KMER_MASK;
-                const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
-                const bool stay_ok = have && stays < P.max_consec_stay && s_probs[kmer] >= thr;
-                const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
-                uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
-                if (!have) mask = 0;
-                o_pstart[obuf][lane] = pstart; o_pend[obuf][lane] = pend; o_pphys[obuf][lane] = phys; o_pmoves[obuf][lane] = pmoves;
-                o_pmeta[obuf][lane] = pmeta; o_pprob[obuf][lane] = __float_as_uint(pprob);
-                const uint32_t ncand = (uint32_t)__popc(mask);
-                uint32_t ctot;
-                const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
-                {
-                    uint32_t w = coff;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b)
-                        if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
-                }
-                // everything the slot assignment needs later travels in one word (the rest is re-read from the staging)
-                const uint32_t pinfo = mask | (stay_ok ? 16u : 0u) | (have ? 32u : 0u) | (coff << 8);
-                wave_sync();
-                // ---- B: first round of FM look-ups issued ...
-                FmPending fp;
-                fp.fl = 0; fp.c = 0; fp.kk = fp.ll = 0;
-                fp.bl.cnt = 0; fp.bl.lo = fp.bl.hi = make_uint4(0u, 0u, 0u, 0u);
-                fp.bk = fp.bl;
-                const bool fm0 = (uint32_t)lane < ctot;
-                if (fm0) {
-                    const uint32_t cd = s_cand[lane];
-                    fp = fm_issue(ix, o_pstart[obuf][cd >> 2], o_pend[obuf][cd >> 2], cd & 3u);
-                }
-                // ---- C: ... while the previous pass's children are written
-                if (pend_n) emit_children(pend_n, pend_base, pend_buf);
-                pend_n = 0;
-                wave_sync();
-                // ---- D: ranges of this pass
-                if (fm0) {
-                    uint64_t ns, ne;
-                    fm_finish(ix, fp, &ns, &ne);
-                    s_res[lane] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
-                }
-                for (uint32_t c0 = WAVE; c0 < ctot; c0 += WAVE) {
-                    const uint32_t ci = c0 + (uint32_t)lane;
-                    if (ci < ctot) {
-                        const uint32_t cd = s_cand[ci];
-                        uint64_t ns, ne;
-                        fm_get_neighbor(ix, o_pstart[obuf][cd >> 2], o_pend[obuf][cd >> 2], cd & 3u, &ns, &ne);
-                        s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
-                    }
-                }
-                wave_sync();
-                // ---- E: child slots of this pass (same rules as the plain loop)
-                {
-                    const uint32_t emask = pinfo & 15u, ecoff = pinfo >> 8, encand = (uint32_t)__popc(emask);
-                    const bool ehave = (pinfo & 32u) != 0, estay = (pinfo & 16u) != 0;
-                    uint32_t vmask = (s_res[ecoff] != 0 ? 1u : 0u) | (s_res[ecoff + 1] != 0 ? 2u : 0u) | (s_res[ecoff + 2] != 0 ? 4u : 0u) |
-                                     (s_res[ecoff + 3] != 0 ? 8u : 0u);
-                    vmask &= (1u << encand) - 1u;
-                    const uint32_t nch = (estay ? 1u : 0u) + (uint32_t)__popc(vmask);
-                    uint32_t chtot;
-                    const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
-                    const uint32_t room = max_paths - nchild;
-                    const uint32_t nwrite = chtot < room ? chtot : room;
-                    const bool visited = ehave && choff < room;
-                    if (choff + (estay ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += encand;
-                    else
-                        for (uint32_t j = 0; j < encand; ++j)
-                            if (choff + (estay ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
-                    {
-                        uint32_t w = choff;
-                        if (estay) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
-                        uint32_t jj = 0;
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            if (emask & (1u << b)) {
-                                if (vmask & (1u << jj)) {
-                                    if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((ecoff + jj) << 9);
-                                    ++w;
-                                }
-                                ++jj;
-                            }
-                        }
-                    }
-                    const uint32_t emeta = o_pmeta[obuf][lane];
-                    bool ended_seed = false;
-                    uint32_t e_count = 0, e_mc = 0;
-                    const uint64_t estart = o_pstart[obuf][lane];
-                    if (visited && nch == 0 && !(emeta & META_SA_CHECKED)) {
-                        const uint64_t eplen_fm = o_pend[obuf][lane] - estart + 1;
-                        const uint32_t emoves = o_pmoves[obuf][lane];
-                        const float eprob = __uint_as_float(o_pprob[obuf][lane]);
-                        const uint32_t plen = (emeta >> META_LEN_SHIFT) & 31u;
-                        const uint32_t mc = (uint32_t)__popc(emoves);
-                        const bool base_ok = plen == P.seed_len && eprob >= P.min_seed_prob;
-                        const bool uniq = eplen_fm == 1 && (emoves & 1u) == 1u &&
-                                          (float)(plen - mc) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
-                        const bool rep = eplen_fm <= (uint64_t)P.max_rep_copy && mc >= P.min_rep_len;
-                        ended_seed = base_ok && (uniq || rep);
-                        e_count = (uint32_t)eplen_fm;
-                        e_mc = mc;
-                    }
-                    const uint64_t em = __ballot(ended_seed);
-                    const uint32_t pos = n_seedp + (uint32_t)prefix_popc(em);
-                    if (ended_seed && pos < A.sc.max_seed_paths) {
-                        SeedPath sp; sp.start = estart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
-                        seedp[pos] = sp;
-                    }
-                    n_seedp += (uint32_t)__popcll(em);
-                    pend_n = nwrite; pend_base = nchild; pend_buf = obuf;
-                    nchild += nwrite;
-                }
-                obuf ^= 1u;
-                wave_sync();
-            }
-            if (pend_n) emit_children(pend_n, pend_base, pend_buf);
-            wave_sync();
-#endif
             if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
 
@@ -1271,6 +1051,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             const uint32_t n = nchild;
             uint32_t n_surv = 0, n_src = 0;
             if (n > 0) {
+                SortKey *const ukeys = reinterpret_cast<SortKey *>(sb + ukeys_off), *const skeys = reinterpret_cast<SortKey *>(sb + skeys_off);
                 uint64_t *const skeys64 = reinterpret_cast<uint64_t *>(skeys);
                 uint32_t kl = klb;     // key mode of THIS event
                 if (kl) {
@@ -1337,7 +1118,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     const uint32_t i = base + (uint32_t)lane;
                     const bool have = i < n;
                     const bool has_next = i + 1 < n;
-                    uint64_t start, end, nstart, sb;     // sb: info word of the child that survives at this position
+                    uint64_t start, end, nstart, sb_;     // sb_: info word of the child that survives at this position
                     uint32_t kmer, nkmer;
                     bool dup;
                     ulonglong2 krc = make_ulonglong2(1ull, 0ull);
@@ -1366,12 +1147,12 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
                         if (lane == 0) pr = carry_range;
                         const bool rhead = !have || ri != pr;
-                        sb = seg_incl_max64(bi, rhead);
+                        sb_ = seg_incl_max64(bi, rhead);
                         const uint64_t rheads = __ballot(rhead);
-                        if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb) sb = carry_w;
+                        if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb_) sb_ = carry_w;
                         const uint32_t nvv = n - base < WAVE ? n - base : WAVE;
                         carry_range = bcast64(ri, (int)nvv - 1);
-                        carry_w = bcast64(sb, (int)nvv - 1);
+                        carry_w = bcast64(sb_, (int)nvv - 1);
                     } else {
                         SortKey ki, kn;
                         ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
@@ -1382,9 +1163,9 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
                         nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
                         dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
-                        sb = ki.b;                               // sorted by seed_prob inside the run: the last one survives
+                        sb_ = ki.b;                              // sorted by seed_prob inside the run: the last one survives
                     }
-                    const uint32_t idx = (uint32_t)(sb >> 16) & 0xFFFFu;
+                    const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
                     uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
                     if (lane == 0) pk = carry_kmer;
                     const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
@@ -1411,24 +1192,25 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     const uint32_t q0 = n_src + soff;                      // sources appended before this child
                     const bool not_full0 = q0 < room;                      // next_path != end at step A
                     if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
-                    if (a_valid && not_full0) write_source(chd + n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
+                    if (a_valid && not_full0) write_source(sb + chd_off, n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
                     const uint32_t qc = q0 + (a_valid ? 1u : 0u);
-                    if (c_valid && qc < room) write_source(chd + n + qc, c_s, c_e, kmer, s_probs[kmer]);
+                    if (c_valid && qc < room) write_source(sb + chd_off, n + qc, c_s, c_e, kmer, s_probs[kmer]);
                     // survivors keep sorted order in the next parent list
                     const bool surv = have && !dup;
                     const uint64_t sm = __ballot(surv);
-                    if (surv) nord[n_surv + (uint32_t)prefix_popc(sm)] = idx;
+                    if (surv) gst(sb, nord_off + ((n_surv + (uint32_t)prefix_popc(sm)) << 2), idx);
                     n_surv += (uint32_t)__popcll(sm);
                     // update_seeds(child, false), :601 -- validity was decided at creation
-                    const bool sv = surv && (sb & KEYB_SEED_FLAG);
+                    const bool sv = surv && (sb_ & KEYB_SEED_FLAG);
                     const uint64_t svm = __ballot(sv);
                     if (sv) {
                         const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
-                        atomicOr(&chd[idx].meta, META_SA_CHECKED);   // path.sa_checked_ = true (no value returned: no round trip)
+                        // path.sa_checked_ = true (no value returned: no round trip)
+                        atomicOr(reinterpret_cast<uint32_t *>(sb + chd_off + (idx << 6) + 24u), META_SA_CHECKED);
                         if (pos < A.sc.max_seed_paths) {
                             SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
-                            sp.ref_len = (uint32_t)(sb >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
-                            seedp[pos] = sp;
+                            sp.ref_len = (uint32_t)(sb_ >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
+                            gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
                         }
                     }
                     n_seedp += (uint32_t)__popcll(svm);
@@ -1443,32 +1225,6 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             }
             wave_sync();
-#ifdef UNC_LAZY_CHILD
-            // ---------------- M: the survivors' records get their parents' rings (experiment, off by default) ----------------
-            {
-                uint32_t id0 = (uint32_t)lane < n_surv ? nord[lane] : 0u;
-                uint32_t id1 = (uint32_t)lane + WAVE < n_surv ? nord[lane + WAVE] : 0u;
-                uint4 d0 = make_uint4(0u, 0u, 0u, 0u);
-                if ((uint32_t)lane < n_surv) d0 = gld<uint4>(chd, (id0 << 7) + 32u);
-                for (uint32_t k0 = 0; k0 < n_surv; k0 += WAVE) {
-                    const uint32_t k = k0 + (uint32_t)lane;
-                    const uint32_t idx = id0;
-                    const uint4 d = d0;
-                    id0 = id1;
-                    if (k + WAVE < n_surv) d0 = gld<uint4>(chd, (id1 << 7) + 32u);
-                    if (k + 2 * WAVE < n_surv) id1 = nord[k + 2 * WAVE];
-                    if (k < n_surv) {
-                        const uint32_t po = d.x, co = idx << 7;
-                        const uint4 r2 = gld<uint4>(par, po + 32u), r3 = gld<uint4>(par, po + 48u), r4 = gld<uint4>(par, po + 64u),
-                                    r5 = gld<uint4>(par, po + 80u), r6 = gld<uint4>(par, po + 96u), r7 = gld<uint4>(par, po + 112u);
-                        gst(chd, co + 32u, r2); gst(chd, co + 48u, r3); gst(chd, co + 64u, r4); gst(chd, co + 80u, r5);
-                        gst(chd, co + 96u, r6); gst(chd, co + 112u, r7);
-                        gst(chd, co + 32u + (d.y << 2), d.z);          // same lane, after the copy: program order
-                    }
-                }
-            }
-            wave_sync();
-#endif
 
             PHASE_END(3);
             // ---------------- F: remaining full-range sources, :605-624 ----------------
@@ -1498,44 +1254,45 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 if (!(lane & 1)) s_flags[lane >> 1] = newflags | (other << 16);
                 for (uint32_t q = (uint32_t)lane; q < ent - ent0; q += WAVE) {
                     const uint32_t k = s_list[q];
-                    write_source(chd + ent0 + q, ix.kmer_ranges[2 * k], ix.kmer_ranges[2 * k + 1], k, s_probs[k]);
+                    write_source(sb + chd_off, ent0 + q, ix.kmer_ranges[2 * k], ix.kmer_ranges[2 * k + 1], k, s_probs[k]);
                 }
             }
             wave_sync();
             const uint32_t nsrc_total = ent - n;
-            for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) nord[n_surv + q] = n + q;
+            for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) gst(sb, nord_off + ((n_surv + q) << 2), n + q);
             n_parents = n_surv + nsrc_total;
             cur ^= 1u;
             wave_sync();
 
             PHASE_END(4);
             // ---------------- T: seeds ----------------
-            for (uint32_t sb = 0; sb < n_seedp && !T.status; sb += WAVE) {
-                const uint32_t si = sb + (uint32_t)lane;
+            for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
+                const uint32_t si = sb0 + (uint32_t)lane;
                 SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
-                if (si < n_seedp) sp = seedp[si];
+                if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
                 uint32_t ttot;
                 const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
-                for (uint32_t j = 0; j < sp.count; ++j) tasks[toff + j] = sp.start + j;
+                for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), sp.start + j);
                 wave_sync();
                 for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
                     const uint32_t ti = t0 + (uint32_t)lane;
                     if (ti < ttot) {
                         uint32_t lf;
-                        const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, tasks[ti], &lf) : fm_sa(ix, tasks[ti], &lf);
-                        tasks[ti] = ix.seq_len - sa;    // sa_end, mapper.cpp:678
+                        const uint64_t row = gld<uint64_t>(sb, tasks_off + (ti << 3));
+                        const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
+                        gst(sb, tasks_off + (ti << 3), ix.seq_len - sa);    // sa_end, mapper.cpp:678
                         c_sa++;
                         c_lf += lf;
                     }
                 }
                 wave_sync();
                 PHASE_END(5);
-                const uint32_t nl = n_seedp - sb < WAVE ? n_seedp - sb : WAVE;
+                const uint32_t nl = n_seedp - sb0 < WAVE ? n_seedp - sb0 : WAVE;
                 for (uint32_t l = 0; l < nl; ++l) {
                     const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
                     const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
                     for (uint32_t j = 0; j < cnt; ++j) {
-                        const uint64_t sa_end = uniform64(tasks[o + j]);
+                        const uint64_t sa_end = uniform64(gld<uint64_t>(sb, tasks_off + ((o + j) << 3)));
                         add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane);
                     }
                 }
@@ -1553,7 +1310,48 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             }
             if (T.status) { done = 2; }
             else if (conf) { done = 1; }
-            else event_i++;
+            else {
+                // ---------------- M: every 4th event the rings of the live paths are brought up to date (PathRec) ----------------
+                // Events g-3 .. g have left their sums in recent[0..3]; they go into ring slots (g-3 .. g) % 23 of a copy of
+                // the lineage's previous ring (the other half of the ring pool), and second[0..3] for the children of events
+                // g+1 .. g+4 are the ring's entries of events g-21 .. g-18.  A path without a ring is younger than four
+                // events: only its recent sums exist, nothing older is ever read.
+                if (g_sl == MAT_PERIOD - 1u) {
+                    const uint32_t op = (event_i >> 2) & 1u;
+                    const uint32_t oring_off = A.sc.off_rings + op * max_paths * (RING_FLOATS * 4u);
+                    const uint32_t nring_off = A.sc.off_rings + (op ^ 1u) * max_paths * (RING_FLOATS * 4u);
+                    const uint32_t rec_off = A.sc.off_paths + cur * (max_paths << 6);        // the next event's parents
+                    const uint32_t lst_off = A.sc.off_order + cur * (max_paths << 2);
+                    const uint32_t w0 = ((event_i - 3u) % PS_RING) << 2, w1 = ((event_i - 2u) % PS_RING) << 2,
+                                   w2 = ((event_i - 1u) % PS_RING) << 2, w3 = (event_i % PS_RING) << 2;
+                    const uint32_t r0 = ((event_i + 2u) % PS_RING) << 2, r1 = ((event_i + 3u) % PS_RING) << 2,
+                                   r2 = ((event_i + 4u) % PS_RING) << 2, r3 = ((event_i + 5u) % PS_RING) << 2;
+                    for (uint32_t k0 = 0; k0 < n_parents; k0 += WAVE) {
+                        const uint32_t k = k0 + (uint32_t)lane;
+                        if (k < n_parents) {
+                            const uint32_t idx = gld<uint32_t>(sb, lst_off + (k << 2));
+                            const uint32_t ro = rec_off + (idx << 6);
+                            const uint32_t oring = gld<uint32_t>(sb, ro + 28u);
+                            const float4 rc = gld<float4>(sb, ro + 32u);
+                            const uint32_t no = nring_off + idx * (RING_FLOATS * 4u);
+                            if (oring != RING_NONE) {
+                                const uint32_t oo = oring_off + oring * (RING_FLOATS * 4u);
+                                const uint4 a0 = gld<uint4>(sb, oo), a1 = gld<uint4>(sb, oo + 16u), a2 = gld<uint4>(sb, oo + 32u),
+                                            a3 = gld<uint4>(sb, oo + 48u), a4 = gld<uint4>(sb, oo + 64u), a5 = gld<uint4>(sb, oo + 80u);
+                                float4 sc2;
+                                sc2.x = gld<float>(sb, oo + r0); sc2.y = gld<float>(sb, oo + r1); sc2.z = gld<float>(sb, oo + r2); sc2.w = gld<float>(sb, oo + r3);
+                                gst(sb, no, a0); gst(sb, no + 16u, a1); gst(sb, no + 32u, a2); gst(sb, no + 48u, a3); gst(sb, no + 64u, a4); gst(sb, no + 80u, a5);
+                                gst(sb, ro + 48u, sc2);
+                            }
+                            // same lane, after the copy: program order
+                            gst(sb, no + w0, rc.x); gst(sb, no + w1, rc.y); gst(sb, no + w2, rc.z); gst(sb, no + w3, rc.w);
+                            gst(sb, ro + 28u, idx);
+                        }
+                    }
+                    wave_sync();
+                }
+                event_i++;
+            }
             PHASE_END(7);
         }
 

@@ -12,23 +12,36 @@ constexpr int NKMER = UNC_NKMER;
 constexpr uint32_t KMASK = NKMER - 1;
 constexpr int MAX_REP_COPY_LIMIT = 64;
 
-// One path of the forest = exactly one 128-byte line in HBM (Mapper::PathBuffer, mapper.hpp:139-196).
+// One path of the forest (Mapper::PathBuffer, mapper.hpp:139-196) = one 64-byte record.  The 23 float prefix sums
+// (prob_sums_) are NOT part of it: the reference only ever reads prob_sums_[length_] (the newest sum) and, once the
+// window is full, prob_sums_[1] (the sum that drops out next).  Sums are addressed by the event t that produced them:
+//   recent[t & 3]  the sums of this path's lineage for the events since the last materialisation (every 4th event),
+//                  recent[g & 3] of a path created by event g being its own newest sum;
+//   second[t & 3]  the sum of event t - 22, i.e. what a child created by event t subtracts (copied down the lineage);
+//   ring           index of the lineage's 23-entry ring (slot t % 23 = sum of event t) in the slot's ring pool.
+// After every 4th event the rings of the paths that are still alive are brought up to date (k_map phase M): old ring +
+// the four recent sums -> new ring, and the next four `second`s are read off it.  Children that the walk prunes (45 %)
+// never touch a ring, and extending a path writes 64 bytes instead of 128.
 struct alignas(16) PathRec {
     uint64_t start, end;        // fm_range_
     uint32_t moves;             // event_moves_ (22-bit shift register, LSB = newest event)
     float seed_prob;            // seed_prob_
-    uint32_t meta;              // kmer | length | consec_stays | sa_checked, see below
-    uint32_t pad;
-    float ps[24];               // prob_sums_[0..22] as a ring: logical entry j sits in slot (head + j) % 23
+    uint32_t meta;              // kmer | length | consec_stays | sa_checked | first_full, see below
+    uint32_t ring;              // ring pool index (RING_NONE: the path is younger than the last materialisation)
+    float recent[4];
+    float second[4];
 };
-static_assert(sizeof(PathRec) == 128, "PathRec must be one cache line");
+static_assert(sizeof(PathRec) == 64, "PathRec must be half a cache line");
 
 constexpr uint32_t META_KMER_MASK = 0x3FFu;
 constexpr int META_LEN_SHIFT = 10;       // 5 bits
 constexpr int META_STAY_SHIFT = 16;      // 8 bits
 constexpr uint32_t META_SA_CHECKED = 1u << 24;
-constexpr int META_HEAD_SHIFT = 25;      // 5 bits: ring slot of prob_sums_[0]
-constexpr uint32_t PS_RING = UNC_SEED_LEN + 1;
+constexpr uint32_t META_FIRST_FULL = 1u << 25;   // length_ reached seed_len with this event: prob_sums_[0] is still the initial 0
+constexpr uint32_t PS_RING = UNC_SEED_LEN + 1;   // entries per ring
+constexpr uint32_t RING_FLOATS = 24;             // floats per ring in the pool (96 bytes, 16-byte aligned)
+constexpr uint32_t RING_NONE = 0xFFFFFFFFu;
+constexpr uint32_t MAT_PERIOD = 4;               // events between materialisations (= entries of recent[] / second[])
 
 // Sort key of one child (operator< of mapper.cpp:866-871 made total by creation order):
 //   a = fm_range_.start << 30 | (fm_range_.length - 1)      (start asc, then end asc)
@@ -83,12 +96,12 @@ struct alignas(64) SchedCtl {
 // quarters full and hands it back when it is done; ids travel through a ring like the slots'.  When none is free, a
 // time-sliced read waits parked; otherwise it carries on and, should it overflow after all, is re-mapped by the host.
 struct DevBig {
-    ClusterKey *keys, *dir;      // [n_big][max_clusters / 16][64], [n_big][max_clusters / 16]
-    uint32_t *cnt;               // [n_big][max_clusters / 16]
-    ClusterPay *pay;             // [n_big][max_clusters]
+    char *base;                  // buffer b at base + b * buf_bytes: leaves | directory | counts | payloads
+    uint64_t buf_bytes;
+    uint32_t off_dir, off_cnt, off_pay, max_clusters;
     SchedQueue *q;
     SchedCell *cells;
-    uint32_t cap_mask, n_big, max_clusters, pad;
+    uint32_t cap_mask, n_big;
 };
 
 struct DevSched {
@@ -112,18 +125,25 @@ struct DevIndex {
     float thresholds[64];
 };
 
+// Per-slot scratch: ONE allocation, slot s at base + s * slot_bytes, regions at fixed byte offsets inside a slot (all
+// below 4 GB, so kernels address them as uniform base + 32-bit offset).  Layout computed by scratch_layout().
 struct DevScratch {
-    PathRec *paths;        // [n_slots][2][max_paths]
-    uint32_t *order;       // [n_slots][2][max_paths]
-    SortKey *keys;         // [n_slots][2][keys_cap]   (unsorted | sorted)
-    SeedPath *seedp;       // [n_slots][max_seed_paths]
-    uint64_t *sa_tasks;    // [n_slots][WAVE * MAX_REP_COPY_LIMIT]
-    ClusterKey *cl_keys;   // [n_slots][max_clusters / 16][64]: leaves of the seed-cluster set (16 bytes per key)
-    ClusterKey *cl_dir;    // [n_slots][max_clusters / 16]: sorted directory (first key + leaf id)
-    uint32_t *cl_cnt;      // [n_slots][max_clusters / 16]: keys per leaf
-    ClusterPay *cl_pay;    // [n_slots][max_clusters]
-    SlotState *state;      // [n_slots]
+    char *base;
+    uint64_t slot_bytes;
     uint32_t max_paths, keys_cap, max_seed_paths, max_clusters;
+    // region offsets inside a slot
+    uint32_t off_paths;    // PathRec [2][max_paths]
+    uint32_t off_rings;    // float   [2][max_paths][RING_FLOATS]
+    uint32_t off_order;    // u32     [2][max_paths]
+    uint32_t off_keys;     // SortKey [2][keys_cap]   (unsorted | sorted)
+    uint32_t off_seedp;    // SeedPath[max_seed_paths]
+    uint32_t off_tasks;    // u64     [WAVE * MAX_REP_COPY_LIMIT]
+    uint32_t off_cl_keys;  // ClusterKey [max_clusters / 16][64]: leaves of the seed-cluster set (16 bytes per key)
+    uint32_t off_cl_dir;   // ClusterKey [max_clusters / 16]: sorted directory (first key + leaf id)
+    uint32_t off_cl_cnt;   // u32     [max_clusters / 16]: keys per leaf
+    uint32_t off_cl_pay;   // ClusterPay [max_clusters]
+    uint32_t off_state;    // SlotState
+    uint32_t pad_;
 };
 
 // ---- chunked (realtime) path: state a Mapper keeps per channel between chunks (mapper.hpp:209-226) ----

@@ -418,13 +418,13 @@ struct unc_mapper {
 };
 
 static void free_scratch(DevScratch &sc) {
-    void *ptrs[] = {sc.paths, sc.order, sc.keys, sc.seedp, sc.sa_tasks, sc.cl_keys, sc.cl_dir, sc.cl_cnt, sc.cl_pay, sc.state};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (sc.base) (void)hipFree(sc.base);
     memset(&sc, 0, sizeof sc);
 }
 
-static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, uint32_t max_clusters, uint32_t max_seed_paths,
-                         size_t *bytes_out) {
+// Regions of one slot (DevScratch), each 256-byte aligned; everything below 4 GB so that kernels address a slot as
+// uniform base + 32-bit offset.
+static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths) {
     memset(&sc, 0, sizeof sc);
     sc.max_paths = P.max_paths;
     uint32_t kc = 64;
@@ -432,29 +432,46 @@ static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, 
     sc.keys_cap = kc;
     sc.max_seed_paths = max_seed_paths;
     sc.max_clusters = max_clusters;
-    const size_t S = n_slots;
-    size_t bytes = 0;
-#define ALLOC(field, type, count)                                            \
-    do {                                                                     \
-        size_t b_ = (size_t)(count) * sizeof(type);                          \
-        HIPCHK(hipMalloc((void **)&sc.field, b_));                           \
-        bytes += b_;                                                         \
-    } while (0)
-    ALLOC(paths, PathRec, S * 2 * sc.max_paths);
-    ALLOC(order, uint32_t, S * 2 * sc.max_paths);
-    ALLOC(keys, SortKey, S * 2 * sc.keys_cap);
-    ALLOC(seedp, SeedPath, S * sc.max_seed_paths);
-    ALLOC(sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
-    ALLOC(cl_keys, ClusterKey, S * (sc.max_clusters / 16) * 64);   // leaves are at least half full after a split
-    ALLOC(cl_dir, ClusterKey, S * (sc.max_clusters / 16));
-    ALLOC(cl_cnt, uint32_t, S * (sc.max_clusters / 16));
-    ALLOC(cl_pay, ClusterPay, S * sc.max_clusters);
-    ALLOC(state, SlotState, S);
-#undef ALLOC
-    HIPCHK(hipMemset(sc.state, 0, S * sizeof(SlotState)));
+    uint64_t off = 0;
+    auto region = [&off](uint64_t bytes) { const uint64_t o = off; off += (bytes + 255) & ~255ull; return o; };
+    const uint64_t leaves = max_clusters / 16;
+    const uint64_t o_paths = region(2ull * sc.max_paths * sizeof(PathRec));
+    const uint64_t o_rings = region(2ull * sc.max_paths * RING_FLOATS * 4);
+    const uint64_t o_order = region(2ull * sc.max_paths * 4);
+    const uint64_t o_keys = region(2ull * sc.keys_cap * sizeof(SortKey));
+    const uint64_t o_seedp = region((uint64_t)max_seed_paths * sizeof(SeedPath));
+    const uint64_t o_tasks = region((uint64_t)WAVE * MAX_REP_COPY_LIMIT * 8);
+    const uint64_t o_clk = region(leaves * 64 * sizeof(ClusterKey));     // leaves are at least half full after a split
+    const uint64_t o_cld = region(leaves * sizeof(ClusterKey));
+    const uint64_t o_clc = region(leaves * 4);
+    const uint64_t o_clp = region((uint64_t)max_clusters * sizeof(ClusterPay));
+    const uint64_t o_state = region(sizeof(SlotState));
+    if (off >= (1ull << 32)) return fail(UNC_ERR_ARG, "per-read scratch of %llu bytes does not fit 32-bit offsets (max_clusters %u)", (unsigned long long)off, max_clusters);
+    sc.off_paths = (uint32_t)o_paths; sc.off_rings = (uint32_t)o_rings; sc.off_order = (uint32_t)o_order; sc.off_keys = (uint32_t)o_keys;
+    sc.off_seedp = (uint32_t)o_seedp; sc.off_tasks = (uint32_t)o_tasks; sc.off_cl_keys = (uint32_t)o_clk; sc.off_cl_dir = (uint32_t)o_cld;
+    sc.off_cl_cnt = (uint32_t)o_clc; sc.off_cl_pay = (uint32_t)o_clp; sc.off_state = (uint32_t)o_state;
+    sc.slot_bytes = off;
+    return UNC_OK;
+}
+
+static uint64_t scratch_slot_bytes(const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths) {
+    DevScratch t;
+    return scratch_layout(t, P, max_clusters, max_seed_paths) == UNC_OK ? t.slot_bytes : ~0ull;
+}
+
+static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, uint32_t max_clusters, uint32_t max_seed_paths,
+                         size_t *bytes_out) {
+    int rc = scratch_layout(sc, P, max_clusters, max_seed_paths);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n_slots * sc.slot_bytes;
+    HIPCHK(hipMalloc((void **)&sc.base, bytes));
+    // SlotState of every slot starts zeroed (done = 0, nothing parked)
+    HIPCHK(hipMemset2D(sc.base + sc.off_state, sc.slot_bytes, 0, sizeof(SlotState), n_slots));
     if (bytes_out) *bytes_out = bytes;
     return UNC_OK;
 }
+
+static SlotState *slot_state(const DevScratch &sc, size_t slot) { return reinterpret_cast<SlotState *>(sc.base + slot * sc.slot_bytes + sc.off_state); }
 
 extern "C" void unc_mapper_free(unc_mapper_t *m) {
     if (!m) return;
@@ -462,8 +479,7 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     free_scratch(m->sc);
     free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
-                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells,
-                    m->bigbuf.keys, m->bigbuf.dir, m->bigbuf.cnt, m->bigbuf.pay, m->bigbuf.q, m->bigbuf.cells};
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells, m->bigbuf.base, m->bigbuf.q, m->bigbuf.cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -498,8 +514,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
         const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
-        const size_t per_slot = (size_t)p->max_paths * (2 * sizeof(PathRec) + 8 + 4 * sizeof(SortKey)) + (size_t)msp0 * sizeof(SeedPath) +
-                                (size_t)mcl0 * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + (64 << 10);
+        const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0);
         size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
         if (n_slots < n_waves) n_slots = n_waves;
@@ -520,8 +535,12 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         // what is left of the HBM, at most one per wavefront
         uint32_t n_big = opts ? opts->n_big : 0;
         const uint64_t bc = (opts && opts->big_clusters) ? opts->big_clusters : 4ull * mcl;
-        if (n_big != 0xFFFFFFFFu && bc <= (1ull << 26)) {
-            const size_t per_big = (size_t)bc * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + 64;
+        if (n_big != 0xFFFFFFFFu && bc <= (1ull << 24)) {
+            // one larger buffer: leaves | directory | counts | payloads, as in a slot
+            const size_t leaves = (size_t)(bc / 16);
+            const size_t o_dir = leaves * 64 * sizeof(ClusterKey), o_cnt = o_dir + leaves * sizeof(ClusterKey);
+            const size_t o_pay = (o_cnt + leaves * 4 + 255) & ~(size_t)255;
+            const size_t per_big = (o_pay + (size_t)bc * sizeof(ClusterPay) + 255) & ~(size_t)255;
             if (n_big == 0) {
                 size_t free_b = 0, total_b = 0;
                 HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -535,11 +554,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
                 while (cap < n_big) cap <<= 1;
                 DevBig &B = m->bigbuf;
                 B.cap_mask = cap - 1; B.n_big = n_big; B.max_clusters = (uint32_t)bc;
-                const size_t leaves = (size_t)(bc / 16);
-                HIPCHK(hipMalloc((void **)&B.keys, (size_t)n_big * leaves * 64 * sizeof(ClusterKey)));
-                HIPCHK(hipMalloc((void **)&B.dir, (size_t)n_big * leaves * sizeof(ClusterKey)));
-                HIPCHK(hipMalloc((void **)&B.cnt, (size_t)n_big * leaves * 4));
-                HIPCHK(hipMalloc((void **)&B.pay, (size_t)n_big * bc * sizeof(ClusterPay)));
+                B.buf_bytes = per_big; B.off_dir = (uint32_t)o_dir; B.off_cnt = (uint32_t)o_cnt; B.off_pay = (uint32_t)o_pay;
+                HIPCHK(hipMalloc((void **)&B.base, (size_t)n_big * per_big));
                 HIPCHK(hipMalloc((void **)&B.q, sizeof(SchedQueue)));
                 HIPCHK(hipMalloc((void **)&B.cells, (size_t)cap * sizeof(SchedCell)));
                 bytes += (size_t)n_big * per_big + (size_t)cap * sizeof(SchedCell);
@@ -713,7 +729,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         m->remap_ms = 0;
         const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
-        while (!redo.empty() && cap < (1ull << 26)) {
+        while (!redo.empty() && cap < (1ull << 23)) {   // 2^23 clusters = 0.9 GB per read: the 32-bit offset limit
             cap *= 16;
             const size_t want = std::min<size_t>(std::max<size_t>(redo.size(), 256), m->n_waves);
             if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
@@ -721,8 +737,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                 m->big_cap = 0; m->big_slots = 0;
                 size_t free_b = 0, total_b = 0;
                 HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                const size_t per_slot = (size_t)m->P.max_paths * (2 * sizeof(PathRec) + 8 + 4 * sizeof(SortKey)) +
-                                        (size_t)m->sc.max_seed_paths * sizeof(SeedPath) + cap * (5 * sizeof(ClusterKey) + sizeof(ClusterPay)) + (64 << 10);
+                const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths);
                 const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
                 const size_t slots = std::min(want, fit);
                 int rc2 = alloc_scratch(m->big, m->P, slots, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
@@ -818,7 +833,7 @@ extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, 
     SlotState s0;
     memset(&s0, 0, sizeof s0);
     s0.max_map.rstart = 1; s0.max_map.evt_st = 1;   // NULL_ALN
-    HIPCHK(hipMemcpyAsync(m->sc.state, &s0, sizeof s0, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(slot_state(m->sc, 0), &s0, sizeof s0, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     m->trace_n = n;
     m->trace_active = true;
@@ -840,7 +855,7 @@ extern "C" int unc_trace_step(unc_mapper_t *m, uint32_t n_events, int *done) {
     launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, nullptr, 1, m->stream);
     HIPCHK(hipGetLastError());
     SlotState s;
-    HIPCHK(hipMemcpyAsync(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (done) *done = s.done ? 1 : 0;
     return UNC_OK;
@@ -850,11 +865,23 @@ extern "C" int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, u
     if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
-    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost));
+    const DevScratch &sc = m->sc;
     std::vector<uint32_t> ord(s.n_parents ? s.n_parents : 1);
-    std::vector<PathRec> recs(m->sc.max_paths);
-    HIPCHK(hipMemcpy(ord.data(), m->sc.order + (size_t)s.cur * m->sc.max_paths, (size_t)s.n_parents * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(recs.data(), m->sc.paths + (size_t)s.cur * m->sc.max_paths, (size_t)m->sc.max_paths * sizeof(PathRec), hipMemcpyDeviceToHost));
+    std::vector<PathRec> recs(sc.max_paths);
+    std::vector<float> rings((size_t)sc.max_paths * RING_FLOATS);
+    // The paths belong to event `gen`; materialisations (k_map phase M) ran after the events 3, 7, .. of a read that went
+    // on; prob_sums_ entry j of a path of length L is the sum of event gen - (L - j): in recent[] when that event came
+    // after the last materialisation, else in the lineage's ring.
+    const int64_t gen = s.done == 1 ? (int64_t)s.event_i : (int64_t)s.event_i - 1;
+    const int64_t n_mat = (gen + 1) / 4 - ((s.done == 1 && gen % 4 == 3) ? 1 : 0);
+    const int64_t g0 = 4 * n_mat - 1;                       // event of the last materialisation (-1: none yet)
+    const uint32_t pool = (uint32_t)(n_mat & 1);
+    HIPCHK(hipMemcpy(ord.data(), sc.base + sc.off_order + (size_t)s.cur * sc.max_paths * 4, (size_t)s.n_parents * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(recs.data(), sc.base + sc.off_paths + (size_t)s.cur * sc.max_paths * sizeof(PathRec),
+                     (size_t)sc.max_paths * sizeof(PathRec), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rings.data(), sc.base + sc.off_rings + (size_t)pool * sc.max_paths * RING_FLOATS * 4,
+                     (size_t)sc.max_paths * RING_FLOATS * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < s.n_parents && i < cap; ++i) {
         const PathRec &r = recs[ord[i]];
         unc_path_t &o = out[i];
@@ -864,8 +891,16 @@ extern "C" int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, u
         o.length = (uint8_t)((r.meta >> META_LEN_SHIFT) & 31u);
         o.consec_stays = (uint8_t)((r.meta >> META_STAY_SHIFT) & 255u);
         o.sa_checked = (r.meta & META_SA_CHECKED) ? 1 : 0;
-        const uint32_t head = (r.meta >> META_HEAD_SHIFT) & 31u;
-        for (int j = 0; j <= o.length && j <= UNC_SEED_LEN; ++j) o.prob_sums[j] = r.ps[(head + (uint32_t)j) % PS_RING];
+        const int L = o.length;
+        for (int j = 0; j <= L && j <= UNC_SEED_LEN; ++j) {
+            const int64_t t = gen - (L - j);
+            float v;
+            if (j == 0 && (L < UNC_SEED_LEN || (r.meta & META_FIRST_FULL))) v = 0.0f;      // the initial prob_sums_[0]
+            else if (t > g0) v = r.recent[t & 3];
+            else if (r.ring != RING_NONE && r.ring < sc.max_paths) v = rings[(size_t)r.ring * RING_FLOATS + (size_t)(t % PS_RING)];
+            else return fail(UNC_ERR_HIP, "path %u: prob sum of event %lld has no ring", i, (long long)t);
+            o.prob_sums[j] = v;
+        }
     }
     *n_out = s.n_parents;
     return UNC_OK;
@@ -876,17 +911,17 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
-    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost));
     // flatten the two-level set (directory order, then slot order inside each leaf)
     const uint32_t max_leaves = m->sc.max_clusters / 16;
     std::vector<ClusterKey> dir(s.n_leaves ? s.n_leaves : 1), leaves((size_t)(s.n_alloc ? s.n_alloc : 1) * 64), keys;
     std::vector<uint32_t> cnt(s.n_alloc ? s.n_alloc : 1);
     std::vector<ClusterPay> pay(s.n_pay ? s.n_pay : 1);
     (void)max_leaves;
-    HIPCHK(hipMemcpy(dir.data(), m->sc.cl_dir, (size_t)s.n_leaves * sizeof(ClusterKey), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(leaves.data(), m->sc.cl_keys, (size_t)s.n_alloc * 64 * sizeof(ClusterKey), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cnt.data(), m->sc.cl_cnt, (size_t)s.n_alloc * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(pay.data(), m->sc.cl_pay, (size_t)s.n_pay * sizeof(ClusterPay), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dir.data(), m->sc.base + m->sc.off_cl_dir, (size_t)s.n_leaves * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(leaves.data(), m->sc.base + m->sc.off_cl_keys, (size_t)s.n_alloc * 64 * sizeof(ClusterKey), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), m->sc.base + m->sc.off_cl_cnt, (size_t)s.n_alloc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pay.data(), m->sc.base + m->sc.off_cl_pay, (size_t)s.n_pay * sizeof(ClusterPay), hipMemcpyDeviceToHost));
     for (uint32_t L = 0; L < s.n_leaves; ++L)
         for (uint32_t e = 0; e < cnt[dir[L].pidx]; ++e) keys.push_back(leaves[(size_t)dir[L].pidx * 64 + e]);
     if (keys.size() != s.n_clusters) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: %zu keys, %u clusters", keys.size(), s.n_clusters);
@@ -910,7 +945,7 @@ extern "C" int unc_trace_finish(unc_mapper_t *m, unc_hit_t *hit) {
     if (!m || !m->trace_active) return fail(UNC_ERR_ARG, "no trace in progress");
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
-    HIPCHK(hipMemcpy(&s, m->sc.state, sizeof s, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost));
     unc_evt_info_t inf;
     HIPCHK(hipMemcpy(&inf, m->d_info, sizeof inf, hipMemcpyDeviceToHost));
     DevResult res;
@@ -951,8 +986,7 @@ struct unc_rt {
 extern "C" void unc_rt_free(unc_rt_t *rt) {
     if (!rt) return;
     (void)hipSetDevice(rt->ix->device);
-    void *ptrs[] = {rt->sc.paths, rt->sc.order, rt->sc.keys, rt->sc.seedp, rt->sc.sa_tasks, rt->sc.cl_keys, rt->sc.cl_dir, rt->sc.cl_cnt,
-                    rt->sc.cl_pay, rt->sc.state,
+    void *ptrs[] = {rt->sc.base,
                     rt->d_chans, rt->d_ring, rt->d_desc, rt->d_info, rt->d_ring0, rt->d_newread, rt->d_slotmap, rt->d_next, rt->d_moff,
                     rt->d_results, rt->d_raw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -972,14 +1006,13 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     unc_rt *rt = new unc_rt();
     struct Guard { unc_rt *p; ~Guard() { if (p) unc_rt_free(p); } } guard{rt};
     rt->ix = ix; rt->P = *p; rt->n_channels = n_channels;
-    memset(&rt->sc, 0, sizeof rt->sc);
-    DevScratch &sc = rt->sc;
-    sc.max_paths = p->max_paths;
-    uint32_t kc = 64;
-    while (kc < p->max_paths) kc <<= 1;
-    sc.keys_cap = kc; sc.max_seed_paths = 2 * p->max_paths; sc.max_clusters = 65536;
     const size_t S = n_channels;
     size_t bytes = 0;
+    {
+        int rc = alloc_scratch(rt->sc, *p, S, 65536, 2 * p->max_paths, &bytes);
+        if (rc) return rc;
+        HIPCHK(hipMemset(rt->sc.base, 0, bytes));
+    }
 #define RALLOC(ptr, type, count)                                   \
     do {                                                           \
         size_t b_ = (size_t)(count) * sizeof(type);                \
@@ -987,16 +1020,6 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
         HIPCHK(hipMemset((ptr), 0, b_));                           \
         bytes += b_;                                               \
     } while (0)
-    RALLOC(sc.paths, PathRec, S * 2 * sc.max_paths);
-    RALLOC(sc.order, uint32_t, S * 2 * sc.max_paths);
-    RALLOC(sc.keys, SortKey, S * 2 * sc.keys_cap);
-    RALLOC(sc.seedp, SeedPath, S * sc.max_seed_paths);
-    RALLOC(sc.sa_tasks, uint64_t, S * WAVE * MAX_REP_COPY_LIMIT);
-    RALLOC(sc.cl_keys, ClusterKey, S * (sc.max_clusters / 16) * 64);
-    RALLOC(sc.cl_dir, ClusterKey, S * (sc.max_clusters / 16));
-    RALLOC(sc.cl_cnt, uint32_t, S * (sc.max_clusters / 16));
-    RALLOC(sc.cl_pay, ClusterPay, S * sc.max_clusters);
-    RALLOC(sc.state, SlotState, S);
     RALLOC(rt->d_chans, RtChan, S);
     RALLOC(rt->d_ring, float, S * NORM_LEN);
     RALLOC(rt->d_desc, RtChunkDesc, S);
@@ -1119,7 +1142,8 @@ extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_
         HIPCHK(hipMemcpyAsync(rt->h_info.data(), rt->d_info, n_act * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
     }
     rt->h_state.resize(rt->n_channels);
-    HIPCHK(hipMemcpyAsync(rt->h_state.data(), rt->sc.state, (size_t)rt->n_channels * sizeof(SlotState), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpy2DAsync(rt->h_state.data(), sizeof(SlotState), rt->sc.base + rt->sc.off_state, rt->sc.slot_bytes, sizeof(SlotState), rt->n_channels,
+                             hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (n_act) {
         HIPCHK(hipEventElapsedTime(&rt->ms_events, rt->ev[0], rt->ev[1]));

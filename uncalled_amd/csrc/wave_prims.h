@@ -12,11 +12,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) -
 // compiler-level ordering of this wave's global/LDS traffic between cooperative phases (lanes of a
 // wave share the L1 and the memory pipeline executes a wave's accesses in order)
 __device__ __forceinline__ void wave_sync() {
-#ifdef UNC_STRONG_SYNC
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // s_waitcnt vmcnt(0) lgkmcnt(0): stores have landed
-#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -95,8 +91,6 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
-// Streaming (write-once / read-once) traffic such as the path records: keep it from evicting the FM index
-// out of the XCD's L2.
 // Value of lane (lane ^ d), d uniform.  (DPP forms of the short distances were tried in the sort networks and measured
 // slower than ds_bpermute there: the per-stage dispatch on d and the DPP wait states cost more than the crossbar trips.)
 __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
