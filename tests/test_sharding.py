@@ -12,17 +12,9 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def test_shard_bounds_cover_all_reads_once():
-    from uncalled_amd.sharding import shard_bounds
-    rng = np.random.default_rng(0)
-    for n in (0, 1, 2, 7, 100):
-        off = np.concatenate(([0], np.cumsum(rng.integers(1, 50000, n)))).astype(np.uint64)
-        for w in (1, 2, 3, 8):
-            b = shard_bounds(off, w)
-            assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0)
-            if n >= 4 * w:   # balanced by samples
-                per = np.array([off[b[r + 1]] - off[b[r]] for r in range(w)], dtype=np.float64)
-                assert per.max() <= per.mean() + 50000
+def _split(n, rank, world):
+    """contiguous share of n reads for `rank` (the product shards by file / by seed: uncalled_amd/__main__.py, bench.py)"""
+    return n * rank // world, n * (rank + 1) // world
 
 
 def _worker(rank, world, port, out_dir):
@@ -33,12 +25,11 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
     from uncalled_amd import capi
-    from uncalled_amd.sharding import shard
     lib = capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
     gold = np.load(ROOT / "tests" / "golden" / "ref_goldens.npz")
     n = 8
     off = gold["sim_offsets"][:n + 1]
-    a, b = shard(off, rank, world)
+    a, b = _split(n, rank, world)
     ix = capi.Index(ROOT / "tests" / "golden" / "example_index" / "example_ref", lib=lib)   # index replicated per rank
     m = capi.Mapper(ix, n_slots=2)
     loc_off = (off[a:b + 1] - off[a]).astype(np.uint64)
@@ -71,3 +62,27 @@ def test_two_rank_sharded_mapping_matches_single_rank(sim_lib, goldens, tmp_path
     merged = np.concatenate(parts)
     for f in ("mapped", "fwd", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "matches", "event_i", "n_nbr", "n_sa", "n_lf"):
         assert np.array_equal(merged[f], single[f]), f
+
+
+def test_bench_py_two_ranks_gloo(sim_lib, tmp_path):
+    """bench.py's own world > 1 branch (rank-0 index step, barriers, MAX all-reduce of the timed region, one JSON line from
+    rank 0) on two CPU ranks: UNC_DIST_BACKEND=gloo, kernels = the lanesim build of the same sources."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UNC_DIST_BACKEND="gloo", UNC_BENCH_LIB=str(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so"),
+               UNC_BENCH_CACHE=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "example", "--reads", "3"], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 2 and b["scaling"] == "weak" and b["metric"] == "reads_mapped_per_sec"
+    assert b["config"]["reads_per_gpu_per_step"] == 3
+    assert abs(b["value"] - 3 * 2 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6     # whole job: both ranks' reads
+    assert b["verify"]["all_steps_identical"] and b["verify"]["steps_hashed"] == 2
+    assert "cpu_baseline" not in b and "secondary" not in b                               # N > 1: neither is run
