@@ -20,7 +20,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .build_index import DEFAULT_UNCL, pack2
+from .build_index import DEFAULT_UNCL
 
 K = 21            # symbols per 63-bit key
 B = 8             # symbols of the bucket id
@@ -83,13 +83,13 @@ def _sort_chunk(t, pos, n):
         del sub_pos, sub_grp, k2, k2s, o1, g1, g2, o2, perm, k2f, brk, idx
 
 
-def suffix_rows(t_np, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False):
-    """Generator over the suffix array of t (uint8 codes 0..3, '$'-terminated order) in order, one chunk (int64 tensor
-    of text positions, on `device`) at a time; also returns the text tensor through the first yielded item."""
+def suffix_rows(t_in, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False):
+    """Generator over the suffix array of t (uint8 codes 0..3 -- ndarray or tensor --, '$'-terminated order) in order, one
+    chunk (int64 tensor of text positions, on `device`) at a time; the text tensor comes along with every item."""
     import torch
-    n = int(t_np.size)
     dev = torch.device(device)
-    t = torch.as_tensor(t_np, device=dev)
+    t = torch.as_tensor(t_in, device=dev)
+    n = int(t.numel())
     nb = 1 << (3 * B)
     # histogram of bucket ids, text scanned in pieces
     hist = torch.zeros(nb, dtype=torch.int64, device=dev)
@@ -126,19 +126,20 @@ def suffix_rows(t_np, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False
     assert done == n, (done, n)
 
 
-def big_masked_genome(n_contigs, total_len, seed, masked_frac=0.30, mean_run=5000, gc=0.41, name="syn"):
+def big_masked_genome(n_contigs, total_len, seed, masked_frac=0.30, mean_run=5000, name="syn"):
     """`grch38_syn`-style reference: i.i.d. contigs, `masked_frac` of the length recorded as N-runs (bwa
-    fills N with random bases, the genome is random anyway: the runs only go to .amb).  Generated contig by contig, so
-    that nothing of 8 bytes per base is ever resident."""
+    fills N with random bases, the genome is random anyway: the runs only go to .amb).  Generated contig by contig from
+    one random byte per base (76/52/52/76 of 256 values for A/C/G/T: GC 0.406), a few seconds for 3.1 Gbp."""
     base = total_len // n_contigs
     lens = [base] * n_contigs
     lens[-1] += total_len - base * n_contigs
-    p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+    lut = np.empty(256, dtype=np.uint8)
+    lut[:76], lut[76:128], lut[128:180], lut[180:] = 0, 1, 2, 3
     codes = np.empty(total_len, dtype=np.uint8)
     holes, n_ambs, off = [], [], 0
     for i, ln in enumerate(lens):
         rng = np.random.default_rng([seed, i])
-        codes[off:off + ln] = rng.choice(4, size=ln, p=p).astype(np.uint8)
+        np.take(lut, rng.integers(0, 256, size=ln, dtype=np.uint8), out=codes[off:off + ln])
         n_runs = max(1, int(ln * masked_frac / mean_run))
         starts = np.sort(rng.integers(0, max(1, ln - mean_run), n_runs))
         runs = rng.geometric(1.0 / mean_run, n_runs)
@@ -165,13 +166,20 @@ def build_from_codes_big(prefix, names, annos, lens, codes, holes=(), n_ambs=Non
     l_pac = int(codes.size)
     assert sum(lens) == l_pac
     n_ambs = n_ambs or [0] * len(names)
-    pac = pack2(codes, 4, np.uint8)
-    with open(prefix + ".pac", "wb") as f:
-        f.write(pac.tobytes())
+    dev = torch.device(device)
+    codes_t = torch.as_tensor(codes).to(dev)
+    with open(prefix + ".pac", "wb") as f:      # 4 bases per byte, first base in the top bits; packed on the device in pieces
+        step4 = piece * 4
+        for lo in range(0, l_pac, step4):
+            seg = codes_t[lo:min(l_pac, lo + step4)]
+            pad = (-seg.numel()) % 4
+            if pad:
+                seg = torch.cat((seg, torch.zeros(pad, dtype=torch.uint8, device=dev)))
+            q = seg.view(-1, 4)
+            f.write(((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).cpu().numpy().tobytes())
         if l_pac % 4 == 0:
             f.write(b"\x00")
         f.write(bytes([l_pac % 4]))
-    del pac
     with open(prefix + ".ann", "w") as f:
         f.write(f"{l_pac} {len(names)} 11\n")
         off = 0
@@ -184,9 +192,9 @@ def build_from_codes_big(prefix, names, annos, lens, codes, holes=(), n_ambs=Non
         for off, ln, ch in holes:
             f.write(f"{off} {ln} {ch}\n")
 
-    t_np = np.concatenate((codes, (3 - codes[::-1]))).astype(np.uint8)
-    n = int(t_np.size)
-    dev = torch.device(device)
+    t_all = torch.cat((codes_t, 3 - codes_t.flip(0)))      # forward strand + reverse complement, as bwa builds it
+    del codes_t
+    n = int(t_all.numel())
     intv = 32
     n_sa = (n + intv) // intv
     samples = np.zeros(n_sa, dtype=np.uint64)          # SA of the rows r = 0, 32, 64, .. of the matrix with the sentinel row
@@ -195,7 +203,7 @@ def build_from_codes_big(prefix, names, annos, lens, codes, holes=(), n_ambs=Non
     primary = None
     row = 1                                             # matrix row of the next suffix (row 0 = sentinel)
     t = None
-    for t, pos in suffix_rows(t_np, device, chunk, piece, verbose):
+    for t, pos in suffix_rows(t_all, device, chunk, piece, verbose):
         m = pos.numel()
         rows = torch.arange(row, row + m, dtype=torch.int64, device=dev)
         zero = torch.nonzero(pos == 0).flatten()
