@@ -226,6 +226,11 @@ uint64_t unc_rt_device_bytes(const unc_rt_t *rt);
 /* raw: int16 samples (host, or device when on_device != 0); chunks/results: host arrays of n_chunks */
 int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, int on_device,
                           void *stream, unc_rt_result_t *results);
+/* the same for chunks that already hold floats -- what the reference's Chunk keeps (src/chunk.cpp:27-66: float32 as sent by
+ * MinKNOW, or int16/int32 converted WITHOUT calibration) and what Mapper::new_read(Chunk&)/add_chunk hand to the event
+ * detector: `offset` indexes `signal`, the chunk's `calib` is ignored */
+int unc_rt_process_chunks_f32(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const float *signal, int on_device,
+                              void *stream, unc_rt_result_t *results);
 int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *ms_map);
 
 /* ---- stage taps (parity tests) */

@@ -75,6 +75,22 @@ def sim_lib():
 
 
 @pytest.fixture(scope="session")
+def sim_host(sim_lib):
+    """TEST INFRASTRUCTURE: the host module's sources (MapPool, RealtimePool, ...) linked against the lanesim build of the
+    C ABI, so that their logic runs in the GPU-less container.  Lives beside the lanesim library, never in the package."""
+    import importlib.util
+    import sysconfig
+    import __graft_entry__ as g
+    out_dir = ROOT / "tests" / "lanesim" / "_build"
+    mod = g.build_host(lib=out_dir / "libuncalled_sim.so", out_dir=out_dir)
+    assert mod.name == "_uncalled_amd" + sysconfig.get_config_var("EXT_SUFFIX")
+    spec = importlib.util.spec_from_file_location("_uncalled_amd", mod)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The real gfx950 library; GPU tests fail loudly if it is missing."""
     from uncalled_amd import capi

@@ -1,0 +1,155 @@
+"""The realtime host classes (Chunk / RealtimePool / ClientSim of `_uncalled_amd`, mirroring src/chunk.hpp:47-59,
+src/realtime_pool.hpp:63-70, src/client_sim.hpp:39-44) -- their sources linked against the lanesim build of the C ABI and
+driven the way MapPoolOrd drives the reference's pool (map_pool_ord.cpp:61-112: try_add_chunk, an empty chunk once a read
+has run out, update), checked read by read against the oracle's chunked path."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
+
+pytestmark = pytest.mark.lanesim
+G = Path(__file__).resolve().parent / "golden"
+
+
+def test_chunk_class(sim_host):
+    unc = sim_host
+    sig = [float(i) for i in range(10)]
+    c = unc.Chunk("r1", 7, 3, 4000, sig, 2, 5)
+    assert (c.id, c.channel, c.number, c.size(), c.empty(), c.start) == ("r1", 7, 3, 5, False, 4000)
+    assert c.pop() == [2.0, 3.0, 4.0, 5.0, 6.0] and c.empty()
+    assert unc.Chunk("r1", 7, 3, 0, sig, 8, 5).size() == 2                 # cut at the end of the read (chunk.cpp:60-66)
+    raw = np.array([-3, 0, 700, 32767], dtype=np.int16)
+    assert unc.Chunk("r", 1, 0, 0, "int16", raw.tobytes()).pop() == [-3.0, 0.0, 700.0, 32767.0]   # no calibration (chunk.cpp:33-38)
+    f = np.array([1.5, -2.25], dtype=np.float32)
+    assert unc.Chunk("r", 1, 0, 0, "float32", f.tobytes()).pop() == [1.5, -2.25]
+    a, b = unc.Chunk("a", 1, 1, 0, sig, 0, 3), unc.Chunk("b", 2, 2, 9, sig, 0, 4)
+    a.swap(b)
+    assert (a.id, a.channel, a.number, a.size(), b.id, b.size()) == ("b", 2, 2, 4, "a", 3)
+
+
+def _conf(unc, n_channels, **kw):
+    c = unc.Conf()
+    c.bwa_prefix = str(G / "example_index" / "example_ref")
+    c.num_channels = n_channels
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_realtime_pool_ordered_replay_matches_oracle(sim_host, oracle_lib, example, goldens):
+    unc, po = sim_host, oracle_lib
+    n_channels, n_reads, chunk_len = 3, 9, 4000
+    off = goldens["sim_offsets"]
+    reads = [po.calibrate(example["signal"], example["range"], example["offset"], example["digitisation"])]
+    for i in range(n_reads - 1):
+        reads.append(po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION))
+    oix = po.Index(G / "example_index" / "example_ref")
+    oms = [po.Mapper(oix) for _ in range(n_channels)]
+    want = {i: oms[i % n_channels].chunk_read(reads[i], chunk_len)[0] for i in range(n_reads)}
+
+    pool = unc.RealtimePool(_conf(unc, n_channels))
+    queues = [[i for i in range(n_reads) if i % n_channels == ch] for ch in range(n_channels)]
+    chunk_i = [0] * n_channels
+    got = {}
+    rounds = 0
+    while any(queues) or not pool.all_finished():
+        for ch, nm, paf in pool.update():
+            i = nm
+            got[i] = paf
+            assert queues[ch - 1] and queues[ch - 1][0] == i
+            queues[ch - 1].pop(0)
+            chunk_i[ch - 1] = 0
+        for ch in range(n_channels):                       # MapPoolOrd::update: the next chunk of the channel's front read
+            if not queues[ch]:
+                continue
+            i = queues[ch][0]
+            sig = reads[i]
+            st = min(chunk_i[ch] * chunk_len, len(sig))
+            c = unc.Chunk("read%d" % i, ch + 1, i, st, sig.tolist(), st, chunk_len)
+            if pool.try_add_chunk(c):
+                chunk_i[ch] += 1
+        rounds += 1
+        assert rounds < 2000
+    names = oix.ref_names()
+    assert sorted(got) == list(range(n_reads))
+    for i in range(n_reads):
+        cols = str(got[i]).split("\t")
+        o = want[i]
+        assert cols[0] == "read%d" % i
+        wantcols = po.hit_paf_cols(o, names)
+        if o["mapped"]:
+            assert got[i].is_mapped()
+            assert (int(cols[1]), int(cols[2]), int(cols[3]), cols[4], cols[5], int(cols[6]), int(cols[7]), int(cols[8]), int(cols[9]),
+                    int(cols[10]), int(cols[11])) == wantcols, (i, cols, wantcols)
+        else:
+            assert not got[i].is_mapped() and int(cols[1]) == wantcols[0] and cols[2] == "*"
+        assert "ch:i:%d" % (i % n_channels + 1) in cols
+    pool.stop_all()
+    assert pool.all_finished() and pool.update() == []
+
+
+def test_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens):
+    """RealtimePool::add_chunk (realtime_pool.cpp:74-110): a chunk of a NEW read on a channel whose read is still undecided
+    ends that read (unmapped, `ended`) and starts the new one."""
+    unc, po = sim_host, oracle_lib
+    pool = unc.RealtimePool(_conf(unc, 2))
+    noise = (np.random.default_rng(3).normal(90.0, 12.0, 9000)).astype(np.float32).tolist()      # never maps
+    assert pool.add_chunk(unc.Chunk("noise", 1, 5, 100, noise, 0, 4000))
+    assert not pool.add_chunk(unc.Chunk("noise", 1, 5, 4100, noise, 4000, 4000))                 # previous chunk not mapped yet
+    assert pool.update() == [] and pool.active_count() == 1
+    assert pool.add_chunk(unc.Chunk("noise", 1, 5, 4100, noise, 4000, 4000))
+    assert pool.update() == []
+    off = goldens["sim_offsets"]
+    good = po.calibrate(goldens["sim_signal"][int(off[0]):int(off[1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION).tolist()
+    assert pool.add_chunk(unc.Chunk("good", 1, 6, 0, good, 0, 4000))                              # new read number on channel 1
+    out = pool.update()
+    ended = [(ch, nm, p) for ch, nm, p in out if nm == 5]
+    assert len(ended) == 1 and ended[0][0] == 1 and ended[0][2].is_ended() and not ended[0][2].is_mapped()
+    assert str(ended[0][2]).split("\t")[0] == "noise" and int(str(ended[0][2]).split("\t")[1]) == int(8000 * 450.0 / 4000.0)
+    k = 1
+    mapped = [p for ch, nm, p in out if nm == 6]
+    while not mapped and k * 4000 < len(good):
+        assert pool.add_chunk(unc.Chunk("good", 1, 6, k * 4000, good, k * 4000, 4000))
+        mapped = [p for ch, nm, p in pool.update() if nm == 6]
+        k += 1
+    assert mapped and mapped[0].is_mapped() and pool.all_finished()
+
+
+def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
+    """ClientSim-shaped source over fast5 files + the enrich/deplete loop of scripts/uncalled:216-256 (uncalled_amd sim)."""
+    unc = sim_host
+    off = goldens["sim_offsets"]
+    reads = [dict(id="sim-%d" % i, channel=1 + i % 2, number=i, start=1000 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
+                  signal=goldens["sim_signal"][int(off[i]):int(off[i + 1])].tolist()) for i in range(4)]
+    f5 = tmp_path / "reads.fast5"
+    assert unc.write_fast5(str(f5), reads, True, 4000.0)
+    conf = _conf(unc, 2)
+    client = unc.ClientSim(conf)
+    client.add_fast5(str(f5))
+    client.load_fast5s()
+    assert client.run() and client.is_running
+    first = client.get_read_chunks()
+    assert [(ch, c.id, c.number, c.size()) for ch, c in first] == [(1, "sim-0", 0, 4000), (2, "sim-1", 1, 4000)]
+    assert first[0][1].start == 0 and first[1][1].start == 1000
+    client.stop_receiving_read(1, 0)                       # channel 1 moves on to its next read
+    second = client.get_read_chunks()
+    assert [(ch, c.id, c.start) for ch, c in second] == [(1, "sim-2", 2000), (2, "sim-1", 1000 + 4000)]
+    assert client.unblock_read(2, 1) == 0
+    assert [(ch, c.id) for ch, c in client.get_read_chunks()] == [(1, "sim-2"), (2, "sim-3")]
+    assert abs(client.get_runtime() - 3.0) < 1e-6
+
+    from uncalled_amd.__main__ import realtime_loop
+    lines = []
+    conf.realtime_mode = int(unc.RealtimePool.DEPLETE)
+    client = unc.ClientSim(conf)
+    client.add_fast5(str(f5))
+    client.load_fast5s()
+    client.run()
+    pool = unc.RealtimePool(conf)
+    realtime_loop(unc, conf, client, pool, sim=True, emit=lambda p: lines.append(str(p)), sleep=lambda s: None)
+    ids = sorted(l.split("\t")[0] for l in lines)
+    assert ids == ["sim-0", "sim-1", "sim-2", "sim-3"]
+    for l in lines:      # deplete: mapped reads are ejected, unmapped ones kept
+        assert ("\tej:f:" in l) == (l.split("\t")[2] != "*") and (("\tkp:f:" in l) or ("\ten:f:" in l) or ("\tej:f:" in l))

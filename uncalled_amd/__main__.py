@@ -1,5 +1,5 @@
-"""`python -m uncalled_amd {index,map,pafstats}` -- the offline subcommands of the reference's `scripts/uncalled`
-(index_cmd :38-78, map_cmd :126-167, pafstats) with the same options (uncalled/args.py:90-124,244-304) on the GPU path.
+"""`python -m uncalled_amd {index,map,sim,pafstats}` -- the subcommands of the reference's `scripts/uncalled` that do not need
+a sequencer (index_cmd :38-78, map_cmd :126-167, realtime_cmd :170-256 fed from fast5 files, pafstats) with the same options (uncalled/args.py:90-124,244-304) on the GPU path.
 """
 import argparse
 import os
@@ -186,6 +186,79 @@ def map_cmd(args):
     mapper.stop()
 
 
+def realtime_loop(unc, conf, client, pool, sim=True, emit=None, sleep=time.sleep):
+    """The enrich / deplete decision loop of scripts/uncalled:216-256 (realtime_cmd), statement for statement, over a
+    RealtimePool and a chunk source with the ClientSim surface.  Per result: the read ended -> stop receiving it; it
+    mapped and we deplete (or did not map and we enrich) -> eject it; otherwise keep it."""
+    emit = emit or (lambda paf: paf.print_paf())
+    deplete = conf.realtime_mode == int(unc.RealtimePool.DEPLETE)
+    even = conf.active_chs == int(unc.RealtimePool.EVEN)
+    chunk_times = [time.time() for _ in range(conf.num_channels)]
+    unblocked = [None for _ in range(conf.num_channels)]
+    end_time = float("inf") if not conf.duration else conf.duration * 60 * 60
+    while client.is_running or not pool.all_finished():
+        t0 = time.time()
+        for ch, nm, paf in pool.update():
+            t = time.time() - chunk_times[ch - 1]
+            if paf.is_ended():
+                paf.set_float(unc.Paf.ENDED, t)
+                client.stop_receiving_read(ch, nm)
+            elif (paf.is_mapped() and deplete) or not (paf.is_mapped() or deplete):
+                paf.set_float(unc.Paf.EJECT, t)
+                u = client.unblock_read(ch, nm)
+                if sim:
+                    paf.set_int(unc.Paf.DELAY, u)
+                unblocked[ch - 1] = nm
+            else:
+                paf.set_float(unc.Paf.KEEP, t)
+                client.stop_receiving_read(ch, nm)
+            emit(paf)
+        if not client.is_running:
+            break            # the source ran dry: what is still undecided stays so, as in the reference
+        for channel, read in client.get_read_chunks():
+            if even and channel % 2 == 1:
+                client.stop_receiving_read(channel, read.number)
+            else:
+                if unblocked[channel - 1] == read.number:
+                    sys.stdout.write("# recieved chunk from %s after unblocking\n" % read.id)
+                    continue
+                chunk_times[channel - 1] = time.time()
+                pool.add_chunk(read)
+        if client.get_runtime() >= end_time:
+            break
+        dt = time.time() - t0
+        if dt < MAX_SLEEP:
+            sleep(MAX_SLEEP - dt)
+
+
+def sim_cmd(args):
+    """`uncalled sim`: the realtime loop fed from fast5 files instead of MinKNOW (scripts/uncalled:170-256)."""
+    from . import _uncalled_amd as unc
+    conf = unc.Conf()
+    for k, v in vars(args).items():
+        if v is not None and not k.startswith("_") and hasattr(conf, k) and k not in ("realtime_mode", "active_chs"):
+            setattr(conf, k, v)
+    conf.realtime_mode = int(unc.RealtimePool.ENRICH if args.enrich else unc.RealtimePool.DEPLETE)
+    conf.active_chs = int(unc.RealtimePool.EVEN if args.even else unc.RealtimePool.ODD if args.odd else unc.RealtimePool.FULL)
+    _assert_exists(conf.bwa_prefix + ".bwt")
+    _assert_exists(conf.bwa_prefix + ".uncl")
+    pool = None
+    try:
+        client = unc.ClientSim(conf)
+        for f in load_fast5s(args.fast5s, args.recursive):
+            if f is not None:
+                client.add_fast5(f)
+        client.load_fast5s()
+        if not client.run():
+            sys.exit(1)
+        pool = unc.RealtimePool(conf)
+        realtime_loop(unc, conf, client, pool, sim=True)
+    except KeyboardInterrupt:
+        sys.stderr.write("Keyboard interrupt\n")
+    if pool is not None:
+        pool.stop_all()
+
+
 def get_parser():
     from . import index_params, pafstats
     d = index_params.DEFAULTS
@@ -224,6 +297,26 @@ def get_parser():
     p.add_argument("--batch-reads", type=int, default=4096, help="Reads per GPU batch")
     p.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use: one worker process each, fast5 files dealt round-robin")
 
+    p = sp.add_parser("sim", help="Simulate real-time targeted sequencing from fast5 files (enrich / deplete decisions per read)")
+    p.add_argument("bwa_prefix", type=str, help="BWA prefix to mapping to. Must be processed by \"uncalled index\".")
+    p.add_argument("-p", "--idx-preset", type=str, default="default", help="Mapping mode")
+    p.add_argument("fast5s", nargs="+", type=str, help="Reads to replay: directories, fast5 files, or text files with one fast5 name per line")
+    p.add_argument("-r", "--recursive", action="store_true")
+    mode = p.add_mutually_exclusive_group(required=True)
+    mode.add_argument("-D", "--deplete", action="store_true", help="Will eject reads that align to the reference")
+    mode.add_argument("-E", "--enrich", action="store_true", help="Will eject reads that do not align to the reference")
+    chs = p.add_mutually_exclusive_group()
+    chs.add_argument("--even", action="store_true", help="Will only eject reads from even channels")
+    chs.add_argument("--odd", action="store_true", help="Will only eject reads from odd channels")
+    p.add_argument("-l", "--read-list", type=str, default=None, help="Only replay reads with these ids")
+    p.add_argument("-n", "--max-reads", type=int, default=None, help="Maximum number of reads to replay")
+    p.add_argument("--num-channels", type=int, default=512)
+    p.add_argument("-e", "--max-events", type=int, default=30000)
+    p.add_argument("-c", "--max-chunks", type=int, default=10, help="Will give up on a read after this many chunks have been processed")
+    p.add_argument("--chunk-time", type=float, default=1, help="Length of chunks in seconds")
+    p.add_argument("--duration", type=float, default=None, help="Duration to map real-time run in hours")
+    p.add_argument("--device", type=int, default=0, help="GPU ordinal")
+
     p = sp.add_parser("pafstats", help="Computes speed and accuracy of UNCALLED mappings")
     pafstats.add_opts(p)
     return ap
@@ -235,6 +328,8 @@ def main(argv=None):
         index_cmd(args)
     elif args.subcmd == "map":
         map_cmd(args)
+    elif args.subcmd == "sim":
+        sim_cmd(args)
     else:
         from . import pafstats
         pafstats.run(args)

@@ -113,6 +113,7 @@ def load(path=None):
     L.unc_rt_free.argtypes = [vp]
     L.unc_rt_device_bytes.argtypes = [vp]; L.unc_rt_device_bytes.restype = u64
     L.unc_rt_process_chunks.argtypes = [vp, u32, vp, vp, C.c_int, vp, vp]
+    L.unc_rt_process_chunks_f32.argtypes = [vp, u32, vp, vp, C.c_int, vp, vp]
     L.unc_rt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_trace_begin.argtypes = [vp, vp, u32, vp]
     L.unc_trace_step.argtypes = [vp, u32, C.POINTER(C.c_int)]
@@ -368,6 +369,15 @@ class Realtime:
             ptr, on_dev = C.c_void_p(raw.ctypes.data), 0
         _check(self.L, self.L.unc_rt_process_chunks(self.h, ch.size, ch.ctypes.data, ptr, on_dev, C.c_void_p(stream or 0),
                                                     res.ctypes.data))
+        return res
+
+    def process_chunks_f32(self, chunks, signal_f32):
+        """the same for chunks that hold floats already (what the reference's Chunk keeps): `offset` indexes signal_f32"""
+        ch = np.ascontiguousarray(chunks, dtype=RT_CHUNK)
+        res = np.zeros(ch.size, dtype=RT_RESULT)
+        sig = np.ascontiguousarray(signal_f32, dtype=np.float32)
+        _check(self.L, self.L.unc_rt_process_chunks_f32(self.h, ch.size, ch.ctypes.data, C.c_void_p(sig.ctypes.data), 0, None,
+                                                        res.ctypes.data))
         return res
 
     def last_timing(self):

@@ -3,7 +3,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
-#include "unc_pool.hpp"
+#include "unc_realtime.hpp"
 
 namespace py = pybind11;
 using namespace unc_host;
@@ -15,7 +15,8 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def(py::init<>())
 #define PRP(P) .def_readwrite(#P, &Conf::P)
         PRP(threads) PRP(bwa_prefix) PRP(idx_preset) PRP(model_path) PRP(max_events) PRP(seed_len) PRP(chunk_time) PRP(fast5_list)
-        PRP(read_list) PRP(max_reads) PRP(max_buffer) PRP(num_channels) PRP(max_chunks) PRP(sample_rate) PRP(device) PRP(batch_reads);
+        PRP(read_list) PRP(max_reads) PRP(max_buffer) PRP(num_channels) PRP(max_chunks) PRP(sample_rate) PRP(device) PRP(batch_reads)
+        PRP(realtime_mode) PRP(active_chs) PRP(duration) PRP(max_active_reads);
 #undef PRP
 
     py::class_<Paf> paf(m, "Paf");
@@ -29,7 +30,8 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("set_str", &Paf::set_str);
     py::enum_<Paf::Tag>(paf, "Tag")
         .value("MAP_TIME", Paf::MAP_TIME).value("EJECT", Paf::EJECT).value("IN_SCAN", Paf::IN_SCAN).value("ENDED", Paf::ENDED)
-        .value("KEEP", Paf::KEEP).value("DELAY", Paf::DELAY)
+        .value("KEEP", Paf::KEEP).value("DELAY", Paf::DELAY).value("WAIT_TIME", Paf::WAIT_TIME).value("CHANNEL", Paf::CHANNEL)
+        .value("READ_START", Paf::READ_START)
         .export_values();
 
     // ReadBuffer as Fast5Reader::pop_read returns it (read_buffer.hpp:182-198): id / start / channel / raw, with the
@@ -87,6 +89,49 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("fill_buffer", &Fast5Reader::fill_buffer)
         .def("all_buffered", &Fast5Reader::all_buffered)
         .def("empty", &Fast5Reader::empty);
+
+    // ---- realtime path: Chunk / RealtimePool / ClientSim with the reference's names (pybinder.cpp:33-47,
+    //      chunk.hpp:47-59, realtime_pool.hpp:63-70, client_sim.hpp:57-75)
+    py::class_<Chunk>(m, "Chunk")
+        .def(py::init<>())
+        .def(py::init([](const std::string &id, uint16_t channel, uint32_t number, uint64_t start, const std::string &dtype, const py::bytes &raw) {
+            return new Chunk(id, channel, number, start, dtype, std::string(raw));
+        }))
+        .def(py::init<const std::string &, uint16_t, uint32_t, uint64_t, const std::vector<float> &, uint32_t, uint32_t>())
+        .def("pop", [](Chunk &c) { std::vector<float> v; c.pop(v); return v; })
+        .def("swap", &Chunk::swap)
+        .def("empty", &Chunk::empty)
+        .def("print", &Chunk::print)
+        .def("size", &Chunk::size)
+        .def_property_readonly("channel", &Chunk::get_channel)
+        .def_property_readonly("number", &Chunk::get_number)
+        .def_property_readonly("id", &Chunk::get_id)
+        .def_property_readonly("start", &Chunk::get_start);
+
+    py::class_<RealtimePool> rp(m, "RealtimePool");
+    rp.def(py::init<const Conf &>())
+        .def("add_chunk", &RealtimePool::add_chunk)
+        .def("try_add_chunk", &RealtimePool::try_add_chunk)
+        .def("end_read", &RealtimePool::end_read)
+        .def("update", &RealtimePool::update)
+        .def("all_finished", &RealtimePool::all_finished)
+        .def("stop_all", &RealtimePool::stop_all)
+        .def("active_count", &RealtimePool::active_count)
+        .def("last_round_ms", &RealtimePool::last_round_ms);
+    py::enum_<RealtimePool::Mode>(rp, "RealtimeMode").value("DEPLETE", RealtimePool::DEPLETE).value("ENRICH", RealtimePool::ENRICH).export_values();
+    py::enum_<RealtimePool::ActiveChs>(rp, "ActiveChs")
+        .value("FULL", RealtimePool::FULL).value("EVEN", RealtimePool::EVEN).value("ODD", RealtimePool::ODD).export_values();
+
+    py::class_<ClientSim>(m, "ClientSim")
+        .def(py::init<const Conf &>())
+        .def("add_fast5", &ClientSim::add_fast5)
+        .def("load_fast5s", &ClientSim::load_fast5s)
+        .def("run", &ClientSim::run)
+        .def("get_read_chunks", &ClientSim::get_read_chunks)
+        .def("stop_receiving_read", &ClientSim::stop_receiving_read)
+        .def("unblock_read", &ClientSim::unblock_read)
+        .def("get_runtime", &ClientSim::get_runtime)
+        .def_property_readonly("is_running", &ClientSim::is_running);
 
     py::class_<MapPool>(m, "MapPool")
         .def(py::init<const Conf &>())

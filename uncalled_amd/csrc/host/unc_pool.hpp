@@ -25,7 +25,12 @@ struct Conf {
     float chunk_time = 1.0f, sample_rate = 4000.0f;
     std::string fast5_list, read_list;
     int device = 0;                  // GPU ordinal
-    uint32_t batch_reads = 4096;     // reads handed to one unc_map_batch call
+    uint32_t batch_reads = 0;        // reads handed to one unc_map_batch call (0 = as many as the mapper keeps in flight)
+    // realtime (conf.hpp:57-96 RealtimeParams): what the decision loop of scripts/uncalled:216-256 reads
+    int realtime_mode = 0;           // RealtimePool::DEPLETE / ENRICH
+    int active_chs = 0;              // RealtimePool::FULL / EVEN / ODD
+    float duration = 0;              // hours (0 = until the source runs dry)
+    uint32_t max_active_reads = 512;
 };
 
 class Paf {

@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t roll_unread(uint32_t n, uint32_t rd, uint32_
     return rd < wr ? wr - rd : (n - rd) + wr;   // Normalizer::unread_size, normalizer.cpp:131-134
 }
 
-__global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans,
+__global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans,
                                                   float *norm_ring, unc_params_t P, float tgt_mean, float tgt_stdv,
                                                   unc_evt_info_t *info, uint32_t *ring0_out) {
     __shared__ double s_sum[RING * WAVE];
@@ -257,10 +257,16 @@ __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const RtCh
         n_full = 0;
     }
 
-    const int16_t *rp = raw + cd.offset;
+    // samples: stored int16 + the channel's calibration, or floats taken as they are (Chunk keeps floats, chunk.cpp:27-66)
+    const int16_t *rp = raw_pa ? nullptr : raw + cd.offset;
+    const float *fp = raw_pa ? raw_pa + cd.offset : nullptr;
     for (uint32_t k = 0; k < cd.n_samples; ++k) {
-        const uint16_t ru = (uint16_t)rp[k];
-        const float s = __fdiv_rn(__fmul_rn(cd.cal_range, __fadd_rn((float)(int)ru, cd.cal_offset)), cd.cal_digit);
+        float s;
+        if (fp) s = fp[k];
+        else {
+            const uint16_t ru = (uint16_t)rp[k];
+            s = __fdiv_rn(__fmul_rn(cd.cal_range, __fadd_rn((float)(int)ru, cd.cal_offset)), cd.cal_digit);
+        }
         const uint32_t cur = (t & (RING - 1)) * WAVE + lane, prv = ((t - 1) & (RING - 1)) * WAVE + lane;
         const float ss = __fmul_rn(s, s);
         s_sum[cur] = s_sum[prv] + (double)s;
@@ -337,9 +343,9 @@ __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const RtCh
 
 #include "unc_kernels.h"
 namespace unc {
-void launch_rt_events(const int16_t *raw, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans, float *norm_ring,
+void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans, float *norm_ring,
                       const unc_params_t &P, float tgt_mean, float tgt_stdv, unc_evt_info_t *info, uint32_t *ring0_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + WAVE - 1) / WAVE), dim3(WAVE), 0, st, raw, chunks, n_chunks, chans, norm_ring, P,
+    hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + WAVE - 1) / WAVE), dim3(WAVE), 0, st, raw, raw_pa, chunks, n_chunks, chans, norm_ring, P,
                        tgt_mean, tgt_stdv, info, ring0_out);
 }
 void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st) {

@@ -1057,9 +1057,11 @@ static void rt_unmapped(const unc_rt *rt, const RtHostChan &hc, const SlotState 
     fill_hit(rt->ix, rt->P, res, inf ? *inf : z, hc.raw_len, h);
 }
 
-extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, int on_device,
-                                     void *stream, unc_rt_result_t *results) {
-    if (!rt || !chunks || !raw || !results) return fail(UNC_ERR_ARG, "null argument");
+// raw (int16 + per-chunk calibration) or raw_pa (floats taken as they are): exactly one of the two
+static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, const float *raw_pa, int on_device,
+                      void *stream, unc_rt_result_t *results) {
+    if (!rt || !chunks || (!raw && !raw_pa) || !results) return fail(UNC_ERR_ARG, "null argument");
+    const size_t esz = raw_pa ? sizeof(float) : sizeof(int16_t);
     if (n_chunks > rt->n_channels) return fail(UNC_ERR_ARG, "more chunks than channels");
     HIPCHK(hipSetDevice(rt->ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : rt->stream;
@@ -1109,25 +1111,27 @@ extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_
     const uint32_t n_act = (uint32_t)desc.size();
     rt->ms_events = rt->ms_map = 0;
     if (n_act) {
-        const int16_t *d_raw = raw;
+        const char *d_base = raw_pa ? reinterpret_cast<const char *>(raw_pa) : reinterpret_cast<const char *>(raw);
         if (!on_device) {
             const uint64_t span = hi > lo ? hi - lo : 0;
-            if (span > rt->raw_cap) {
+            if (span * 2 > rt->raw_cap) {              // raw_cap counts int16 elements; floats take two each
                 if (rt->d_raw) (void)hipFree(rt->d_raw);
                 rt->d_raw = nullptr;
-                HIPCHK(hipMalloc((void **)&rt->d_raw, (span + 64) * 2));
-                rt->raw_cap = span;
+                HIPCHK(hipMalloc((void **)&rt->d_raw, (span * 2 + 64) * 2));
+                rt->raw_cap = span * 2;
             }
-            if (span) HIPCHK(hipMemcpyAsync(rt->d_raw, raw + lo, span * 2, hipMemcpyHostToDevice, st));
-            d_raw = rt->d_raw - lo;
+            if (span) HIPCHK(hipMemcpyAsync(rt->d_raw, d_base + lo * esz, span * esz, hipMemcpyHostToDevice, st));
+            d_base = reinterpret_cast<const char *>(rt->d_raw) - lo * esz;
         }
+        const int16_t *d_raw = raw_pa ? nullptr : reinterpret_cast<const int16_t *>(d_base);
+        const float *d_pa = raw_pa ? reinterpret_cast<const float *>(d_base) : nullptr;
         moff.push_back(0);
         HIPCHK(hipMemcpyAsync(rt->d_desc, desc.data(), n_act * sizeof(RtChunkDesc), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(rt->d_slotmap, slotmap.data(), n_act * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(rt->d_newread, newread.data(), n_act * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(rt->d_moff, moff.data(), (n_act + 1) * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(rt->ev[0], st));
-        launch_rt_events(d_raw, rt->d_desc, n_act, rt->d_chans, rt->d_ring, rt->P, rt->ix->model_mean, rt->ix->model_stdv, rt->d_info,
+        launch_rt_events(d_raw, d_pa, rt->d_desc, n_act, rt->d_chans, rt->d_ring, rt->P, rt->ix->model_mean, rt->ix->model_stdv, rt->d_info,
                          rt->d_ring0, st);
         HIPCHK(hipEventRecord(rt->ev[1], st));
         DevReads rd;
@@ -1193,6 +1197,18 @@ extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_
     }
     if (worst) return fail(worst, "device scratch overflow on at least one channel (see hit.status)");
     return UNC_OK;
+}
+
+extern "C" int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const int16_t *raw, int on_device,
+                                     void *stream, unc_rt_result_t *results) {
+    if (!raw) return fail(UNC_ERR_ARG, "null argument");
+    return rt_process(rt, n_chunks, chunks, raw, nullptr, on_device, stream, results);
+}
+
+extern "C" int unc_rt_process_chunks_f32(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const float *signal, int on_device,
+                                         void *stream, unc_rt_result_t *results) {
+    if (!signal) return fail(UNC_ERR_ARG, "null argument");
+    return rt_process(rt, n_chunks, chunks, nullptr, signal, on_device, stream, results);
 }
 
 // ------------------------------------------------------------------ uncalled index: self alignment
