@@ -66,13 +66,28 @@ __global__ void k_self_align(DevIndex ix, const uint8_t *pac, uint32_t n_samples
     out_len[i] = n;
 }
 
-// Dense SA: every row walks to its sampled row once, at index load (bwt_sa for all rows in parallel)
+// Dense SA: every row walks to its sampled row once, at index load (bwt_sa for all rows in parallel).  Grid-stride: a
+// launch of one thread per row would need more than 2^32 threads for GRCh38 (6.2 G rows), which HIP does not dispatch.
 __global__ void k_dense_sa(DevIndex ix, uint64_t *out) {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > ix.seq_len) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= ix.seq_len; k += stride) {
+        uint32_t steps;
+        const uint64_t sa = fm_sa(ix, k, &steps);
+        out[k] = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);   // row 0 (SA = -1) is never looked up
+    }
+}
+
+// Load-time self-check of the dense table: `n` probe rows spread over the whole index (the last row included) must agree
+// with the BWA-format walk; *bad counts the ones that do not.
+__global__ void k_dense_sa_check(DevIndex ix, const uint64_t *dense, uint32_t n, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = n > 1 ? (uint64_t)((__uint128_t)ix.seq_len * i / (n - 1)) : ix.seq_len;
+    if (k == 0) k = 1;
     uint32_t steps;
     const uint64_t sa = fm_sa(ix, k, &steps);
-    out[k] = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);   // row 0 (SA = -1) is never looked up
+    const uint64_t want = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);
+    if (dense[k] != want) atomicAdd(bad, 1u);
 }
 
 // PoreModel::match_prob for all 1024 k-mers of each level (mapper.cpp:443-445)
@@ -100,7 +115,11 @@ void launch_self_align(const DevIndex &ix, const uint8_t *pac, uint32_t n, const
 }
 void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st) {
     const uint64_t n = ix.seq_len + 1;
-    hipLaunchKernelGGL(k_dense_sa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix, out);
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_dense_sa, dim3((unsigned)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, st, ix, out);
+}
+void launch_dense_sa_check(const DevIndex &ix, const uint64_t *dense, uint32_t n, uint32_t *bad, hipStream_t st) {
+    hipLaunchKernelGGL(k_dense_sa_check, dim3((n + 255) / 256), dim3(256), 0, st, ix, dense, n, bad);
 }
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st) {
     hipLaunchKernelGGL(k_fm_sa, dim3((n + 63) / 64), dim3(64), 0, st, ix, n, rows, out);

@@ -246,6 +246,16 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
             launch_dense_sa(d, ix->d_sa_dense, nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipDeviceSynchronize());
+            {   // self-check: 16 384 rows spread over the whole table (the last row included) against the BWA-format walk
+                uint32_t *d_bad = nullptr, bad = 0;
+                HIPCHK(hipMalloc((void **)&d_bad, 4));
+                HIPCHK(hipMemset(d_bad, 0, 4));
+                launch_dense_sa_check(d, ix->d_sa_dense, 16384, d_bad, nullptr);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+                (void)hipFree(d_bad);
+                if (bad) return fail(UNC_ERR_HIP, "dense SA self-check failed on %u of 16384 probe rows", bad);
+            }
             d.sa_dense = ix->d_sa_dense;
             ix->device_bytes += need;
         }
