@@ -132,24 +132,24 @@ def cpu_baseline(prefix, raw_host, offsets, calib, hits_gpu, budget_s=80.0, swee
 
     t_begin = time.time()
     # one thread first: the per-core rate everything else is sized from
-    n1, s1, cols1, ms1 = run(6, 1)
+    n1, s1, cols1, ms1 = run(8, 1)
     rate1 = n1 / s1
     checked = {i: c for i, c in enumerate(cols1)}
-    per_leg = max(3.0, budget_s / 12.0)
+    per_leg = max(3.0, budget_s / 16.0)
     sweep_out = {"1": round(rate1, 2)}
     best_n, best_rate = 1, rate1
-    per_thread = rate1
     for t in [t for t in sweep if 1 < t <= aff] + ([aff] if aff not in sweep and aff > 1 else []):
-        n = max(2 * t, int(per_thread * t * per_leg))
+        # sized as if the extra threads bought nothing (they rarely buy much: every Mapper drags 2.8 MB of path buffers
+        # through the caches), at least four reads per thread so that the dynamic queue can balance
+        n = max(4 * t, int(best_rate * per_leg))
         n, secs, cols, _ = run(n, t)
         rate = n / secs
-        per_thread = rate / t
         sweep_out[str(t)] = round(rate, 2)
         checked.update({i: c for i, c in enumerate(cols)})
         if rate > best_rate:
             best_n, best_rate = t, rate
     # the stated figure: best N for >= 30 s (or what is left of the budget, never below 10 s)
-    left = max(10.0, min(35.0, budget_s - (time.time() - t_begin) - 8.0))
+    left = max(10.0, min(35.0, budget_s - (time.time() - t_begin) - 10.0))
     n, secs, cols, ms = run(int(best_rate * left), best_n)
     checked.update({i: c for i, c in enumerate(cols)})
     out = dict(value=n / secs, unit="reads/s", cores=best_n, kind=kind,
@@ -172,6 +172,27 @@ def cpu_baseline(prefix, raw_host, offsets, calib, hits_gpu, budget_s=80.0, swee
     out["tie_order_note"] = ("children tying on (fm_range, seed_prob) are ordered by creation in oracle and kernels alike; "
                              "upstream's unstable pdqsort (mapper.cpp:531) is not available here, oracle/shim uses std::stable_sort")
     return out
+
+
+def cpu_baseline_subprocess(prefix, raw_host, offsets, calib, hits_gpu, budget_s):
+    """cpu_baseline in a process of its own: the reference keeps its index in process-global statics (mapper.hpp:80-85, one
+    index per process), so every reference index of a bench run needs a fresh process."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="unc_cpu_leg_") as d:
+        f = Path(d) / "leg.npz"
+        np.savez(f, raw=raw_host, offsets=offsets, calib=calib, hits=hits_gpu, prefix=str(prefix), budget=budget_s)
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-leg", str(f)], capture_output=True, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("CPU baseline process failed: " + r.stderr[-600:])
+        return json.loads(lines[-1])
+
+
+def cpu_leg_main(path):
+    d = np.load(path, allow_pickle=False)
+    out = cpu_baseline(str(d["prefix"]), d["raw"], d["offsets"], d["calib"], d["hits"], budget_s=float(d["budget"]))
+    print(json.dumps(out))
 
 
 def a_reads(a, workload):
@@ -299,7 +320,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
         if world == 1 and cpu_budget > 0:
             n_cpu = min(n_reads, 12288)
             host_sig = sim["signal"][:int(offsets[n_cpu])].cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(prefix, host_sig, offsets[:n_cpu + 1], calib, hits, budget_s=cpu_budget)
+            res["cpu_baseline"] = cpu_baseline_subprocess(prefix, host_sig, offsets[:n_cpu + 1], calib[:n_cpu], hits[:n_cpu], cpu_budget)
             res["verify"]["reads_checked_vs_cpu"] = res["cpu_baseline"]["paf_reads_checked"]
             res["verify"]["paf_mismatches"] = res["cpu_baseline"]["paf_mismatches_vs_gpu"]
     mapper.close()
@@ -390,7 +411,10 @@ def main():
                     help="secondary blocks are skipped once this much wall time has gone")
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--rt-ref", choices=["ecoli", "chr20"], default="ecoli", help="reference of the realtime workload")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)      # internal: cpu_baseline_subprocess
     a = ap.parse_args()
+    if a.cpu_leg:
+        return cpu_leg_main(a.cpu_leg)
     if a.reads is None:
         a.reads = a_reads(argparse.Namespace(reads=int(os.environ.get("UNC_BENCH_READS", 50000)), chr20_reads=a.chr20_reads,
                                              grch38_reads=a.grch38_reads), a.workload)
@@ -431,7 +455,7 @@ def main():
         return
 
     extras = not a.no_profile_pass
-    cpu_budget = 0.0 if (a.no_cpu_baseline or not have_gpu) else 80.0
+    cpu_budget = 0.0 if (a.no_cpu_baseline or not have_gpu) else 100.0
     head = run_workload(a, a.workload, a.reads, a.steps, a.warmup, rank, world, local_rank, dist, barrier, cache, lib, dev_name,
                         extras, cpu_budget)
     out = None
@@ -456,7 +480,7 @@ def main():
             try:
                 t0 = time.time()
                 r = run_workload(a, w, a_reads(a, w), 2 if w == "grch38" else 1, 1, rank, world, local_rank, dist, barrier, cache, lib,
-                                 dev_name, extras, 0.0 if a.no_cpu_baseline else 45.0)
+                                 dev_name, extras, 0.0 if a.no_cpu_baseline else 60.0)
                 r = {k: v for k, v in r.items() if k != "dt"}
                 r["unit"] = "reads/s"
                 r["wall_s_incl_index_build"] = time.time() - t0

@@ -108,6 +108,10 @@ typedef struct unc_mapper unc_mapper_t;
 
 const char *unc_last_error(void);
 const char *unc_version(void);
+/* page-locked host memory for batches handed to unc_map_batch with on_device == 0 (the copy to HBM then runs at full
+ * PCIe rate and asynchronously); NULL on failure */
+void *unc_host_alloc(uint64_t bytes);
+void unc_host_free(void *p);
 
 /* Conf defaults: compiled-in PRMS of the reference (SURVEY.md section 5 "Config / flags") */
 void unc_params_default(unc_params_t *p);
@@ -160,6 +164,8 @@ typedef struct {
                               * index rows, else as many as a quarter of the remaining HBM holds, at most n_waves;
                               * 0xFFFFFFFF = none) */
     uint32_t big_clusters;   /* seed clusters per larger buffer (0 = 4 x max_clusters) */
+    uint32_t events_reads_per_wave;   /* k_events: reads (lanes in use) per wavefront, 1..64 (0 = 32: a 50 k-read batch then
+                              * spreads over 1563 wavefronts instead of 782) */
 } unc_mapper_opts_t;
 
 int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out);

@@ -69,6 +69,10 @@ def case_events_edge_cases(lib, oracle_lib, example, goldens):
     reads = [np.zeros(0, np.int16), np.array([500], np.int16), rng.integers(300, 700, 12).astype(np.int16),
              np.full(400, 512, np.int16), rng.integers(-200, 900, 700).astype(np.int16),
              np.repeat(rng.integers(350, 650, 60), 9).astype(np.int16)]
+    # k_events takes 8 samples per step from the first 16-byte boundary past sample 16 on: every head / tail length and
+    # every alignment of a read inside the batch (step signals, so that events fall into heads and tails as well)
+    for ln in list(range(13, 42)) + [63, 64, 65, 127, 129, 1000, 1003]:
+        reads.append(np.repeat(rng.integers(330, 680, ln // 5 + 1), 5)[:ln].astype(np.int16) + rng.integers(-6, 7, ln).astype(np.int16))
     raw = np.concatenate(reads)
     off = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint64)
     cal = capi.make_calib(len(reads), CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)

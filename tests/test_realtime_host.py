@@ -153,3 +153,41 @@ def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
     assert ids == ["sim-0", "sim-1", "sim-2", "sim-3"]
     for l in lines:      # deplete: mapped reads are ejected, unmapped ones kept
         assert ("\tej:f:" in l) == (l.split("\t")[2] != "*") and (("\tkp:f:" in l) or ("\ten:f:" in l) or ("\tej:f:" in l))
+
+
+def test_map_pool_pipeline_matches_oracle(sim_host, oracle_lib, tmp_path, goldens):
+    """MapPool (loader thread -> page-locked staging buffers -> mapper thread -> update()) over several fast5 files and
+    batches: every read comes out once, PAF columns as the oracle maps the same signal."""
+    unc, po = sim_host, oracle_lib
+    off = goldens["sim_offsets"]
+    n = 7
+    reads = [dict(id="sim-%d" % i, channel=1 + i, number=i, start=100 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
+                  signal=goldens["sim_signal"][int(off[i]):int(off[i + 1])].tolist()) for i in range(n)]
+    assert unc.write_fast5(str(tmp_path / "a.fast5"), reads[:4], True, 4000.0)
+    assert unc.write_fast5(str(tmp_path / "b.fast5"), reads[4:], True, 4000.0)
+    pool = unc.MapPool(_conf(unc, 512, batch_reads=3))          # 3 + 3 + 1
+    pool.add_fast5(str(tmp_path / "a.fast5"))
+    pool.add_fast5(str(tmp_path / "b.fast5"))
+    assert pool.running()
+    lines = []
+    import time
+    t0 = time.time()
+    while pool.running():
+        lines += [str(p) for p in pool.update()]
+        time.sleep(0.01)
+        assert time.time() - t0 < 600
+    pool.stop()
+    assert not pool.running() and pool.update() == []
+    oix = po.Index(G / "example_index" / "example_ref")
+    om = po.Mapper(oix)
+    got = {l.split("\t")[0]: l.split("\t") for l in lines}
+    assert sorted(got) == sorted(r["id"] for r in reads) and len(lines) == n
+    for i, r in enumerate(reads):
+        o = om.map_read(po.calibrate(np.array(r["signal"], dtype=np.int16), CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION))
+        want = po.hit_paf_cols(o, oix.ref_names())
+        c = got[r["id"]]
+        if o["mapped"]:
+            assert (int(c[1]), int(c[2]), int(c[3]), c[4], c[5], int(c[6]), int(c[7]), int(c[8]), int(c[9]), int(c[10]), int(c[11])) == want
+        else:
+            assert int(c[1]) == want[0] and c[2] == "*"
+        assert "ch:i:%d" % r["channel"] in c and "st:i:%d" % r["start"] in c

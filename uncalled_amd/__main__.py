@@ -288,13 +288,13 @@ def get_parser():
     p.add_argument("-r", "--recursive", action="store_true")
     p.add_argument("-l", "--read-list", type=str, default=None, help="Only map reads with these ids")
     p.add_argument("-n", "--max-reads", type=int, default=None, help="Maximum number of reads to map")
-    p.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility; the GPU path batches reads instead")
+    p.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility and ignored: reads are batched onto the GPU (one loader and one mapper thread feed it)")
     p.add_argument("--num-channels", type=int, default=512)
     p.add_argument("-e", "--max-events", type=int, default=30000, help="Will give up on a read after this many events have been processed")
     p.add_argument("-c", "--max-chunks", type=int, default=1000000, help="Will give up on a read after this many chunks have been processed")
     p.add_argument("--chunk-time", type=float, default=1, help="Length of chunks in seconds")
     p.add_argument("--device", type=int, default=0, help="GPU ordinal")
-    p.add_argument("--batch-reads", type=int, default=4096, help="Reads per GPU batch")
+    p.add_argument("--batch-reads", type=int, default=None, help="Reads per GPU batch (default: as many as the mapper keeps in flight)")
     p.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use: one worker process each, fast5 files dealt round-robin")
 
     p = sp.add_parser("sim", help="Simulate real-time targeted sequencing from fast5 files (enrich / deplete decisions per read)")

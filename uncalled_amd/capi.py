@@ -32,7 +32,8 @@ class Params(C.Structure):
 
 class MapperOpts(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
-                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("n_big", C.c_uint32), ("big_clusters", C.c_uint32)]
+                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("n_big", C.c_uint32), ("big_clusters", C.c_uint32),
+                ("events_reads_per_wave", C.c_uint32)]
 
 
 CALIB = np.dtype([("range", "<f4"), ("offset", "<f4"), ("digitisation", "<f4")])
@@ -78,6 +79,8 @@ def load(path=None):
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.unc_last_error.restype = C.c_char_p
     L.unc_version.restype = C.c_char_p
+    L.unc_host_alloc.argtypes = [u64]; L.unc_host_alloc.restype = vp
+    L.unc_host_free.argtypes = [vp]; L.unc_host_free.restype = None
     L.unc_params_default.argtypes = [C.POINTER(Params)]
     L.unc_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.unc_index_free.argtypes = [vp]
@@ -230,11 +233,11 @@ class Mapper:
     """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
 
     def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0, n_big=0,
-                 big_clusters=0):
+                 big_clusters=0, events_reads_per_wave=0):
         self.index = index
         self.L = index.L
         self.params = params or default_params(self.L)
-        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, n_big, big_clusters)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, n_big, big_clusters, events_reads_per_wave)
         h = C.c_void_p()
         _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
         self.h = h

@@ -283,9 +283,7 @@ bool write_fast5(const std::string &path, const std::vector<RawRead> &reads, boo
 }
 
 // ------------------------------------------------------------------ MapPool (map_pool.cpp:28-158), batched on one GPU
-static Conf with_buffer(Conf c) { if (c.max_buffer < c.batch_reads) c.max_buffer = c.batch_reads; return c; }
-
-MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(with_buffer(conf)) {
+MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(conf) {
     unc_params_t p;
     unc_params_default(&p);
     p.max_events = conf.max_events;
@@ -297,47 +295,149 @@ MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(with_buffer(conf)) {
         std::cerr << "Error: " << unc_last_error() << "\n";   // Mapper::load_static aborts on a bad index, mapper.cpp:118-127
         abort();
     }
+    // a batch = as many reads as the mapper keeps in flight (the time-sliced scheduler of k_map needs them all at once
+    // to find the long reads early); --batch-reads overrides
+    uint32_t geo[5] = {0, 0, 0, 0, 0};
+    unc_mapper_geometry(mapper_, geo);
+    batch_reads_ = conf.batch_reads ? conf.batch_reads : (geo[1] ? geo[1] : 4096);
+    free_.push_back(0);
+    free_.push_back(1);
 }
 
 MapPool::~MapPool() {
+    stop();
+    for (Batch &b : bufs_) if (b.raw) unc_host_free(b.raw);
     if (mapper_) unc_mapper_free(mapper_);
     if (ix_) unc_index_free(ix_);
 }
 
+void MapPool::add_fast5(const std::string &fname) {
+    std::lock_guard<std::mutex> lk(mtx_);
+    new_files_.push_back(fname);
+}
+
+bool MapPool::grow(Batch &b, uint64_t need) {
+    if (need <= b.cap) return true;
+    uint64_t cap = b.cap ? b.cap : (64ull << 20);
+    while (cap < need) cap *= 2;
+    int16_t *p = static_cast<int16_t *>(unc_host_alloc(cap * 2));
+    if (!p) return false;
+    if (b.used) memcpy(p, b.raw, b.used * 2);
+    if (b.raw) unc_host_free(b.raw);
+    b.raw = p; b.cap = cap;
+    return true;
+}
+
+// fast5 files -> staged batches (flattened int16 samples in page-locked memory + per-read offsets / calibration)
+void MapPool::loader_main() {
+    for (;;) {
+        int bi;
+        {
+            std::unique_lock<std::mutex> lk(mtx_);
+            cv_.wait(lk, [&] { return stopped_ || !free_.empty(); });
+            if (stopped_) break;
+            bi = free_.front();
+            free_.pop_front();
+            while (!new_files_.empty()) { reader_.add_fast5(new_files_.front()); new_files_.pop_front(); }
+        }
+        Batch &b = bufs_[bi];
+        b.used = 0; b.off.assign(1, 0); b.cal.clear(); b.meta.clear();
+        while (b.meta.size() < batch_reads_) {
+            if (reader_.buffered() == 0 && (reader_.empty() || reader_.fill_buffer() == 0)) break;
+            RawRead r = reader_.pop_read();
+            if (!grow(b, b.used + r.signal.size() + 1)) { std::cerr << "Error: out of page-locked host memory\n"; abort(); }
+            if (!r.signal.empty()) memcpy(b.raw + b.used, r.signal.data(), r.signal.size() * 2);
+            b.used += r.signal.size();
+            b.off.push_back(b.used);
+            b.cal.push_back(r.calib);
+            b.meta.push_back(ReadMeta{r.id, r.channel_idx, r.start_sample});
+        }
+        std::lock_guard<std::mutex> lk(mtx_);
+        if (b.meta.empty()) {          // the files ran dry
+            free_.push_front(bi);
+            loader_done_ = true;
+            cv_.notify_all();
+            break;
+        }
+        staged_.push_back(bi);
+        cv_.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mtx_);
+    loader_done_ = true;
+    cv_.notify_all();
+}
+
+void MapPool::mapper_main() {
+    for (;;) {
+        int bi;
+        {
+            std::unique_lock<std::mutex> lk(mtx_);
+            cv_.wait(lk, [&] { return stopped_ || !staged_.empty() || loader_done_; });
+            if (stopped_ || (staged_.empty() && loader_done_)) break;
+            bi = staged_.front();
+            staged_.pop_front();
+        }
+        Batch &b = bufs_[bi];
+        const size_t n = b.meta.size();
+        std::vector<unc_hit_t> hits(n);
+        if (b.used == 0) { grow(b, 1); b.raw[0] = 0; }
+        const int rc = unc_map_batch(mapper_, (uint32_t)n, b.raw, b.off.data(), b.cal.data(), 0, nullptr, hits.data());
+        if (rc != UNC_OK && rc != UNC_ERR_OVERFLOW) { std::cerr << "Error: " << unc_last_error() << "\n"; abort(); }
+        float ms_e = 0, ms_m = 0;
+        unc_mapper_last_timing(mapper_, &ms_e, &ms_m);
+        const float ms_per_read = (ms_e + ms_m) / (float)n;
+        std::vector<Paf> out;
+        out.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            const unc_hit_t &h = hits[i];
+            Paf p(b.meta[i].id, (uint16_t)(b.meta[i].channel_idx + 1), b.meta[i].start_sample);
+            p.set_read_len(h.rd_len);
+            if (h.mapped) p.set_mapped(h.rd_st, h.rd_en, unc_index_seq_name(ix_, h.rid), h.rf_st, h.rf_en, h.rf_len, h.fwd != 0, (uint16_t)h.matches);
+            // GPU time of the batch / reads in it: reads share the wavefronts, there is no per-read wall clock (the
+            // reference times Mapper::map_read on the read's own thread)
+            p.set_float(Paf::MAP_TIME, ms_per_read);
+            if (h.status)   // the reference's SeedTracker is unbounded: say so instead of printing a silent unmapped line
+                std::cerr << "Warning: read " << b.meta[i].id << ": device scratch overflow (status " << h.status
+                          << ") even after re-mapping with more room; reported unmapped\n";
+            out.push_back(std::move(p));
+        }
+        std::lock_guard<std::mutex> lk(mtx_);
+        for (Paf &p : out) done_.push_back(std::move(p));
+        free_.push_back(bi);
+        cv_.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mtx_);
+    mapper_done_ = true;
+    cv_.notify_all();
+}
+
 std::vector<Paf> MapPool::update() {
     std::vector<Paf> ret;
-    if (stopped_) return ret;
-    reader_.fill_buffer();
-    std::vector<RawRead> batch;
-    while (reader_.buffered() && batch.size() < conf_.batch_reads) batch.push_back(reader_.pop_read());
-    if (batch.empty()) return ret;
-    std::vector<int16_t> flat;
-    std::vector<uint64_t> off{0};
-    std::vector<unc_calib_t> cal;
-    for (auto &r : batch) {
-        flat.insert(flat.end(), r.signal.begin(), r.signal.end());
-        off.push_back(flat.size());
-        cal.push_back(r.calib);
+    std::lock_guard<std::mutex> lk(mtx_);
+    if (!started_ && !stopped_) {       // the first update starts the pipeline: every add_fast5 of the CLI has happened by then
+        started_ = true;
+        loader_ = std::thread(&MapPool::loader_main, this);
+        mapper_thread_ = std::thread(&MapPool::mapper_main, this);
     }
-    if (flat.empty()) flat.push_back(0);
-    std::vector<unc_hit_t> hits(batch.size());
-    const int rc = unc_map_batch(mapper_, (uint32_t)batch.size(), flat.data(), off.data(), cal.data(), 0, nullptr, hits.data());
-    if (rc != UNC_OK && rc != UNC_ERR_OVERFLOW) { std::cerr << "Error: " << unc_last_error() << "\n"; abort(); }
-    float ms_e = 0, ms_m = 0;
-    unc_mapper_last_timing(mapper_, &ms_e, &ms_m);
-    const float ms_per_read = (ms_e + ms_m) / (float)batch.size();
-    for (size_t i = 0; i < batch.size(); ++i) {
-        const unc_hit_t &h = hits[i];
-        Paf p(batch[i].id, (uint16_t)(batch[i].channel_idx + 1), batch[i].start_sample);
-        p.set_read_len(h.rd_len);
-        if (h.mapped) p.set_mapped(h.rd_st, h.rd_en, unc_index_seq_name(ix_, h.rid), h.rf_st, h.rf_en, h.rf_len, h.fwd != 0, (uint16_t)h.matches);
-        p.set_float(Paf::MAP_TIME, ms_per_read);   // amortised over the batch (the reference times each read on its thread)
-        ret.push_back(p);
-    }
+    ret.swap(done_);
     return ret;
 }
 
-bool MapPool::running() { return !stopped_ && !reader_.empty(); }
-void MapPool::stop() { stopped_ = true; }
+bool MapPool::running() {
+    std::lock_guard<std::mutex> lk(mtx_);
+    if (stopped_) return false;
+    if (!started_) return !new_files_.empty() || !reader_.empty();
+    return !(mapper_done_ && done_.empty());
+}
+
+void MapPool::stop() {
+    {
+        std::lock_guard<std::mutex> lk(mtx_);
+        stopped_ = true;
+        cv_.notify_all();
+    }
+    if (loader_.joinable()) loader_.join();
+    if (mapper_thread_.joinable()) mapper_thread_.join();
+}
 
 }  // namespace unc_host

@@ -8,8 +8,11 @@
 #pragma once
 #include <stdint.h>
 
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -99,22 +102,45 @@ private:
 // /Raw/Reads/Read_<n> + /UniqueGlobalKey/channel_id).  Used by the simulators and the tests; the reference only reads.
 bool write_fast5(const std::string &path, const std::vector<RawRead> &reads, bool multi, float sample_rate = 4000.0f);
 
+// MapPool (map_pool.cpp:28-158) on one GPU.  The reference hands reads to worker threads and update() never blocks; here
+// a loader thread reads fast5 files into page-locked staging buffers (two of them: batch k+1 is read and flattened while
+// batch k is on the GPU), a mapper thread feeds them to unc_map_batch, and update() returns whatever has finished.
 class MapPool {
 public:
     explicit MapPool(const Conf &conf);
     ~MapPool();
     MapPool(const MapPool &) = delete;
-    void add_fast5(const std::string &fname) { reader_.add_fast5(fname); }
+    void add_fast5(const std::string &fname);
     std::vector<Paf> update();
     bool running();
     void stop();
+    uint32_t batch_reads() const { return batch_reads_; }
 
 private:
+    struct ReadMeta { std::string id; uint16_t channel_idx; uint64_t start_sample; };
+    struct Batch {
+        int16_t *raw = nullptr;        // page-locked
+        uint64_t cap = 0, used = 0;
+        std::vector<uint64_t> off;
+        std::vector<unc_calib_t> cal;
+        std::vector<ReadMeta> meta;
+    };
+    void loader_main();
+    void mapper_main();
+    bool grow(Batch &b, uint64_t need);
     Conf conf_;
     Fast5Reader reader_;
     unc_index_t *ix_ = nullptr;
     unc_mapper_t *mapper_ = nullptr;
-    bool stopped_ = false;
+    uint32_t batch_reads_ = 0;
+    Batch bufs_[2];
+    std::deque<int> free_, staged_;       // indices into bufs_
+    std::deque<std::string> new_files_;   // add_fast5 -> loader thread
+    std::vector<Paf> done_;
+    std::mutex mtx_;
+    std::condition_variable cv_;
+    std::thread loader_, mapper_thread_;
+    bool started_ = false, stopped_ = false, loader_done_ = false, mapper_done_ = false;
 };
 
 }  // namespace unc_host

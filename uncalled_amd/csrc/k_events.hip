@@ -1,11 +1,17 @@
-// Event detection + whole-read normalisation, one LANE per read (each lane runs the reference's
-// strictly sequential two-window t-test detector over its own read, so the double cumulative sums
-// are added in exactly the reference's order).  Replaces, for a batch of reads:
+// Event detection + whole-read normalisation.  Replaces, for a batch of reads:
 //   ReadBuffer calibration            read_buffer.cpp:239-241   (u16 reinterpretation included)
 //   EventDetector::get_means          event_detector.cpp:133-145 (add_sample 83-112, compute_tstat
 //                                     174-219, peak_detect 221-279, create_event 296-319)
 //   Normalizer::set_signal / at       normalizer.cpp:31-44,114-118 (scale/shift only; the affine map
 //                                     itself is applied per event in k_map)
+// Work decomposition (k_events): the detector is a strictly sequential machine per read -- two peak-detector FSMs that
+// consume the two t-statistics of EVERY sample and whose state after a sample depends on all earlier ones -- so one
+// lane follows one read, and the double cumulative sums are added in exactly the reference's order (no exactness
+// argument needed).  What is parallel inside a read, the t-statistics, is exposed as instruction-level parallelism: a
+// lane takes its samples eight at a time (one aligned 16-byte load), keeps the 20 cumulative sums the eight window
+// pairs need in registers, computes the sixteen t-statistics independently and only then runs the sixteen FSM steps.
+// A wavefront carries `reads_per_wave` reads (64, or fewer so that a batch spreads over more wavefronts).
+// (k_rt_events below, one chunk per lane, keeps its 16-slot ring of sums in LDS.)
 // All float expressions are written one IEEE operation at a time and the file is compiled with
 // -ffp-contract=off: the reference is built without FMA (setup.py:121).
 #include <hip/hip_runtime.h>
@@ -86,74 +92,133 @@ __device__ __forceinline__ float tstat(const double *sum, const double *sumsq, i
     return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(__fdiv_rn(combined_var, wf)));
 }
 
-__global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P) {
-    __shared__ double s_sum[RING * WAVE];
-    __shared__ double s_sumsq[RING * WAVE];
-    const int lane = lane_id();
-    const uint32_t r = blockIdx.x * WAVE + lane;
-    const bool active = r < R.n_reads;
+// ---- k_events: register-window detector ----------------------------------------------------------------------------
+constexpr int EB = 8;                 // samples per block of the fast path
+constexpr int WIN = 12 + EB;          // window of cumulative sums: positions base-11 .. base+EB (13 = the reference's ring)
 
-    uint64_t off = 0, n = 0, moff = 0;
-    uint32_t mcap = 0;
-    float cal_range = 1.f, cal_offset = 0.f, cal_digit = 1.f;
-    if (active) {
-        off = R.offsets[r];
-        n = R.offsets[r + 1] - off;
-        moff = R.moff[r];
-        mcap = (uint32_t)(R.moff[r + 1] - moff);
-        cal_range = R.calib[r].range;
-        cal_offset = R.calib[r].offset;
-        cal_digit = R.calib[r].digitisation;
+// compute_tstat (event_detector.cpp:174-219) for the sample whose newest cumulative sum sits at window index `ni`:
+// buf_mid = ni - 6, the two windows end / start there.  `st` = index of C[buf_mid - w] (the caller resolves the
+// reference's wrap for the first samples).
+__device__ __forceinline__ float tstat_win(const double *C, const double *Q, int ni, int st, uint32_t w) {
+    const float wf = (float)w;
+    const int i = ni - 6, en = i + (int)w;
+    double sum1 = C[i] - C[st];
+    double sumsq1 = Q[i] - Q[st];
+    float sum2 = (float)(C[en] - C[i]);
+    float sumsq2 = (float)(Q[en] - Q[i]);
+    float mean1 = (float)(sum1 / (double)wf);
+    float mean2 = __fdiv_rn(sum2, wf);
+    float m1sq = __fmul_rn(mean1, mean1), q2 = __fdiv_rn(sumsq2, wf), m2sq = __fmul_rn(mean2, mean2);
+    float combined_var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)q2) - (double)m2sq);
+    combined_var = fmaxf(combined_var, FLT_MIN);
+    float delta_mean = __fsub_rn(mean2, mean1);
+    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(__fdiv_rn(combined_var, wf)));
+}
+
+struct EvRun {                        // what EventDetector carries from sample to sample
+    Detector sd, ld;
+    uint32_t t, evt_st, total_events, n_kept;
+    double evt_st_sum, mean_sum;
+    float len_sum;
+};
+
+// both peak detectors on one sample's t-statistics, then create_event (event_detector.cpp:101-110,296-319); csum = C[evt_en]
+__device__ __forceinline__ void fsm_step(EvRun &E, const unc_params_t &P, float t1, float t2, uint32_t buf_mid, double csum, float *means,
+                                         uint32_t mcap) {
+    const bool p1 = peak_detect(E.sd, &E.ld, t1, buf_mid, P.peak_height);
+    const bool p2 = peak_detect(E.ld, nullptr, t2, buf_mid, P.peak_height);
+    if (p1 || p2) {
+        const uint32_t evt_en = buf_mid - UNC_WINDOW1 + 1;
+        const uint32_t length = (uint32_t)(float)(evt_en - E.evt_st);
+        float mean = (float)((csum - E.evt_st_sum) / (double)length);
+        E.evt_st = evt_en;
+        E.evt_st_sum = csum;
+        E.len_sum = __fadd_rn(E.len_sum, (float)length);
+        E.total_events++;
+        mean = __fmul_rn(__fadd_rn(mean, 0.0f), 1.0f);   // calibrate(): cal_offset_=0, cal_coef_=1
+        if (mean >= P.min_mean && mean <= P.max_mean && E.n_kept < mcap) {
+            means[E.n_kept++] = mean;
+            E.mean_sum += (double)mean;                  // Normalizer::set_signal's first sum, in index order
+        }
     }
-    // EventDetector::reset, event_detector.cpp:47-77
-    s_sum[lane] = 0.0;
-    s_sumsq[lane] = 0.0;
-    uint32_t t = 1, evt_st = 0, total_events = 0, n_kept = 0;
-    double evt_st_sum = 0.0, evt_st_sumsq = 0.0;
-    float len_sum = 0.0f;
-    Detector sd{P.threshold1, P.window_length1, 0u, -1, FLT_MAX, false};
-    Detector ld{P.threshold2, P.window_length2, 0u, -1, FLT_MAX, false};
+}
+
+__global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P, uint32_t reads_per_wave) {
+    const int lane = lane_id();
+    const uint32_t r = blockIdx.x * reads_per_wave + (uint32_t)lane;
+    const bool active = (uint32_t)lane < reads_per_wave && r < R.n_reads;
+    if (!active) return;              // no collectives in this kernel
+
+    const uint64_t off = R.offsets[r], n = R.offsets[r + 1] - off, moff = R.moff[r];
+    const uint32_t mcap = (uint32_t)(R.moff[r + 1] - moff);
+    const float cal_range = R.calib[r].range, cal_offset = R.calib[r].offset, cal_digit = R.calib[r].digitisation;
     const int16_t *raw = R.raw + off;
     float *means = R.means + moff;
 
-    for (uint64_t k = 0; k < n; ++k) {
-        // calibration: u16 reinterpretation of the stored i16, three float roundings
-        uint16_t ru = (uint16_t)raw[k];
-        float s = __fdiv_rn(__fmul_rn(cal_range, __fadd_rn((float)(int)ru, cal_offset)), cal_digit);
-        // add_sample: position t gets C[t] = C[t-1] + s, Q[t] = Q[t-1] + (float)(s*s)
-        uint32_t cur = (t & (RING - 1)) * WAVE + lane, prv = ((t - 1) & (RING - 1)) * WAVE + lane;
-        float ss = __fmul_rn(s, s);
-        s_sum[cur] = s_sum[prv] + (double)s;
-        s_sumsq[cur] = s_sumsq[prv] + (double)ss;
-        t++;
-        uint32_t buf_mid = t - 7;   // t - BUF_LEN/2 - 1, wraps for the first samples exactly as the u32 does
-        float t1 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW1);
-        float t2 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW2);
-        bool p1 = peak_detect(sd, &ld, t1, buf_mid, P.peak_height);
-        bool p2 = peak_detect(ld, nullptr, t2, buf_mid, P.peak_height);
-        if (p1 || p2) {
-            // create_event(buf_mid - window_length1 + 1)
-            uint32_t evt_en = buf_mid - UNC_WINDOW1 + 1;
-            uint32_t eb = (evt_en & (RING - 1)) * WAVE + lane;
-            uint32_t length = (uint32_t)(float)(evt_en - evt_st);
-            double csum = s_sum[eb], csq = s_sumsq[eb];
-            float mean = (float)((csum - evt_st_sum) / (double)length);
-            evt_st = evt_en;
-            evt_st_sum = csum;
-            evt_st_sumsq = csq;
-            len_sum = __fadd_rn(len_sum, (float)length);
-            total_events++;
-            mean = __fmul_rn(__fadd_rn(mean, 0.0f), 1.0f);   // calibrate(): cal_offset_=0, cal_coef_=1
-            if (mean >= P.min_mean && mean <= P.max_mean && n_kept < mcap) means[n_kept++] = mean;
+    // EventDetector::reset, event_detector.cpp:47-77
+    EvRun E;
+    E.sd = Detector{P.threshold1, P.window_length1, 0u, -1, FLT_MAX, false};
+    E.ld = Detector{P.threshold2, P.window_length2, 0u, -1, FLT_MAX, false};
+    E.t = 1; E.evt_st = 0; E.total_events = 0; E.n_kept = 0; E.evt_st_sum = 0.0; E.mean_sum = 0.0; E.len_sum = 0.0f;
+    double C[WIN], Q[WIN];            // C[i] = cumulative sum at position (next sample's position) - 12 + i
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) { C[i] = 0.0; Q[i] = 0.0; }
+
+    // calibration: u16 reinterpretation of the stored i16, three float roundings
+    auto calibrate = [&](int16_t v) {
+        return __fdiv_rn(__fmul_rn(cal_range, __fadd_rn((float)(int)(uint16_t)v, cal_offset)), cal_digit);
+    };
+    // one sample, every special case of the first samples included (the u32 wrap of buf_mid, `t <= 2w`, and the slot the
+    // reference's `(buf_mid - w) % 13` lands on while buf_mid < w: the newest sum)
+    auto step1 = [&](float s) {
+        C[12] = C[11] + (double)s;
+        Q[12] = Q[11] + (double)__fmul_rn(s, s);
+        E.t++;
+        const uint32_t buf_mid = E.t - 7;
+        const float t1 = E.t <= 2 * UNC_WINDOW1 ? 0.0f : tstat_win(C, Q, 12, buf_mid >= UNC_WINDOW1 ? 6 - UNC_WINDOW1 : 12, UNC_WINDOW1);
+        const float t2 = E.t <= 2 * UNC_WINDOW2 ? 0.0f : tstat_win(C, Q, 12, buf_mid >= UNC_WINDOW2 ? 6 - UNC_WINDOW2 : 12, UNC_WINDOW2);
+        fsm_step(E, P, t1, t2, buf_mid, C[4], means, mcap);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { C[i] = C[i + 1]; Q[i] = Q[i + 1]; }
+    };
+
+    uint64_t k = 0;
+    // head: the first 16 samples (special cases) and up to the first 16-byte boundary of this read's samples
+    const uint64_t misalign = (8u - (uint32_t)(((uintptr_t)raw >> 1) & 7u)) & 7u;     // samples until raw + k is 16-byte aligned
+    uint64_t head = 16 + misalign;                                                    // 16 is a multiple of EB
+    if (head > n) head = n;
+    for (; k < head; ++k) step1(calibrate(raw[k]));
+    // middle: EB samples per iteration, everything about them that does not depend on the detectors first
+    for (; k + EB <= n; k += EB) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(raw + k);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float t1[EB], t2[EB];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const float s = calibrate((int16_t)(uint16_t)(w[j >> 1] >> ((j & 1) << 4)));
+            C[12 + j] = C[11 + j] + (double)s;
+            Q[12 + j] = Q[11 + j] + (double)__fmul_rn(s, s);
         }
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            t1[j] = tstat_win(C, Q, 12 + j, 6 + j - UNC_WINDOW1, UNC_WINDOW1);
+            t2[j] = tstat_win(C, Q, 12 + j, 6 + j - UNC_WINDOW2, UNC_WINDOW2);
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            E.t++;
+            fsm_step(E, P, t1[j], t2[j], E.t - 7, C[4 + j], means, mcap);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { C[i] = C[i + EB]; Q[i] = Q[i + EB]; }
     }
+    for (; k < n; ++k) step1(calibrate(raw[k]));     // tail
 
     // Normalizer::set_signal: sequential double sums in index order, then scale/shift (::at)
     float scale = 0.0f, shift = 0.0f;
-    if (active && n_kept > 0) {
-        double mean = 0.0;
-        for (uint32_t i = 0; i < n_kept; ++i) mean += (double)means[i];
-        mean /= (double)n_kept;
+    const uint32_t n_kept = E.n_kept;
+    if (n_kept > 0) {
+        const double mean = E.mean_sum / (double)n_kept;
         double varsum = 0.0;
         for (uint32_t i = 0; i < n_kept; ++i) {
             double e = (double)means[i] - mean;
@@ -163,16 +228,14 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P) {
         scale = (float)((double)tgt_stdv / sqrt(varsum / (double)n_kept));
         shift = (float)((double)tgt_mean - (double)scale * mean);
     }
-    if (active) {
-        unc_evt_info_t inf;
-        inf.n_events = n_kept;
-        inf.total_events = total_events;
-        inf.len_sum = len_sum;
-        inf.scale = scale;
-        inf.shift = shift;
-        inf.pad = 0;
-        R.info[r] = inf;
-    }
+    unc_evt_info_t inf;
+    inf.n_events = n_kept;
+    inf.total_events = E.total_events;
+    inf.len_sum = E.len_sum;
+    inf.scale = scale;
+    inf.shift = shift;
+    inf.pad = 0;
+    R.info[r] = inf;
 }
 
 }  // namespace unc
@@ -348,7 +411,8 @@ void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc
     hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + WAVE - 1) / WAVE), dim3(WAVE), 0, st, raw, raw_pa, chunks, n_chunks, chans, norm_ring, P,
                        tgt_mean, tgt_stdv, info, ring0_out);
 }
-void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st) {
-    hipLaunchKernelGGL(k_events, dim3((rd.n_reads + WAVE - 1) / WAVE), dim3(WAVE), 0, st, rd, P);
+void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st, uint32_t reads_per_wave) {
+    if (reads_per_wave == 0 || reads_per_wave > (uint32_t)WAVE) reads_per_wave = WAVE;
+    hipLaunchKernelGGL(k_events, dim3((rd.n_reads + reads_per_wave - 1) / reads_per_wave), dim3(WAVE), 0, st, rd, P, reads_per_wave);
 }
 }  // namespace unc

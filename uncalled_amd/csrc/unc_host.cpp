@@ -38,7 +38,13 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *unc_last_error(void) { return g_err; }
-extern "C" const char *unc_version(void) { return "uncalled_hip 0.1 (gfx950)"; }
+extern "C" const char *unc_version(void) { return "uncalled_hip 0.2 (gfx950)"; }
+extern "C" void *unc_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void unc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" void unc_params_default(unc_params_t *p) {
     // mapper.cpp:29-40
@@ -397,7 +403,7 @@ extern "C" int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *l
 struct unc_mapper {
     const unc_index *ix = nullptr;
     unc_params_t P;
-    uint32_t n_slots = 0, n_waves = 0, slice_events = 1024;
+    uint32_t n_slots = 0, n_waves = 0, slice_events = 1024, ev_rpw = 32;
     DevSched sched{};             // ctl != null: sliced batch scheduler (n_slots > n_waves)
     DevScratch sc;
     uint64_t device_bytes = 0;
@@ -533,6 +539,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     m->n_slots = n_slots;
     m->n_waves = n_waves;
     m->slice_events = (opts && opts->slice_events) ? opts->slice_events : 1024;
+    m->ev_rpw = (opts && opts->events_reads_per_wave) ? opts->events_reads_per_wave : 32;
+    if (m->ev_rpw > (uint32_t)WAVE) return fail(UNC_ERR_ARG, "events_reads_per_wave must be in 1..64");
     size_t bytes = 0;
     // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
     const uint32_t msp = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
@@ -704,7 +712,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(m->d_next, 0, 16, st));   // [0] queue head, [2..3] wave-lifetime ticks
     HIPCHK(hipEventRecord(m->ev[0], st));
-    launch_events(rd, m->P, st);
+    launch_events(rd, m->P, st, m->ev_rpw);
     HIPCHK(hipEventRecord(m->ev[1], st));
     const uint32_t grid = n_reads < m->n_waves ? n_reads : m->n_waves;
     const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
@@ -816,7 +824,7 @@ extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_
     DevReads rd;
     int rc = stage_batch(m, n_reads, raw, offsets, calib, 0, st, &rd);
     if (rc) return rc;
-    launch_events(rd, m->P, st);
+    launch_events(rd, m->P, st, m->ev_rpw);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(info, m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -839,7 +847,7 @@ extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, 
     DevReads rd;
     int rc = stage_batch(m, 1, raw, offsets, calib, 0, st, &rd);
     if (rc) return rc;
-    launch_events(rd, m->P, st);
+    launch_events(rd, m->P, st, m->ev_rpw);
     SlotState s0;
     memset(&s0, 0, sizeof s0);
     s0.max_map.rstart = 1; s0.max_map.evt_st = 1;   // NULL_ALN

@@ -5,7 +5,7 @@
 #include "unc_dev_types.h"
 
 namespace unc {
-void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st);
+void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st, uint32_t reads_per_wave = 0);
 void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans, float *norm_ring,
                       const unc_params_t &P, float tgt_mean, float tgt_stdv, unc_evt_info_t *info, uint32_t *ring0_out, hipStream_t st);
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
