@@ -9,12 +9,10 @@ import pytest
 
 from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
 
-pytestmark = pytest.mark.lanesim
 G = Path(__file__).resolve().parent / "golden"
 
 
-def test_chunk_class(sim_host):
-    unc = sim_host
+def case_chunk_class(unc):
     sig = [float(i) for i in range(10)]
     c = unc.Chunk("r1", 7, 3, 4000, sig, 2, 5)
     assert (c.id, c.channel, c.number, c.size(), c.empty(), c.start) == ("r1", 7, 3, 5, False, 4000)
@@ -38,8 +36,7 @@ def _conf(unc, n_channels, **kw):
     return c
 
 
-def test_realtime_pool_ordered_replay_matches_oracle(sim_host, oracle_lib, example, goldens):
-    unc, po = sim_host, oracle_lib
+def case_realtime_pool_ordered_replay(unc, po, example, goldens):
     n_channels, n_reads, chunk_len = 3, 9, 4000
     off = goldens["sim_offsets"]
     reads = [po.calibrate(example["signal"], example["range"], example["offset"], example["digitisation"])]
@@ -90,10 +87,9 @@ def test_realtime_pool_ordered_replay_matches_oracle(sim_host, oracle_lib, examp
     assert pool.all_finished() and pool.update() == []
 
 
-def test_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens):
+def case_add_chunk_resets_the_previous_read(unc, po, goldens):
     """RealtimePool::add_chunk (realtime_pool.cpp:74-110): a chunk of a NEW read on a channel whose read is still undecided
     ends that read (unmapped, `ended`) and starts the new one."""
-    unc, po = sim_host, oracle_lib
     pool = unc.RealtimePool(_conf(unc, 2))
     noise = (np.random.default_rng(3).normal(90.0, 12.0, 9000)).astype(np.float32).tolist()      # never maps
     assert pool.add_chunk(unc.Chunk("noise", 1, 5, 100, noise, 0, 4000))
@@ -117,9 +113,8 @@ def test_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens):
     assert mapped and mapped[0].is_mapped() and pool.all_finished()
 
 
-def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
+def case_client_sim_feeds_the_decision_loop(unc, tmp_path, goldens):
     """ClientSim-shaped source over fast5 files + the enrich/deplete loop of scripts/uncalled:216-256 (uncalled_amd sim)."""
-    unc = sim_host
     off = goldens["sim_offsets"]
     reads = [dict(id="sim-%d" % i, channel=1 + i % 2, number=i, start=1000 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
                   signal=goldens["sim_signal"][int(off[i]):int(off[i + 1])].tolist()) for i in range(4)]
@@ -155,10 +150,9 @@ def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
         assert ("\tej:f:" in l) == (l.split("\t")[2] != "*") and (("\tkp:f:" in l) or ("\ten:f:" in l) or ("\tej:f:" in l))
 
 
-def test_map_pool_pipeline_matches_oracle(sim_host, oracle_lib, tmp_path, goldens):
+def case_map_pool_pipeline(unc, po, tmp_path, goldens):
     """MapPool (loader thread -> page-locked staging buffers -> mapper thread -> update()) over several fast5 files and
     batches: every read comes out once, PAF columns as the oracle maps the same signal."""
-    unc, po = sim_host, oracle_lib
     off = goldens["sim_offsets"]
     n = 7
     reads = [dict(id="sim-%d" % i, channel=1 + i, number=i, start=100 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
@@ -191,3 +185,29 @@ def test_map_pool_pipeline_matches_oracle(sim_host, oracle_lib, tmp_path, golden
         else:
             assert int(c[1]) == want[0] and c[2] == "*"
         assert "ch:i:%d" % r["channel"] in c and "st:i:%d" % r["start"] in c
+
+
+# ---- the cases above on the lanesim build of the host module (tests/test_gpu_host.py runs them on the real one)
+@pytest.mark.lanesim
+def test_chunk_class(sim_host):
+    case_chunk_class(sim_host)
+
+
+@pytest.mark.lanesim
+def test_realtime_pool_ordered_replay_matches_oracle(sim_host, oracle_lib, example, goldens):
+    case_realtime_pool_ordered_replay(sim_host, oracle_lib, example, goldens)
+
+
+@pytest.mark.lanesim
+def test_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens):
+    case_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens)
+
+
+@pytest.mark.lanesim
+def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
+    case_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens)
+
+
+@pytest.mark.lanesim
+def test_map_pool_pipeline_matches_oracle(sim_host, oracle_lib, tmp_path, goldens):
+    case_map_pool_pipeline(sim_host, oracle_lib, tmp_path, goldens)

@@ -23,15 +23,17 @@ sim = simulate_reads_torch(codes, lens, n, seed=42, device="cuda:0")
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 first = None
 for spec in sys.argv[2:]:
-    # lib.so[@n_slots[@slice_events]]: n_slots 0 = library default, 1 = one slot per wavefront (no time slicing)
+    # lib.so[@n_slots[@slice_events[@events_reads_per_wave]]]: n_slots 0 = library default, 1 = one slot per wavefront (no time slicing)
     lib, *rest = spec.split("@")
     kw = {}
     if rest and int(rest[0]) == 1:
         kw = dict(n_slots=256 * 12, n_waves=256 * 12)
     elif rest and int(rest[0]) > 1:
         kw = dict(n_slots=int(rest[0]), n_waves=256 * 12)
-    if len(rest) > 1:
+    if len(rest) > 1 and int(rest[1]):
         kw["slice_events"] = int(rest[1])
+    if len(rest) > 2:
+        kw["events_reads_per_wave"] = int(rest[2])
     try:
         L = capi.load(lib)
         ix = capi.Index(pre, lib=L)
@@ -39,9 +41,10 @@ for spec in sys.argv[2:]:
             m = capi.Mapper(ix, **kw)
         except TypeError:
             m = capi.Mapper(ix)
-        t = []
+        t, te = [], []
         for i in range(2):
             hits = m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
+            te.append(m.last_timing()[0])
             t.append(m.last_timing()[1])
         busy = m.last_wave_busy() if hasattr(L, "unc_mapper_last_wave_busy") else -1
         if hasattr(L, "unc_mapper_set_profile"):   # phase shares from one extra pass of the counting instantiation
@@ -56,7 +59,7 @@ for spec in sys.argv[2:]:
             bad = [f for f in hits.dtype.names if not np.array_equal(hits[f], first[f])]
             same = "IDENTICAL" if not bad else "MISMATCH in %s (%d reads)" % (bad, int(sum((hits[f] != first[f]).sum() for f in bad)))
         print({k: round(v / tot, 3) for k, v in pc.items() if v})
-        print(spec.split("/")[-1], "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", same, flush=True)
+        print(spec.split("/")[-1], "k_events ms:", [round(x, 2) for x in te], "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", same, flush=True)
         m.close(); ix.close()
     except Exception as e:   # a bad variant must not hide the others
         print(Path(lib).name, "FAILED:", repr(e)[:300], flush=True)

@@ -8,10 +8,18 @@
 namespace py = pybind11;
 using namespace unc_host;
 
+// tests link these sources a second time against the lanesim build of the C ABI and load both modules into one process:
+// that copy registers its types module-locally
+#ifdef UNC_PYBIND_LOCAL
+#define UNC_ML , py::module_local()
+#else
+#define UNC_ML
+#endif
+
 PYBIND11_MODULE(_uncalled_amd, m) {
     m.doc() = "MI355X-native UNCALLED map path: Conf / MapPool / Paf over libuncalled_hip.so";
 
-    py::class_<Conf>(m, "Conf")
+    py::class_<Conf>(m, "Conf" UNC_ML)
         .def(py::init<>())
 #define PRP(P) .def_readwrite(#P, &Conf::P)
         PRP(threads) PRP(bwa_prefix) PRP(idx_preset) PRP(model_path) PRP(max_events) PRP(seed_len) PRP(chunk_time) PRP(fast5_list)
@@ -19,7 +27,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         PRP(realtime_mode) PRP(active_chs) PRP(duration) PRP(max_active_reads);
 #undef PRP
 
-    py::class_<Paf> paf(m, "Paf");
+    py::class_<Paf> paf(m, "Paf" UNC_ML);
     paf.def(py::init<>())
         .def("print_paf", &Paf::print_paf)
         .def("__str__", &Paf::str)
@@ -28,7 +36,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("set_int", &Paf::set_int)
         .def("set_float", &Paf::set_float)
         .def("set_str", &Paf::set_str);
-    py::enum_<Paf::Tag>(paf, "Tag")
+    py::enum_<Paf::Tag>(paf, "Tag" UNC_ML)
         .value("MAP_TIME", Paf::MAP_TIME).value("EJECT", Paf::EJECT).value("IN_SCAN", Paf::IN_SCAN).value("ENDED", Paf::ENDED)
         .value("KEEP", Paf::KEEP).value("DELAY", Paf::DELAY).value("WAIT_TIME", Paf::WAIT_TIME).value("CHANNEL", Paf::CHANNEL)
         .value("READ_START", Paf::READ_START)
@@ -36,7 +44,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
 
     // ReadBuffer as Fast5Reader::pop_read returns it (read_buffer.hpp:182-198): id / start / channel / raw, with the
     // int16 samples and the calibration triple beside the calibrated floats
-    py::class_<RawRead>(m, "ReadBuffer")
+    py::class_<RawRead>(m, "ReadBuffer" UNC_ML)
         .def("empty", [](const RawRead &r) { return r.signal.empty(); })
         .def("size", [](const RawRead &r) { return r.signal.size(); })
         .def_property_readonly("id", [](const RawRead &r) { return r.id; })
@@ -74,7 +82,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
           },
           py::arg("path"), py::arg("reads"), py::arg("multi") = true, py::arg("sample_rate") = 4000.0f);
 
-    py::class_<Fast5Reader>(m, "Fast5Reader")
+    py::class_<Fast5Reader>(m, "Fast5Reader" UNC_ML)
         .def(py::init<const Conf &>())
         .def(py::init([](const std::string &fast5_list, const std::string &read_list, uint32_t max_reads, uint32_t max_buffer) {
             Conf c; c.fast5_list = fast5_list; c.read_list = read_list; c.max_reads = max_reads; c.max_buffer = max_buffer;
@@ -92,7 +100,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
 
     // ---- realtime path: Chunk / RealtimePool / ClientSim with the reference's names (pybinder.cpp:33-47,
     //      chunk.hpp:47-59, realtime_pool.hpp:63-70, client_sim.hpp:57-75)
-    py::class_<Chunk>(m, "Chunk")
+    py::class_<Chunk>(m, "Chunk" UNC_ML)
         .def(py::init<>())
         .def(py::init([](const std::string &id, uint16_t channel, uint32_t number, uint64_t start, const std::string &dtype, const py::bytes &raw) {
             return new Chunk(id, channel, number, start, dtype, std::string(raw));
@@ -108,7 +116,7 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def_property_readonly("id", &Chunk::get_id)
         .def_property_readonly("start", &Chunk::get_start);
 
-    py::class_<RealtimePool> rp(m, "RealtimePool");
+    py::class_<RealtimePool> rp(m, "RealtimePool" UNC_ML);
     rp.def(py::init<const Conf &>())
         .def("add_chunk", &RealtimePool::add_chunk)
         .def("try_add_chunk", &RealtimePool::try_add_chunk)
@@ -118,11 +126,11 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("stop_all", &RealtimePool::stop_all)
         .def("active_count", &RealtimePool::active_count)
         .def("last_round_ms", &RealtimePool::last_round_ms);
-    py::enum_<RealtimePool::Mode>(rp, "RealtimeMode").value("DEPLETE", RealtimePool::DEPLETE).value("ENRICH", RealtimePool::ENRICH).export_values();
-    py::enum_<RealtimePool::ActiveChs>(rp, "ActiveChs")
+    py::enum_<RealtimePool::Mode>(rp, "RealtimeMode" UNC_ML).value("DEPLETE", RealtimePool::DEPLETE).value("ENRICH", RealtimePool::ENRICH).export_values();
+    py::enum_<RealtimePool::ActiveChs>(rp, "ActiveChs" UNC_ML)
         .value("FULL", RealtimePool::FULL).value("EVEN", RealtimePool::EVEN).value("ODD", RealtimePool::ODD).export_values();
 
-    py::class_<ClientSim>(m, "ClientSim")
+    py::class_<ClientSim>(m, "ClientSim" UNC_ML)
         .def(py::init<const Conf &>())
         .def("add_fast5", &ClientSim::add_fast5)
         .def("load_fast5s", &ClientSim::load_fast5s)
@@ -133,10 +141,11 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("get_runtime", &ClientSim::get_runtime)
         .def_property_readonly("is_running", &ClientSim::is_running);
 
-    py::class_<MapPool>(m, "MapPool")
+    py::class_<MapPool>(m, "MapPool" UNC_ML)
         .def(py::init<const Conf &>())
         .def("update", &MapPool::update)
         .def("running", &MapPool::running)
         .def("add_fast5", &MapPool::add_fast5)
+        .def("batch_reads", &MapPool::batch_reads)
         .def("stop", &MapPool::stop);
 }
