@@ -71,23 +71,13 @@ __device__ __forceinline__ FmPart fm_load_part(const DevIndex &ix, uint64_t kk, 
     return b;
 }
 
-#ifndef UNC_FM_XOR
-__device__ __forceinline__ uint64_t fm_part_rank(const FmPart &b, uint64_t kk, uint32_t c) {
-    FmBlock f;
-    f.q0 = f.q1 = make_uint4(0u, 0u, 0u, 0u);
-    f.q2 = b.lo; f.q3 = b.hi;
-    return b.cnt + fm_block_rank(f, kk, c);
-}
-
-#else
-// experiment (off by default; parity-checked under the emulator and on the GPU; measured neutral on the plain kernel,
-// -4.5 % on the profiling instantiation, 20 k reads): the same rank with the base folded
-// into an XOR pattern (no per-word selects on c) and the prefix mask of each word derived arithmetically from the
-// position -- about half the instructions of the form above
+// rank inside the loaded words: the base folded into an XOR pattern (both bits of a 2-bit field set <=> the symbol equals c, no
+// per-word selects on c) and the prefix mask of each word derived arithmetically from the position -- about half the
+// instructions of a select-per-word form (round 2, 50 k E. coli reads, same box: k_map 6368 -> 6122 ms)
 __device__ __forceinline__ uint32_t fm_word_rank(uint32_t w_hi, uint32_t w_lo, uint64_t npat, int32_t keep) {
     // keep: how many of this word's 32 symbols count (<= 0: none, >= 32: all); symbol j sits at bits 62 - 2j .. 63 - 2j
     const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
-    const uint64_t x = w ^ npat;                                  // both bits of a field set <=> the symbol equals c
+    const uint64_t x = w ^ npat;
     uint64_t m = x & (x >> 1) & 0x5555555555555555ull;
     const int32_t k = keep < 0 ? 0 : (keep > 32 ? 32 : keep);
     const uint64_t pm = k == 0 ? 0ull : (~0ull << (64 - 2 * k));
@@ -102,7 +92,6 @@ __device__ __forceinline__ uint64_t fm_part_rank(const FmPart &b, uint64_t kk, u
                        fm_word_rank(b.hi.x, b.hi.y, npat, r1 - 64) + fm_word_rank(b.hi.z, b.hi.w, npat, r1 - 96);
     return b.cnt + n;
 }
-#endif
 
 // BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c (bwt_2occ).  Like bwt_2occ, the two
 // rank queries share the block when s - 1 and e fall into the same one (nearly always for the short ranges that make

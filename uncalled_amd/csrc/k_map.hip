@@ -139,28 +139,41 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
     else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
 }
 
-// move directory entries [a,b) one slot up / down
+// move directory entries [a,b) one slot up / down, 256 entries (four per lane) per memory round trip: a leaf split on a
+// large set (thousands of leaves on a human-sized reference) is a few trips, not one per 64 entries
 __device__ __forceinline__ void dir_shift_up(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
     for (uint32_t hi = b; hi > a;) {
-        uint32_t lo = hi - a > 64 ? hi - 64 : a;
-        uint32_t idx = lo + lane;
-        ClusterKey k;
-        bool have = idx < hi;
-        if (have) k = tm_dir(M, idx);
+        const uint32_t lo = hi - a > 256 ? hi - 256 : a;
+        ClusterKey k[4];
+        bool have[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = lo + (uint32_t)lane + 64u * j;
+            have[j] = idx < hi;
+            if (have[j]) k[j] = tm_dir(M, idx);
+        }
         wave_sync();
-        if (have) tm_dir_st(M, idx + 1, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (have[j]) tm_dir_st(M, lo + (uint32_t)lane + 64u * j + 1, k[j]);
         wave_sync();
         hi = lo;
     }
 }
 __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
-    for (uint32_t lo = a; lo < b; lo += 64) {
-        uint32_t idx = lo + lane;
-        ClusterKey k;
-        bool have = idx < b;
-        if (have) k = tm_dir(M, idx);
+    for (uint32_t lo = a; lo < b; lo += 256) {
+        ClusterKey k[4];
+        bool have[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = lo + (uint32_t)lane + 64u * j;
+            have[j] = idx < b;
+            if (have[j]) k[j] = tm_dir(M, idx);
+        }
         wave_sync();
-        if (have) tm_dir_st(M, idx - 1, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (have[j]) tm_dir_st(M, lo + (uint32_t)lane + 64u * j - 1, k[j]);
         wave_sync();
     }
 }
@@ -232,6 +245,19 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
     return true;
 }
 
+// The same insert when the caller already holds the target leaf (directory position L, id, count c < LEAF, lane l's key
+// k): no load at all, the keys at and behind `slot` move up one and the new one goes in.
+__device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, const ClusterKey &k,
+                                                    ClusterKey nk, int lane) {
+    if ((uint32_t)lane >= slot && (uint32_t)lane < c) tm_leaf_st(M, id, lane + 1, k);
+    if (lane == 0) {
+        tm_leaf_st(M, id, slot, nk);
+        tm_cnt_st(M, id, c + 1);
+        if (slot == 0) { ClusterKey f = nk; f.pidx = id; tm_dir_st(M, L, f); }
+    }
+    wave_sync();
+}
+
 // SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
 static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
                                 int lane) {
@@ -280,6 +306,10 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
     ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.pidx = 0;
     bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
     bool stop = false;
+    // the leaf the lower bound lies in (where a new key would go), as the scan saw it
+    uint32_t lb_id = id0, lb_c = c0;
+    ClusterKey lb_k = lk;
+    bool lb_held = lb_in_leaf0;
     {
         uint32_t curL = lbL;
         bool first = true;
@@ -291,6 +321,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
                 id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(tm_dir(M, curL).pidx);
                 k = tm_leaf(M, id, lane);
                 c = tm_cnt(M, id);
+                if (first) { lb_id = id; lb_c = c; lb_k = k; lb_held = true; }     // lower bound = slot 0 of this leaf
             }
             if (first) {   // the key at the lower bound is the first one this scan looks at
                 const uint64_t kr = bcast64(k.rstart, (int)from);
@@ -303,11 +334,12 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             if (have) {
                 r1 = k.rstart;
                 e1 = k.evt_en;
-                tl = tm_pay_len(M, k.pidx);
             }
             const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
             const bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
             const bool far = have && dr >= (uint64_t)e2;
+            // total_len_ of the candidates only (on a large reference most seeds have none: one dependent load less)
+            if (in_range) tl = tm_pay_len(M, k.pidx);
             uint32_t tot;
             uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
             if (pm < best_len) pm = best_len;
@@ -388,7 +420,13 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             if (T.n_pay >= M.max_pay) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = T.n_pay;
             wave_sync();
-            if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (lbL == T.n_leaves && d > 0) {
+                // after everything: append to the last leaf = directory position d - 1, which is the one loaded above
+                if (c0 < LEAF) tracker_insert_held(M, d - 1, c0, id0, c0, lk, nk, lane);
+                else if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            } else if (lb_held && lbL < T.n_leaves && lb_c < LEAF) {
+                tracker_insert_held(M, lbL, lbS, lb_id, lb_c, lb_k, nk, lane);
+            } else if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             if (lane == 0) {
                 ClusterPay np; np.ref_st = r2; np.rend = ref_en; np.evt_st = e2; np.total_len = ref_len;
                 np.pad[0] = np.pad[1] = 0;

@@ -403,7 +403,7 @@ extern "C" int unc_match_probs(const unc_index_t *ix, uint32_t n, const float *l
 struct unc_mapper {
     const unc_index *ix = nullptr;
     unc_params_t P;
-    uint32_t n_slots = 0, n_waves = 0, slice_events = 1024, ev_rpw = 32;
+    uint32_t n_slots = 0, n_waves = 0, slice_events = 1024, ev_rpw = 64;
     DevSched sched{};             // ctl != null: sliced batch scheduler (n_slots > n_waves)
     DevScratch sc;
     uint64_t device_bytes = 0;
@@ -539,7 +539,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     m->n_slots = n_slots;
     m->n_waves = n_waves;
     m->slice_events = (opts && opts->slice_events) ? opts->slice_events : 1024;
-    m->ev_rpw = (opts && opts->events_reads_per_wave) ? opts->events_reads_per_wave : 32;
+    m->ev_rpw = (opts && opts->events_reads_per_wave) ? opts->events_reads_per_wave : 64;
     if (m->ev_rpw > (uint32_t)WAVE) return fail(UNC_ERR_ARG, "events_reads_per_wave must be in 1..64");
     size_t bytes = 0;
     // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
