@@ -239,6 +239,11 @@ int unc_rt_process_chunks_f32(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chun
                               void *stream, unc_rt_result_t *results);
 int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *ms_map);
 
+/* ---- measurement aid: `reps` launches that write, then `reps` that read, n_records (made odd) scattered 64-byte records with
+ * one lane per record and four 16-byte accesses per lane -- k_map's access shape with an exactly known byte count, for
+ * calibrating the HBM traffic counters of rocprofv3 (tools/dev/pmc_calib.py, profiles/r02_pmc_k_map.json) */
+int unc_calib_traffic(int device, uint64_t n_records, int reps);
+
 /* ---- stage taps (parity tests) */
 /* event detection + whole-read normalisation only (EventDetector::get_means, event_detector.cpp:133-145;
  * Normalizer::set_signal, normalizer.cpp:31-44).  means (host) receives the kept event means of read i

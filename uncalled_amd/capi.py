@@ -79,6 +79,7 @@ def load(path=None):
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.unc_last_error.restype = C.c_char_p
     L.unc_version.restype = C.c_char_p
+    L.unc_calib_traffic.argtypes = [C.c_int, u64, C.c_int]
     L.unc_host_alloc.argtypes = [u64]; L.unc_host_alloc.restype = vp
     L.unc_host_free.argtypes = [vp]; L.unc_host_free.restype = None
     L.unc_params_default.argtypes = [C.POINTER(Params)]

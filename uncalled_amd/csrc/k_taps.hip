@@ -102,6 +102,35 @@ __global__ void k_match_probs(DevIndex ix, uint32_t n, const float *levels, floa
     }
 }
 
+// Calibration of the HBM traffic counters (rocprofv3 FETCH_SIZE / WRITE_SIZE) in k_map's own access shape: one lane per
+// 64-byte record, four 16-byte accesses per lane, records scattered by a multiplicative permutation over a buffer far larger
+// than L2 + Infinity Cache.  The byte counts are known exactly: n_rec * 64 written, n_rec * 64 read.
+__global__ void k_calib_write(uint4 *buf, uint64_t n_rec, uint64_t mult) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += stride) {
+        const uint64_t r = (i * mult) % n_rec;
+        uint4 *p = buf + r * 4;
+        const uint32_t v = (uint32_t)i;
+        p[0] = make_uint4(v, v + 1, v + 2, v + 3); p[1] = make_uint4(v, v, v, v); p[2] = make_uint4(v, 1, 2, 3); p[3] = make_uint4(3, 2, 1, v);
+    }
+}
+__global__ void k_calib_read(const uint4 *buf, uint64_t n_rec, uint64_t mult, uint32_t *sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += stride) {
+        const uint64_t r = (i * mult) % n_rec;
+        const uint4 *p = buf + r * 4;
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;    // keeps the loads alive
+}
+void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStream_t st) {
+    const uint64_t mult = 2654435761ull;    // odd, coprime with any power-of-two-free n_rec the host passes (n_rec is made odd)
+    if (write) hipLaunchKernelGGL(k_calib_write, dim3(256 * 16), dim3(256), 0, st, buf, n_rec, mult);
+    else hipLaunchKernelGGL(k_calib_read, dim3(256 * 16), dim3(256), 0, st, buf, n_rec, mult, sink);
+}
+
 void launch_kmer_ranges(const DevIndex &ix, uint64_t *out, hipStream_t st) {
     hipLaunchKernelGGL(k_kmer_ranges, dim3(NKMER / 64), dim3(64), 0, st, ix, out);
 }

@@ -838,6 +838,24 @@ extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_
     return UNC_OK;
 }
 
+// Known-byte traffic in k_map's access shape, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/dev/pmc_calib.py):
+// `reps` passes that write n_records scattered 64-byte records (one lane each, 4 x 16 B), then `reps` passes that read them.
+extern "C" int unc_calib_traffic(int device, uint64_t n_records, int reps) {
+    HIPCHK(hipSetDevice(device));
+    n_records |= 1;     // odd: the multiplicative scatter is then a permutation
+    uint4 *buf = nullptr;
+    uint32_t *sink = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, n_records * 64));
+    HIPCHK(hipMalloc((void **)&sink, 4));
+    for (int i = 0; i < reps; ++i) launch_calib(buf, n_records, 1, sink, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < reps; ++i) launch_calib(buf, n_records, 0, sink, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(buf); (void)hipFree(sink);
+    return UNC_OK;
+}
+
 // ------------------------------------------------------------------ step-wise trace of one read
 extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, const unc_calib_t *calib) {
     if (!m || !raw || !calib) return fail(UNC_ERR_ARG, "null argument");

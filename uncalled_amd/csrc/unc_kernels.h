@@ -28,5 +28,6 @@ void launch_self_align(const DevIndex &ix, const uint8_t *pac, uint32_t n, const
 void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st);
 void launch_dense_sa_check(const DevIndex &ix, const uint64_t *dense, uint32_t n, uint32_t *bad, hipStream_t st);
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st);
+void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStream_t st);
 void launch_match_probs(const DevIndex &ix, uint32_t n, const float *levels, float *out, hipStream_t st);
 }  // namespace unc
