@@ -1,39 +1,65 @@
-"""Dev tool: turn the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/dev/final_run.sh into profiles/<name>.json.
+"""Dev tool: the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/dev/final_run.sh (k_map on the bench's own batch + the
+known-byte calibration kernels in the same access shape) -> profiles/<name>.json.
 
-    python tools/dev/summarise_pmc.py gpurun_out/final profiles/r01_pmc_k_map.json 12000
-Counter units and caveats as in /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are reported in KiB;
-FETCH_SIZE is taken as reported (the guide's 1/2 factor is calibrated for wide coalesced streams only, this kernel gathers
-16 B per lane out of 128-byte records and 64-byte FM blocks)."""
+    python tools/dev/summarise_pmc.py gpurun_out/final profiles/r02_pmc_k_map.json 50000 ecoli
+Both counters are reported in KiB.  The calibration kernels move exactly n_records x 64 B per launch (one lane per 64-byte
+record, four 16-byte accesses per lane, scattered over 8 GB): counter / known bytes is the factor k_map's counters are divided
+by (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is known to under-report wide streams by 2x, other shapes are uncalibrated)."""
 import csv
 import glob
 import json
+import re
 import sys
 from pathlib import Path
 
-src, out, reads = Path(sys.argv[1]), Path(sys.argv[2]), int(sys.argv[3])
-tot, launches, dur = {}, {}, {}
-for name in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(str(src / ("pmc_" + name) / "**" / "*counter_collection.csv"), recursive=True):
+src, out, reads, workload = Path(sys.argv[1]), Path(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+
+
+def collect(dirname, counter, kernel_sub):
+    tot, disp = 0.0, set()
+    for f in glob.glob(str(src / dirname / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r.get("Kernel_Name", "")
-            if "k_map" in k and r["Counter_Name"] == name:
-                tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
-                launches[name] = launches.get(name, set()) | {r.get("Dispatch_Id")}
-    for f in glob.glob(str(src / ("pmc_" + name) / "**" / "*kernel_trace.csv"), recursive=True):
+            if kernel_sub in r.get("Kernel_Name", "") and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+                disp.add(r.get("Dispatch_Id"))
+    return tot * 1024.0, len(disp)
+
+
+def durations(dirname, kernel_sub):
+    d = []
+    for f in glob.glob(str(src / dirname / "**" / "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_map" in r.get("Kernel_Name", ""):
-                dur[name] = dur.get(name, 0.0) + (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6
-fetch_b = tot.get("FETCH_SIZE", 0.0) * 1024.0
-write_b = tot.get("WRITE_SIZE", 0.0) * 1024.0
-res = {
-    "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --reads %d --steps 1 "
-               "--warmup 0 --no-cpu-baseline --no-profile-pass (one pass per counter, tools/dev/final_run.sh)" % reads,
-    "kernel": "unc::k_map<false>", "reads_per_launch": reads,
-    "counters_KiB": tot, "k_map_launches": {k: len(v) for k, v in launches.items()}, "k_map_ms_under_pmc": dur,
-    "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
-    "hbm_bytes_per_read": (fetch_b + write_b) / reads,
-    "note": "FETCH_SIZE/WRITE_SIZE in KiB, summed over the k_map dispatches of the run (the main launch plus the few-read re-map "
-            "launches for reads whose seed-cluster set outgrew its slot); FETCH_SIZE as reported, see MI355X_MICROARCH.md (HBM).",
-}
+            if kernel_sub in r.get("Kernel_Name", ""):
+                d.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+    return d
+
+
+res = {"workload": workload, "reads_per_launch": reads, "kernel": "unc::k_map<false>",
+       "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py --steps 1 --warmup 0 "
+                  "--no-cpu-baseline --no-profile-pass --secondary '' (one pass per counter; tools/dev/final_run.sh pmc)"}
+calib = {}
+for c, kern in (("FETCH_SIZE", "k_calib_read"), ("WRITE_SIZE", "k_calib_write")):
+    log = (src / f"calib_{c}.log")
+    known = None
+    if log.exists():
+        m = re.search(r"bytes per launch (\d+)", log.read_text())
+        known = int(m.group(1)) if m else None
+    b, n = collect(f"calib_{c}", c, kern)
+    calib[c] = {"kernel": kern, "launches": n, "counter_bytes_per_launch": b / n if n else None, "known_bytes_per_launch": known,
+                "factor": (b / n / known) if (n and known) else None}
+res["calibration"] = calib
+raw = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    b, n = collect(f"pmc_{c}", c, "k_map")
+    raw[c] = {"counter_bytes": b, "k_map_dispatches": n, "k_map_ms_under_pmc": durations(f"pmc_{c}", "k_map")}
+res["raw"] = raw
+fac_f = calib["FETCH_SIZE"]["factor"] or 1.0
+fac_w = calib["WRITE_SIZE"]["factor"] or 1.0
+res["fetch_bytes_per_launch"] = raw["FETCH_SIZE"]["counter_bytes"] / fac_f
+res["write_bytes_per_launch"] = raw["WRITE_SIZE"]["counter_bytes"] / fac_w
+res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+res["hbm_bytes_per_read"] = res["hbm_bytes_per_launch"] / reads
+res["note"] = ("counter totals over the k_map dispatches of one 50 k-read step, each divided by the factor its calibration kernel "
+               "measured in the same access shape (factor 1.0 when the calibration pass is missing: then the figure is the raw counter)")
 out.write_text(json.dumps(res, indent=1))
 print(json.dumps(res, indent=1))
