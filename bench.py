@@ -220,7 +220,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     have_gpu = dev_name != "cpu"
     prefix, codes, lens = ensure_index(cache, rank, barrier, workload, dev_name, lib)
     ix = capi.Index(prefix, device=local_rank if have_gpu else 0, lib=lib)
-    kw = dict(n_big=a.n_big, big_clusters=a.big_clusters)
+    kw = dict(pool_chunks=a.pool_chunks)
     if not have_gpu:
         kw.update(n_slots=4, n_waves=2)          # lanesim plumbing test
     mapper = capi.Mapper(ix, **kw)
@@ -306,7 +306,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        "k_map_wave_busy": round(wave_busy, 4),
                        "pcie_inclusive_reads_per_sec": pcie,
                        "remapped_reads": {"n": remap_n, "ms": round(remap_ms, 1),
-                                          "note": "reads whose seed-cluster set outgrew its slot, mapped again with 16x the room (inside the step)"},
+                                          "note": "reads that found the seed-cluster leaf pool dry, mapped again after the batch (inside the step)"},
                        "reads_in_flight": mapper.geometry(),
                        "index_seq_len": int(ix.size), "index_device_bytes": int(ix.device_bytes())},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -398,8 +398,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None,
                     help="reads per GPU per step of the headline workload (default: 50 000 = BASELINE config 2; UNC_BENCH_READS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n-big", type=int, default=0, help="larger seed-cluster buffers (0 = library default)")
-    ap.add_argument("--big-clusters", type=int, default=0, help="clusters per larger buffer (0 = library default)")
+    ap.add_argument("--pool-chunks", type=int, default=0, help="chunks of the seed-cluster leaf pool (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed passes (PCIe-inclusive rate, phase cycle shares)")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "grch38", "realtime", "example"], default="ecoli",
                     help="headline workload (the driver runs the default: BASELINE config 2)")

@@ -255,23 +255,27 @@ def case_sliced_scheduler(lib, oracle_lib, example, goldens, max_paths=10000, sl
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True), "sliced")
 
 
-def case_big_cluster_buffers(lib, oracle_lib, example, goldens, n_big=2, n_waves=2, n_reads=12):
-    """Reads that fill the seed-cluster buffer of their slot move into a larger one (DevBig) at an event boundary, wait
-    parked when none is free, and hand it back when done: same answers, and no read is left for the host's re-map."""
+def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2, n_waves=2, n_reads=12):
+    """The leaves of all seed-cluster sets come from one pool.  With fewer chunks than reads in flight some reads find it
+    dry; with a tiny leaf directory some outgrow that: both are mapped again after the batch (with the pool to themselves,
+    then with a longer directory) and every read still answers as the oracle does.  A roomy pool needs no second pass."""
     dev_index = _index(lib, example)
     off_all = goldens["sim_offsets"]
     raw = goldens["sim_signal"][:int(off_all[n_reads])]
     off = off_all[:n_reads + 1].copy()
     cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
-    m = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, max_clusters=64, n_big=n_big, big_clusters=4096)
-    assert m.geometry() == dict(n_waves=n_waves, n_slots=3 * n_waves, slice_events=60, n_big=n_big, big_clusters=4096)
-    hits = m.map_batch(raw, off, cal)
-    assert m.last_remap()[0] == 0
     oix = oracle_lib.Index(example["prefix"])
-    assert_hits_equal(hits, oracle_hits(oix, raw, off, cal, fresh_mapper_per_read=True), "big cluster buffers")
-    # the same slots without larger buffers: the reads that outgrow 64 clusters go through the re-map
-    m2 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, max_clusters=64, n_big=0xFFFFFFFF)
-    hits2 = m2.map_batch(raw, off, cal)
+    want = oracle_hits(oix, raw, off, cal, fresh_mapper_per_read=True)
+    m = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=pool_chunks)
+    assert m.geometry() == dict(n_waves=n_waves, n_slots=3 * n_waves, slice_events=60, pool_chunks=pool_chunks, max_clusters=1 << 20)
+    hits = m.map_batch(raw, off, cal)
+    assert m.last_remap()[0] > 0            # 3 * n_waves reads in flight, pool_chunks < that many chunks
+    assert_hits_equal(hits, want, "pool pressure")
+    m2 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=64, max_clusters=16)
+    hits2 = m2.map_batch(raw, off, cal)      # one leaf per read: the ones with more than 64 clusters outgrow the directory
     assert m2.last_remap()[0] > 0
+    m3 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=64)
+    hits3 = m3.map_batch(raw, off, cal)
+    assert m3.last_remap()[0] == 0
     for name in hits.dtype.names:
-        assert np.array_equal(hits[name], hits2[name]), name
+        assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]), name

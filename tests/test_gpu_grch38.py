@@ -2,8 +2,8 @@
 FM rows and SA values past 2^32 -- where the reference switches to u64 ranges, src/range.hpp:37) is built on the GPU with
 the chunked suffix sorter, parameterised (`uncalled index`), and a batch of reads is mapped by the HIP path and by the
 oracle restatement (all host threads): PAF, winning cluster, event counts and work counters bit-exact.  At this size the
-index itself selects what the small tests can only force: the natural 128-bit sort keys (no packing fits), the
-`k_map_big` translation unit with the larger seed-cluster buffers, the 50 GB dense SA.
+index itself selects what the small tests can only force: the natural 128-bit sort keys (no packing fits), seed-cluster
+sets of hundreds of thousands of clusters drawn from the leaf pool, the 50 GB dense SA.
 The index lands in bench.py's cache directory, so a bench run on the same box reuses it."""
 import os
 import time

@@ -154,6 +154,6 @@ def test_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slic
     pc.case_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves)
 
 
-@pytest.mark.parametrize("n_big,n_waves", [(2, 2), (1, 1)])
-def test_big_cluster_buffers(hip_lib, oracle_lib, example, goldens, n_big, n_waves):
-    pc.case_big_cluster_buffers(hip_lib, oracle_lib, example, goldens, n_big, n_waves)
+@pytest.mark.parametrize("pool_chunks,n_waves", [(3, 2), (1, 1)])
+def test_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
+    pc.case_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves)

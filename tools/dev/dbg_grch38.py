@@ -31,7 +31,7 @@ print("thresholds", ix.thresholds()[:16], "uncl", open(str(prefix) + ".uncl").re
 m = capi.Mapper(ix)
 print("geometry", m.geometry())
 hits = m.map_batch(raw, off, cal)
-m1 = capi.Mapper(ix, n_slots=64, n_waves=64, n_big=0xFFFFFFFF)      # plain kernel, one slot per wavefront
+m1 = capi.Mapper(ix, n_slots=64, n_waves=64)      # plain kernel, one slot per wavefront
 hits1 = m1.map_batch(raw, off, cal, allow_overflow=True)
 sig = po.calibrate(raw, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 oix = po.Index(prefix)
@@ -58,7 +58,7 @@ print("mismatching reads:", bad)
 if bad:
     i = bad[0]
     r = raw[int(off[i]):int(off[i + 1])]
-    mt = capi.Mapper(ix, n_slots=1, n_big=0xFFFFFFFF, max_clusters=1 << 17)
+    mt = capi.Mapper(ix, n_slots=1)
     om = po.Mapper(oix)
     steps = 0
     for (dd, dp, dc, dmm, dls, dnl), (od, oe, op, oc, omm, ols, onl) in zip(mt.trace(r, cal[:1], max_clusters=1 << 17), om.trace(sig[int(off[i]):int(off[i + 1])], max_clusters=1 << 17)):

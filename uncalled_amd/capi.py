@@ -32,7 +32,7 @@ class Params(C.Structure):
 
 class MapperOpts(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
-                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("n_big", C.c_uint32), ("big_clusters", C.c_uint32),
+                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("pool_chunks", C.c_uint32), ("reserved_", C.c_uint32),
                 ("events_reads_per_wave", C.c_uint32)]
 
 
@@ -233,12 +233,12 @@ def hit_paf_cols(h, names):
 class Mapper:
     """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
 
-    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0, n_big=0,
-                 big_clusters=0, events_reads_per_wave=0):
+    def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0, pool_chunks=0,
+                 events_reads_per_wave=0):
         self.index = index
         self.L = index.L
         self.params = params or default_params(self.L)
-        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, n_big, big_clusters, events_reads_per_wave)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, pool_chunks, 0, events_reads_per_wave)
         h = C.c_void_p()
         _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
         self.h = h
@@ -288,7 +288,7 @@ class Mapper:
     def geometry(self):
         out = np.zeros(5, dtype=np.uint32)
         self.L.unc_mapper_geometry(self.h, out.ctypes.data)
-        return dict(zip(("n_waves", "n_slots", "slice_events", "n_big", "big_clusters"), (int(x) for x in out)))
+        return dict(zip(("n_waves", "n_slots", "slice_events", "pool_chunks", "max_clusters"), (int(x) for x in out)))
 
     def set_profile(self, on=True):
         self.L.unc_mapper_set_profile(self.h, 1 if on else 0)

@@ -26,18 +26,8 @@
 #include "unc_dev_types.h"
 #include "wave_prims.h"
 
-// This file is compiled twice (see k_map_big.hip): plain, and with UNC_BIG, which adds the code that moves reads into
-// larger seed-cluster buffers (DevBig).  Two translation units rather than one template parameter: whatever is added to
-// the plain kernel, even dead, moves its register allocation (measured: 4-5 % on the E. coli workload).
-#ifdef UNC_BIG
-#define UNC_KMAP k_map_big
-#define UNC_MAPARGS MapArgsBig
-#define UNC_LAUNCH launch_map_big
-#else
 #define UNC_KMAP k_map
 #define UNC_MAPARGS MapArgs
-#define UNC_LAUNCH launch_map_plain
-#endif
 
 namespace unc {
 
@@ -57,9 +47,7 @@ struct UNC_MAPARGS {
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
     DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
-#ifdef UNC_BIG
-    DevBig big;                 // batch mode: larger seed-cluster buffers on demand
-#endif
+    DevPool pool;               // leaves of the seed-cluster sets
 };
 
 // ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
@@ -92,38 +80,72 @@ __device__ __forceinline__ uint32_t sched_pop(SchedQueue *q, SchedCell *cells, u
 }
 
 struct Tracker {
-    uint32_t n, n_pay, n_lens, max1, max2, status, n_leaves, n_alloc;
+    uint32_t n, n_lens, max1, max2, status, n_leaves, n_alloc;
     float len_sum;
     ClusterVal mm;
 };
 
-// SeedTracker's std::set<SeedCluster> as a two-level sorted structure: a directory of leaves (first key + leaf id,
-// kept sorted) over leaves of up to 64 keys each (one lane per key).  Insert / erase touch one leaf (a lane-parallel
-// shift inside 64 entries) plus, once every ~32 inserts, a leaf split; nothing is ever O(#clusters).
-constexpr uint32_t LEAF = 64;
-// All four regions hang off ONE uniform base pointer (the slot's, or a larger buffer's) at 32-bit byte offsets.
+// SeedTracker's std::set<SeedCluster> as a two-level B+-tree (layout: unc_dev_types.h, ClusterKey): a per-read directory
+// of leaves (first key + pool index, kept sorted) over leaves of up to 64 clusters each (one lane per cluster), values
+// inline.  Insert / erase touch one leaf (a lane-parallel shift inside 64 entries) plus, once every ~32 inserts, a leaf
+// split; nothing is ever O(#clusters) but the directory shift of a split (256 entries per memory round trip).
+constexpr uint32_t LEAF = LEAF_KEYS;
+constexpr uint32_t LEAF_NONE = 0xFFFFFFFFu;
 struct TrackerMem {
-    char *base;
-    uint32_t off_leaves;  // ClusterKey [max_leaves][LEAF]
-    uint32_t off_dir;     // ClusterKey [max_leaves]: first key of the leaf, .pidx = leaf id
-    uint32_t off_cnt;     // u32 [max_leaves] by leaf id
-    uint32_t off_pay;     // ClusterPay, append-only payload pool
-    uint32_t max_leaves, max_pay;
+    char *sb;              // the read's slot: directory and chunk list live there
+    uint32_t off_dir;      // DirEnt [max_leaves]
+    uint32_t off_chunks;   // u32 [max_leaves / 64 + 1]
+    uint32_t max_leaves;
+    DevPool pool;          // leaves
 };
-__device__ __forceinline__ ClusterKey tm_leaf(const TrackerMem &M, uint32_t id, uint32_t slot) { return gld<ClusterKey>(M.base, M.off_leaves + ((id * LEAF + slot) << 4)); }
-__device__ __forceinline__ void tm_leaf_st(const TrackerMem &M, uint32_t id, uint32_t slot, const ClusterKey &k) { gst(M.base, M.off_leaves + ((id * LEAF + slot) << 4), k); }
-__device__ __forceinline__ ClusterKey tm_dir(const TrackerMem &M, uint32_t i) { return gld<ClusterKey>(M.base, M.off_dir + (i << 4)); }
-__device__ __forceinline__ void tm_dir_st(const TrackerMem &M, uint32_t i, const ClusterKey &k) { gst(M.base, M.off_dir + (i << 4), k); }
-__device__ __forceinline__ uint32_t tm_cnt(const TrackerMem &M, uint32_t id) { return gld<uint32_t>(M.base, M.off_cnt + (id << 2)); }
-__device__ __forceinline__ void tm_cnt_st(const TrackerMem &M, uint32_t id, uint32_t c) { gst(M.base, M.off_cnt + (id << 2), c); }
-__device__ __forceinline__ ClusterPay tm_pay(const TrackerMem &M, uint32_t i) { return gld<ClusterPay>(M.base, M.off_pay + (i << 5)); }
-__device__ __forceinline__ void tm_pay_st(const TrackerMem &M, uint32_t i, const ClusterPay &v) { gst(M.base, M.off_pay + (i << 5), v); }
-__device__ __forceinline__ uint32_t tm_pay_len(const TrackerMem &M, uint32_t i) { return gld<uint32_t>(M.base, M.off_pay + (i << 5) + 20u); }
-static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterPay) == 32 && offsetof(ClusterPay, total_len) == 20, "seed-cluster record layout");
+__device__ __forceinline__ char *tm_leaf_ptr(const TrackerMem &M, uint32_t leaf) { return M.pool.leaves + (size_t)leaf * LEAF_BYTES; }
+__device__ __forceinline__ ClusterKey lf_hot(const char *lp, uint32_t slot) { return gld<ClusterKey>(lp, slot << 4); }
+__device__ __forceinline__ ClusterCold lf_cold(const char *lp, uint32_t slot) { return gld<ClusterCold>(lp, LEAF_COLD_OFF + (slot << 5)); }
+__device__ __forceinline__ void lf_hot_st(char *lp, uint32_t slot, const ClusterKey &k) { gst(lp, slot << 4, k); }
+__device__ __forceinline__ void lf_cold_st(char *lp, uint32_t slot, const ClusterCold &c) { gst(lp, LEAF_COLD_OFF + (slot << 5), c); }
+__device__ __forceinline__ DirEnt tm_dir(const TrackerMem &M, uint32_t i) { return gld<DirEnt>(M.sb, M.off_dir + (i << 4)); }
+__device__ __forceinline__ void tm_dir_st(const TrackerMem &M, uint32_t i, const DirEnt &k) { gst(M.sb, M.off_dir + (i << 4), k); }
+__device__ __forceinline__ void tm_dir_first(const TrackerMem &M, uint32_t i, const ClusterKey &k, uint32_t leaf) {
+    DirEnt f; f.rstart = k.rstart; f.evt_en = k.evt_en; f.leaf = leaf;
+    tm_dir_st(M, i, f);
+}
+__device__ __forceinline__ uint32_t tm_cnt(const TrackerMem &M, uint32_t leaf) { return M.pool.cnt[leaf]; }
+__device__ __forceinline__ void tm_cnt_st(const TrackerMem &M, uint32_t leaf, uint32_t c) { M.pool.cnt[leaf] = c; }
+static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32 && sizeof(DirEnt) == 16, "seed-cluster record layout");
 
-__device__ __forceinline__ bool key_less(const ClusterKey &k, uint64_t r2, uint32_t e2) {
+template <class K> __device__ __forceinline__ bool key_less(const K &k, uint64_t r2, uint32_t e2) {
     // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
     return k.rstart > r2 || (k.rstart == r2 && k.evt_en > e2);
+}
+
+// A fresh leaf for this read: the next one of its newest chunk, or the first of a chunk popped off the pool's ring.
+// LEAF_NONE when the directory is full or the pool has run dry (the read then overflows and is mapped again later).
+__device__ __forceinline__ uint32_t tracker_new_leaf(Tracker &T, const TrackerMem &M, int lane) {
+    const uint32_t a = T.n_alloc;
+    if (a >= M.max_leaves) return LEAF_NONE;
+    uint32_t chunk;
+    if ((a & (CHUNK_LEAVES - 1)) == 0) {
+        uint32_t c = SCHED_EMPTY;
+        if (lane == 0) {
+            c = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
+            if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_LEAVES) << 2), c);
+        }
+        chunk = bcast32(c, 0);
+        if (chunk == SCHED_EMPTY) return LEAF_NONE;
+    } else {
+        chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_LEAVES) << 2)));
+    }
+    T.n_alloc = a + 1;
+    return chunk * CHUNK_LEAVES + (a & (CHUNK_LEAVES - 1));
+}
+
+// the read is over: its chunks go back to the pool
+__device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
+    const uint32_t n_chunks = (T.n_alloc + CHUNK_LEAVES - 1) / CHUNK_LEAVES;
+    for (uint32_t i = (uint32_t)lane; i < n_chunks; i += WAVE)
+        sched_push(M.pool.q, M.pool.cells, M.pool.cap_mask, gld<uint32_t>(M.sb, M.off_chunks + (i << 2)));
+    T.n_alloc = 0; T.n_leaves = 0; T.n = 0;
+    wave_sync();
 }
 
 // std::multiset<u32> all_lens_ reduced to what get_final reads: its size and its two largest values.
@@ -144,7 +166,7 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
 __device__ __forceinline__ void dir_shift_up(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
     for (uint32_t hi = b; hi > a;) {
         const uint32_t lo = hi - a > 256 ? hi - 256 : a;
-        ClusterKey k[4];
+        DirEnt k[4];
         bool have[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -162,7 +184,7 @@ __device__ __forceinline__ void dir_shift_up(const TrackerMem &M, uint32_t a, ui
 }
 __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
     for (uint32_t lo = a; lo < b; lo += 256) {
-        ClusterKey k[4];
+        DirEnt k[4];
         bool have[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -178,13 +200,15 @@ __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, 
     }
 }
 
-// remove entry `slot` of directory position L, whose leaf has id `id` and `c` keys; keeps the directory's first keys right
+// remove entry `slot` of directory position L, whose leaf has pool index `id` and `c` clusters; keeps the directory's first keys right
 __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
+    char *lp = tm_leaf_ptr(M, id);
     ClusterKey k;
+    ClusterCold cc;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
-    if (mv) k = tm_leaf(M, id, lane);
+    if (mv) { k = lf_hot(lp, lane); cc = lf_cold(lp, lane); }
     wave_sync();
-    if (mv) tm_leaf_st(M, id, lane - 1, k);
+    if (mv) { lf_hot_st(lp, lane - 1, k); lf_cold_st(lp, lane - 1, cc); }
     wave_sync();
     if (c == 1) {
         dir_shift_down(M, L + 1, T.n_leaves, lane);
@@ -193,37 +217,40 @@ __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, u
     } else {
         if (lane == 0) {
             tm_cnt_st(M, id, c - 1);
-            if (slot == 0) { ClusterKey f = tm_leaf(M, id, 0); f.pidx = id; tm_dir_st(M, L, f); }
+            if (slot == 0) tm_dir_first(M, L, lf_hot(lp, 0), id);
         }
     }
     wave_sync();
 }
 
-// insert key at (L, slot); L == n_leaves means "after everything".  Returns false on leaf-pool exhaustion.
-__device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, ClusterKey nk, int lane) {
+// insert a cluster at (L, slot); L == n_leaves means "after everything".  Returns false when no leaf can be had.
+__device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, const ClusterKey &nk,
+                                               const ClusterCold &nc, int lane) {
     if (T.n_leaves == 0) {
-        if (T.n_alloc >= M.max_leaves) return false;
-        const uint32_t id = T.n_alloc++;
+        const uint32_t id = tracker_new_leaf(T, M, lane);
+        if (id == LEAF_NONE) return false;
         if (lane == 0) {
-            tm_leaf_st(M, id, 0, nk);
+            char *lp = tm_leaf_ptr(M, id);
+            lf_hot_st(lp, 0, nk); lf_cold_st(lp, 0, nc);
             tm_cnt_st(M, id, 1);
-            ClusterKey f = nk; f.pidx = id; tm_dir_st(M, 0, f);
+            tm_dir_first(M, 0, nk, id);
         }
         T.n_leaves = 1;
         wave_sync();
         return true;
     }
-    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = tm_cnt(M, tm_dir(M, L).pidx); }   // append to the last leaf
-    uint32_t id = tm_dir(M, L).pidx, c = tm_cnt(M, id);
+    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = tm_cnt(M, uniform32(tm_dir(M, L).leaf)); }   // append to the last leaf
+    uint32_t id = uniform32(tm_dir(M, L).leaf), c = tm_cnt(M, id);
     if (c == LEAF) {
         // split: the upper half moves to a fresh leaf that follows this one in the directory
-        if (T.n_alloc >= M.max_leaves) return false;
-        const uint32_t nid = T.n_alloc++;
-        if (lane >= (int)(LEAF / 2)) tm_leaf_st(M, nid, lane - LEAF / 2, tm_leaf(M, id, lane));
+        const uint32_t nid = tracker_new_leaf(T, M, lane);
+        if (nid == LEAF_NONE) return false;
+        char *src = tm_leaf_ptr(M, id), *dst = tm_leaf_ptr(M, nid);
+        if (lane >= (int)(LEAF / 2)) { lf_hot_st(dst, lane - LEAF / 2, lf_hot(src, lane)); lf_cold_st(dst, lane - LEAF / 2, lf_cold(src, lane)); }
         wave_sync();
         dir_shift_up(M, L + 1, T.n_leaves, lane);
         if (lane == 0) {
-            ClusterKey f = tm_leaf(M, nid, 0); f.pidx = nid; tm_dir_st(M, L + 1, f);
+            tm_dir_first(M, L + 1, lf_hot(dst, 0), nid);
             tm_cnt_st(M, id, LEAF / 2); tm_cnt_st(M, nid, LEAF / 2);
         }
         T.n_leaves++;
@@ -231,29 +258,32 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
         if (slot > LEAF / 2) { L = L + 1; slot -= LEAF / 2; id = nid; }
         c = LEAF / 2;
     }
+    char *lp = tm_leaf_ptr(M, id);
     ClusterKey k;
+    ClusterCold cc;
     const bool mv = (uint32_t)lane >= slot && (uint32_t)lane < c;
-    if (mv) k = tm_leaf(M, id, lane);
+    if (mv) { k = lf_hot(lp, lane); cc = lf_cold(lp, lane); }
     wave_sync();
-    if (mv) tm_leaf_st(M, id, lane + 1, k);
+    if (mv) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
     if (lane == 0) {
-        tm_leaf_st(M, id, slot, nk);
+        lf_hot_st(lp, slot, nk); lf_cold_st(lp, slot, nc);
         tm_cnt_st(M, id, c + 1);
-        if (slot == 0) { ClusterKey f = nk; f.pidx = id; tm_dir_st(M, L, f); }
+        if (slot == 0) tm_dir_first(M, L, nk, id);
     }
     wave_sync();
     return true;
 }
 
-// The same insert when the caller already holds the target leaf (directory position L, id, count c < LEAF, lane l's key
-// k): no load at all, the keys at and behind `slot` move up one and the new one goes in.
+// The same insert when the caller already holds the target leaf (directory position L, pool index id, count c < LEAF, lane
+// l's hot key k and cold part cc): no load at all, what sits at and behind `slot` moves up one and the new cluster goes in.
 __device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, const ClusterKey &k,
-                                                    ClusterKey nk, int lane) {
-    if ((uint32_t)lane >= slot && (uint32_t)lane < c) tm_leaf_st(M, id, lane + 1, k);
+                                                    const ClusterCold &cc, const ClusterKey &nk, const ClusterCold &nc, int lane) {
+    char *lp = tm_leaf_ptr(M, id);
+    if ((uint32_t)lane >= slot && (uint32_t)lane < c) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
     if (lane == 0) {
-        tm_leaf_st(M, id, slot, nk);
+        lf_hot_st(lp, slot, nk); lf_cold_st(lp, slot, nc);
         tm_cnt_st(M, id, c + 1);
-        if (slot == 0) { ClusterKey f = nk; f.pidx = id; tm_dir_st(M, L, f); }
+        if (slot == 0) tm_dir_first(M, L, nk, id);
     }
     wave_sync();
 }
@@ -280,20 +310,24 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
     }
     // the last directory window stays in registers (lane l: entry lo + l): leaf ids and first keys are read off it below
     uint32_t d;
-    ClusterKey dk; dk.rstart = 0; dk.evt_en = 0; dk.pidx = 0;
+    DirEnt dk; dk.rstart = 0; dk.evt_en = 0; dk.leaf = 0;
     {
         uint32_t idx = lo + (uint32_t)lane;
         bool less = false;
         if (idx < hi) { dk = tm_dir(M, idx); less = key_less(dk, r2, e2); }
         d = lo + (uint32_t)__popcll(__ballot(less));
     }
-    // leaf d - 1 (the last one whose first key sorts before the seed), its count and keys in one round trip
+    // leaf d - 1 (the last one whose first key sorts before the seed): its count, hot keys and cold parts in one round trip
+    // (the cold parts are what an insert into this leaf has to move; most seeds on a large reference end up as one)
     uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
-    uint32_t id0 = 0, c0 = 0;    // leaf id / count of directory position d - 1
-    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.pidx = 0;
+    uint32_t id0 = 0, c0 = 0;    // pool index / count of the leaf at directory position d - 1
+    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.total_len = 0;
+    ClusterCold lc; lc.ref_st = 0; lc.rend = 0; lc.evt_st = 0; lc.pad[0] = lc.pad[1] = lc.pad[2] = 0;
     if (d > 0) {
-        id0 = d - 1 >= lo ? bcast32(dk.pidx, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).pidx);   // window starts after it
-        lk = tm_leaf(M, id0, lane);       // slots past the count hold stale keys: masked by c0
+        id0 = d - 1 >= lo ? bcast32(dk.leaf, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).leaf);   // window starts after it
+        const char *lp0 = tm_leaf_ptr(M, id0);
+        lk = lf_hot(lp0, lane);           // slots past the count hold stale keys: masked by c0
+        lc = lf_cold(lp0, lane);
         c0 = tm_cnt(M, id0);
         const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
         const uint32_t sn = (uint32_t)__popcll(__ballot(less));
@@ -303,13 +337,9 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
 
     // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
     uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0, m_id = 0, m_c = 0;
-    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.pidx = 0;
+    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.total_len = 0;
     bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
     bool stop = false;
-    // the leaf the lower bound lies in (where a new key would go), as the scan saw it
-    uint32_t lb_id = id0, lb_c = c0;
-    ClusterKey lb_k = lk;
-    bool lb_held = lb_in_leaf0;
     {
         uint32_t curL = lbL;
         bool first = true;
@@ -318,10 +348,9 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             ClusterKey k;
             if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
             else {
-                id = (curL >= lo && curL < hi) ? bcast32(dk.pidx, (int)(curL - lo)) : uniform32(tm_dir(M, curL).pidx);
-                k = tm_leaf(M, id, lane);
+                id = (curL >= lo && curL < hi) ? bcast32(dk.leaf, (int)(curL - lo)) : uniform32(tm_dir(M, curL).leaf);
+                k = lf_hot(tm_leaf_ptr(M, id), lane);
                 c = tm_cnt(M, id);
-                if (first) { lb_id = id; lb_c = c; lb_k = k; lb_held = true; }     // lower bound = slot 0 of this leaf
             }
             if (first) {   // the key at the lower bound is the first one this scan looks at
                 const uint64_t kr = bcast64(k.rstart, (int)from);
@@ -331,15 +360,10 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             const bool have = (uint32_t)lane >= from && (uint32_t)lane < c;
             uint64_t r1 = 0;
             uint32_t e1 = 0, tl = 0;
-            if (have) {
-                r1 = k.rstart;
-                e1 = k.evt_en;
-            }
+            if (have) { r1 = k.rstart; e1 = k.evt_en; tl = k.total_len; }
             const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
             const bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
             const bool far = have && dr >= (uint64_t)e2;
-            // total_len_ of the candidates only (on a large reference most seeds have none: one dependent load less)
-            if (in_range) tl = tm_pay_len(M, k.pidx);
             uint32_t tot;
             uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
             if (pm < best_len) pm = best_len;
@@ -355,7 +379,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             const uint32_t tl_last = bcast32(tl, last);
             if (tm) {
                 mL = curL; mS = (uint32_t)last; best_len = tl_last; m_id = id; m_c = c;
-                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.pidx = bcast32(k.pidx, last);
+                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.total_len = tl_last;
             }
             curL++;
             first = false;
@@ -363,11 +387,11 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
     }
 
     if (mL != 0xFFFFFFFFu) {
-        const uint32_t mid = m_id;
-        const ClusterPay mp = tm_pay(M, mk.pidx);
+        char *mlp = tm_leaf_ptr(M, m_id);
+        const ClusterCold mp = lf_cold(mlp, mS);
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
-        a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mp.total_len;
+        a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mk.total_len;
         const uint32_t prev_len = a.total_len;
         // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
         uint8_t growth = 0;
@@ -387,12 +411,13 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
         }
         // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2)
-        ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = mk.pidx;
+        ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = a.total_len;
+        ClusterCold nc; nc.ref_st = a.ref_st; nc.rend = a.rend; nc.evt_st = a.evt_st; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
         wave_sync();
         if (lbL == mL && lbS == mS) {
             if (lane == 0) {
-                tm_leaf_st(M, mid, mS, nk);
-                if (mS == 0) { ClusterKey f = nk; f.pidx = mid; tm_dir_st(M, mL, f); }
+                lf_hot_st(mlp, mS, nk); lf_cold_st(mlp, mS, nc);
+                if (mS == 0) tm_dir_first(M, mL, nk, m_id);
             }
             wave_sync();
         } else if (exists_at_lb) {
@@ -400,14 +425,8 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             T.n--;
         } else {
             tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // lb sorts before the match: its position is unaffected
-            if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
-        if (lane == 0) {
-            ClusterPay np; np.ref_st = a.ref_st; np.rend = a.rend; np.evt_st = a.evt_st; np.total_len = a.total_len;
-            np.pad[0] = np.pad[1] = 0;
-            tm_pay_st(M, mk.pidx, np);
-        }
-        wave_sync();
     } else {
         // new cluster (:218-228): the bookkeeping happens even when the set insert collides
         lens_insert(T, ref_len);
@@ -417,24 +436,15 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
         }
         if (!exists_at_lb) {
-            if (T.n_pay >= M.max_pay) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
-            ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.pidx = T.n_pay;
+            ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
+            ClusterCold nc; nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
             wave_sync();
-            if (lbL == T.n_leaves && d > 0) {
-                // after everything: append to the last leaf = directory position d - 1, which is the one loaded above
-                if (c0 < LEAF) tracker_insert_held(M, d - 1, c0, id0, c0, lk, nk, lane);
-                else if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
-            } else if (lb_held && lbL < T.n_leaves && lb_c < LEAF) {
-                tracker_insert_held(M, lbL, lbS, lb_id, lb_c, lb_k, nk, lane);
-            } else if (!tracker_insert(T, M, lbL, lbS, nk, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
-            if (lane == 0) {
-                ClusterPay np; np.ref_st = r2; np.rend = ref_en; np.evt_st = e2; np.total_len = ref_len;
-                np.pad[0] = np.pad[1] = 0;
-                tm_pay_st(M, T.n_pay, np);
-            }
+            if (d > 0 && c0 < LEAF && (lb_in_leaf0 || lbL == T.n_leaves)) {
+                // into the leaf loaded above (the lower bound lies in it, or the seed sorts after everything and is appended
+                // to the last leaf = directory position d - 1): nothing to reload
+                tracker_insert_held(M, d - 1, lb_in_leaf0 ? lbS : c0, id0, c0, lk, lc, nk, nc, lane);
+            } else if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             T.n++;
-            T.n_pay++;
-            wave_sync();
         }
     }
 }
@@ -818,22 +828,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         const uint32_t seedp_off = A.sc.off_seedp, tasks_off = A.sc.off_tasks;
         SlotState *const st = reinterpret_cast<SlotState *>(sb + A.sc.off_state);
         TrackerMem TM;
-        TM.base = sb;
-        TM.off_leaves = A.sc.off_cl_keys; TM.off_dir = A.sc.off_cl_dir; TM.off_cnt = A.sc.off_cl_cnt; TM.off_pay = A.sc.off_cl_pay;
-        TM.max_leaves = A.sc.max_clusters / 16; TM.max_pay = A.sc.max_clusters;
-#ifdef UNC_BIG
-        uint32_t big = restore ? uniform32(st->big_id) : 0u;     // 1 + id of the larger seed-cluster buffer, if the read owns one
-        if (big) {
-            TM.base = A.big.base + (size_t)(big - 1u) * A.big.buf_bytes;
-            TM.off_leaves = 0; TM.off_dir = A.big.off_dir; TM.off_cnt = A.big.off_cnt; TM.off_pay = A.big.off_pay;
-            TM.max_leaves = A.big.max_clusters / 16; TM.max_pay = A.big.max_clusters;
-        }
-#endif
+        TM.sb = sb; TM.off_dir = A.sc.off_cl_dir; TM.off_chunks = A.sc.off_cl_chunks; TM.max_leaves = A.sc.max_clusters / 16;
+        TM.pool = A.pool;
 
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if ((A.resume && !fresh) || restore) {
             r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
-            T.n = st->n_clusters; T.n_pay = st->n_pay; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
+            T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
             T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
@@ -842,8 +843,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             else if (uniform32(st->done)) break;
         } else if (A.resume) {
             r = blockIdx.x;
+            {   // a new read takes the channel over: what the previous one still holds goes back to the pool
+                Tracker old;
+                old.n_alloc = uniform32(st->n_alloc);
+                tracker_release(old, TM, lane);
+            }
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
+            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
             if (lane < NKMER / 32) s_flags[lane] = 0;
         } else {
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             }
             if (A.read_list) r = uniform32(A.read_list[r]);
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_pay = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
+            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
             if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
         }
@@ -873,29 +879,6 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
             if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
             if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
-#ifdef UNC_BIG
-            // seed-cluster buffer three quarters full: move into a larger one (DevBig) before the next event
-            if (A.big.n_big && !big && !A.resume && (T.n_pay * 4u >= TM.max_pay * 3u || T.n_alloc * 4u >= TM.max_leaves * 3u)) {
-                uint32_t id = SCHED_EMPTY;
-                if (lane == 0) id = sched_pop(A.big.q, A.big.cells, A.big.cap_mask);
-                id = bcast32(id, 0);
-                if (id != SCHED_EMPTY) {
-                    TrackerMem B;
-                    B.base = A.big.base + (size_t)id * A.big.buf_bytes;
-                    B.off_leaves = 0; B.off_dir = A.big.off_dir; B.off_cnt = A.big.off_cnt; B.off_pay = A.big.off_pay;
-                    B.max_leaves = A.big.max_clusters / 16; B.max_pay = A.big.max_clusters;
-                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc * LEAF; i += WAVE) gst(B.base, B.off_leaves + (i << 4), gld<ClusterKey>(TM.base, TM.off_leaves + (i << 4)));
-                    for (uint32_t i = (uint32_t)lane; i < T.n_leaves; i += WAVE) tm_dir_st(B, i, tm_dir(TM, i));
-                    for (uint32_t i = (uint32_t)lane; i < T.n_alloc; i += WAVE) tm_cnt_st(B, i, tm_cnt(TM, i));
-                    for (uint32_t i = (uint32_t)lane; i < T.n_pay; i += WAVE) tm_pay_st(B, i, tm_pay(TM, i));
-                    TM = B;
-                    big = id + 1u;
-                    wave_sync();
-                } else if (sliced && (T.n_pay * 16u >= TM.max_pay * 15u || T.n_alloc * 16u >= TM.max_leaves * 15u)) {
-                    break;   // none free and hardly any room left: wait parked, the owners hand theirs back when done
-                }
-            }
-#endif
             ++steps;
 
             // ---------------- P: match log-probs ----------------
@@ -1403,21 +1386,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
-#ifdef UNC_BIG
-        if (done && big) {   // hand the larger seed-cluster buffer back
-            if (lane == 0) sched_push(A.big.q, A.big.cells, A.big.cap_mask, big - 1u);
-            big = 0;
-        }
-#endif
+        if (done && !A.resume) tracker_release(T, TM, lane);   // batch mode: the leaves go back to the pool at once
         if (A.resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
-                st->status = T.status; st->n_clusters = T.n; st->n_pay = T.n_pay; st->n_lens = T.n_lens;
+                st->status = T.status; st->n_clusters = T.n; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
-#ifdef UNC_BIG
-                st->big_id = big;
-#endif
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
             }
@@ -1442,27 +1417,16 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
 
 #include "unc_kernels.h"
 namespace unc {
-void UNC_LAUNCH(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
+void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big) {
+                const DevPool &pool, const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile) {
     UNC_MAPARGS a;
-#ifdef UNC_BIG
-    a.big = *big;
-#else
-    (void)big;
-#endif
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
+    a.pool = pool;
     if (profile) hipLaunchKernelGGL(UNC_KMAP<true>, dim3(grid), dim3(WAVE), 0, st, a);
     else hipLaunchKernelGGL(UNC_KMAP<false>, dim3(grid), dim3(WAVE), 0, st, a);
-}
-#ifndef UNC_BIG
-void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
-                uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big) {
-    if (big && big->n_big) launch_map_big(ix, sc, rd, P, results, next_read, max_steps, resume, slot_map, grid, st, read_list, wave_ticks, sched, profile, big);
-    else launch_map_plain(ix, sc, rd, P, results, next_read, max_steps, resume, slot_map, grid, st, read_list, wave_ticks, sched, profile, big);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {
@@ -1484,26 +1448,25 @@ void launch_sched_init(const DevSched &S, hipStream_t st) {
     const uint32_t cap = S.cap_mask + 1u;
     hipLaunchKernelGGL(k_sched_init, dim3((cap + 255) / 256), dim3(256), 0, st, S);
 }
-// every larger seed-cluster buffer free
-__global__ void k_big_init(DevBig B) {
+// every chunk of the leaf pool free
+__global__ void k_pool_init(DevPool B) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = B.cap_mask + 1u;
     if (i < cap) {
-        SchedCell f; f.seq = i < B.n_big ? i + 1u : i; f.val = i;
+        SchedCell f; f.seq = i < B.n_chunks ? i + 1u : i; f.val = i;
         B.cells[i] = f;
     }
     if (i == 0) {
         SchedQueue q;
         memset(&q, 0, sizeof q);
-        q.tail = B.n_big;
+        q.tail = B.n_chunks;
         *B.q = q;
     }
 }
-void launch_big_init(const DevBig &B, hipStream_t st) {
+void launch_pool_init(const DevPool &B, hipStream_t st) {
     const uint32_t cap = B.cap_mask + 1u;
-    hipLaunchKernelGGL(k_big_init, dim3((cap + 255) / 256), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(k_pool_init, dim3((cap + 255) / 256), dim3(256), 0, st, B);
 }
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
 // register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.
 uint32_t map_kernel_waves_per_cu() { return 4 * UNC_LB; }
-#endif
 }  // namespace unc

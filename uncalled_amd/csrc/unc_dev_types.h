@@ -56,10 +56,21 @@ constexpr int KEYB_MOVES_SHIFT = 11;     // 5 bits: popcount(event_moves_)
 // A path that passed is_seed_valid (mapper.cpp:842-863): its FM rows become seeds
 struct alignas(8) SeedPath { uint64_t start; uint32_t count; uint32_t evt; uint32_t ref_len; uint32_t pad; };
 
-// SeedTracker state (seed_tracker.hpp:69-110).  Clusters live in an append-only payload pool; the
-// std::set ordering (ref_en_.start desc, evt_en_ desc) is a sorted array of 16-byte keys.
-struct alignas(16) ClusterKey { uint64_t rstart; uint32_t evt_en; uint32_t pidx; };
-struct alignas(16) ClusterPay { uint64_t ref_st, rend; uint32_t evt_st, total_len; uint32_t pad[2]; };
+// SeedTracker state (seed_tracker.hpp:69-110): the std::set<SeedCluster> (ordered by ref_en_.start desc, evt_en_ desc) is a
+// two-level B+-tree per read.
+//   leaf  = up to 64 clusters in set order, values inline: 64 hot keys of 16 bytes (all the forward scan of add_seed reads:
+//           ref_en_.start, evt_en_, total_len_) followed by 64 cold parts of 32 bytes (what a merge needs on top: ref_st_,
+//           ref_en_.end, evt_st_) = 3 KB.  Leaves come from ONE pool per mapper, a chunk of 64 leaves (192 KB) at a time,
+//           through a ring of free chunk ids: a read takes what it needs -- tens of clusters on a bacterial reference,
+//           hundreds of thousands for an off-target read on a human-sized one -- and gives it back when it is done.
+//   dir   = per read, sorted: first key of every leaf + the leaf's pool index (16 bytes per leaf)
+struct alignas(16) ClusterKey { uint64_t rstart; uint32_t evt_en; uint32_t total_len; };      // hot part of a cluster
+struct alignas(16) ClusterCold { uint64_t ref_st, rend; uint32_t evt_st; uint32_t pad[3]; };  // cold part
+struct alignas(16) DirEnt { uint64_t rstart; uint32_t evt_en; uint32_t leaf; };               // directory entry
+constexpr uint32_t LEAF_KEYS = 64;
+constexpr uint32_t LEAF_COLD_OFF = LEAF_KEYS * 16;
+constexpr uint32_t LEAF_BYTES = LEAF_KEYS * 16 + LEAF_KEYS * 32;
+constexpr uint32_t CHUNK_LEAVES = 64;
 
 struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
 
@@ -71,8 +82,8 @@ struct alignas(16) SlotState {
     uint32_t cur;            // which of the two path buffers holds the parents
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
-    uint32_t n_clusters, n_pay, n_lens, len_max1, len_max2, n_leaves, n_alloc;
-    uint32_t big_id;         // 0, or 1 + the larger seed-cluster buffer this read has moved into (DevBig)
+    uint32_t n_clusters, n_lens, len_max1, len_max2, n_leaves, n_alloc;   // n_alloc: leaves taken from the read's own chunks so far
+    uint32_t pad_[2];
     float len_sum;
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
@@ -91,17 +102,13 @@ struct alignas(64) SchedCtl {
     uint32_t next_read, pad0[15];
     SchedQueue freeq, parkq;
 };
-// Larger seed-cluster buffers for the reads that fill the one of their slot (off-target reads on a large reference collect
-// tens of thousands of clusters).  A read moves into a free one at an event boundary when its slot's buffer is three
-// quarters full and hands it back when it is done; ids travel through a ring like the slots'.  When none is free, a
-// time-sliced read waits parked; otherwise it carries on and, should it overflow after all, is re-mapped by the host.
-struct DevBig {
-    char *base;                  // buffer b at base + b * buf_bytes: leaves | directory | counts | payloads
-    uint64_t buf_bytes;
-    uint32_t off_dir, off_cnt, off_pay, max_clusters;
+// The leaf pool of the seed-cluster sets (see ClusterKey): chunk ids travel through a ring like the scheduler's.
+struct DevPool {
+    char *leaves;               // [n_chunks * CHUNK_LEAVES][LEAF_BYTES]
+    uint32_t *cnt;              // [n_chunks * CHUNK_LEAVES] clusters per leaf
     SchedQueue *q;
     SchedCell *cells;
-    uint32_t cap_mask, n_big;
+    uint32_t cap_mask, n_chunks;
 };
 
 struct DevSched {
@@ -138,10 +145,8 @@ struct DevScratch {
     uint32_t off_keys;     // SortKey [2][keys_cap]   (unsorted | sorted)
     uint32_t off_seedp;    // SeedPath[max_seed_paths]
     uint32_t off_tasks;    // u64     [WAVE * MAX_REP_COPY_LIMIT]
-    uint32_t off_cl_keys;  // ClusterKey [max_clusters / 16][64]: leaves of the seed-cluster set (16 bytes per key)
-    uint32_t off_cl_dir;   // ClusterKey [max_clusters / 16]: sorted directory (first key + leaf id)
-    uint32_t off_cl_cnt;   // u32     [max_clusters / 16]: keys per leaf
-    uint32_t off_cl_pay;   // ClusterPay [max_clusters]
+    uint32_t off_cl_dir;   // DirEnt  [max_clusters / 16]: sorted directory of the read's leaves (first key + pool index)
+    uint32_t off_cl_chunks;  // u32   [max_clusters / 16 / 64 + 1]: the pool chunks this read holds
     uint32_t off_state;    // SlotState
     uint32_t pad_;
 };

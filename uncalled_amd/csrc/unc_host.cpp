@@ -412,8 +412,8 @@ struct unc_mapper {
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
-    DevBig bigbuf{};               // larger seed-cluster buffers handed out by k_map (n_big = 0: none)
-    DevScratch big{};              // scratch with more seed-cluster room for the reads that outgrew a slot (kept between batches)
+    DevPool pool{};                // leaves of the seed-cluster sets, shared by every read in flight
+    DevScratch big{};              // scratch with a longer leaf directory for the reads that outgrew a slot's (kept between batches)
     uint64_t big_cap = 0;
     size_t big_slots = 0;
     bool big_at_limit = false;     // big_slots is all the free HBM allowed
@@ -450,22 +450,20 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     sc.max_clusters = max_clusters;
     uint64_t off = 0;
     auto region = [&off](uint64_t bytes) { const uint64_t o = off; off += (bytes + 255) & ~255ull; return o; };
-    const uint64_t leaves = max_clusters / 16;
+    const uint64_t leaves = max_clusters / 16;     // directory entries: leaves are at least half full after a split
     const uint64_t o_paths = region(2ull * sc.max_paths * sizeof(PathRec));
     const uint64_t o_rings = region(2ull * sc.max_paths * RING_FLOATS * 4);
     const uint64_t o_order = region(2ull * sc.max_paths * 4);
     const uint64_t o_keys = region(2ull * sc.keys_cap * sizeof(SortKey));
     const uint64_t o_seedp = region((uint64_t)max_seed_paths * sizeof(SeedPath));
     const uint64_t o_tasks = region((uint64_t)WAVE * MAX_REP_COPY_LIMIT * 8);
-    const uint64_t o_clk = region(leaves * 64 * sizeof(ClusterKey));     // leaves are at least half full after a split
-    const uint64_t o_cld = region(leaves * sizeof(ClusterKey));
-    const uint64_t o_clc = region(leaves * 4);
-    const uint64_t o_clp = region((uint64_t)max_clusters * sizeof(ClusterPay));
+    const uint64_t o_cld = region(leaves * sizeof(DirEnt));
+    const uint64_t o_clc = region((leaves / CHUNK_LEAVES + 1) * 4);
     const uint64_t o_state = region(sizeof(SlotState));
     if (off >= (1ull << 32)) return fail(UNC_ERR_ARG, "per-read scratch of %llu bytes does not fit 32-bit offsets (max_clusters %u)", (unsigned long long)off, max_clusters);
     sc.off_paths = (uint32_t)o_paths; sc.off_rings = (uint32_t)o_rings; sc.off_order = (uint32_t)o_order; sc.off_keys = (uint32_t)o_keys;
-    sc.off_seedp = (uint32_t)o_seedp; sc.off_tasks = (uint32_t)o_tasks; sc.off_cl_keys = (uint32_t)o_clk; sc.off_cl_dir = (uint32_t)o_cld;
-    sc.off_cl_cnt = (uint32_t)o_clc; sc.off_cl_pay = (uint32_t)o_clp; sc.off_state = (uint32_t)o_state;
+    sc.off_seedp = (uint32_t)o_seedp; sc.off_tasks = (uint32_t)o_tasks; sc.off_cl_dir = (uint32_t)o_cld; sc.off_cl_chunks = (uint32_t)o_clc;
+    sc.off_state = (uint32_t)o_state;
     sc.slot_bytes = off;
     return UNC_OK;
 }
@@ -487,6 +485,29 @@ static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, 
     return UNC_OK;
 }
 
+static void free_pool(DevPool &p) {
+    void *ptrs[] = {p.leaves, p.cnt, p.q, p.cells};
+    for (void *x : ptrs) if (x) (void)hipFree(x);
+    memset(&p, 0, sizeof p);
+}
+
+static int alloc_pool(DevPool &p, uint32_t n_chunks, size_t *bytes_out) {
+    memset(&p, 0, sizeof p);
+    uint32_t cap = 64;
+    while (cap < n_chunks) cap <<= 1;
+    p.cap_mask = cap - 1; p.n_chunks = n_chunks;
+    const size_t n_leaves = (size_t)n_chunks * CHUNK_LEAVES;
+    HIPCHK(hipMalloc((void **)&p.leaves, n_leaves * LEAF_BYTES));
+    HIPCHK(hipMalloc((void **)&p.cnt, n_leaves * 4));
+    HIPCHK(hipMalloc((void **)&p.q, sizeof(SchedQueue)));
+    HIPCHK(hipMalloc((void **)&p.cells, (size_t)cap * sizeof(SchedCell)));
+    launch_pool_init(p, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    if (bytes_out) *bytes_out += n_leaves * (LEAF_BYTES + 4) + (size_t)cap * sizeof(SchedCell);
+    return UNC_OK;
+}
+
 static SlotState *slot_state(const DevScratch &sc, size_t slot) { return reinterpret_cast<SlotState *>(sc.base + slot * sc.slot_bytes + sc.off_state); }
 
 extern "C" void unc_mapper_free(unc_mapper_t *m) {
@@ -495,7 +516,8 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     free_scratch(m->sc);
     free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
-                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells, m->bigbuf.base, m->bigbuf.q, m->bigbuf.cells};
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells};
+    free_pool(m->pool);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -525,11 +547,11 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     }
     if (n_slots == 0) {
         // four times more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched);
-        // about 7 MB of scratch per slot, bounded by a third of the free HBM
+        // about 5 MB of scratch per slot, bounded by a third of the free HBM
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
-        const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
+        const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
         const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0);
         size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
@@ -544,41 +566,26 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     size_t bytes = 0;
     // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
     const uint32_t msp = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
-    const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : 32768;
+    // per read: the directory of its seed-cluster leaves (16 bytes per leaf, 2^20 clusters by default); the leaves themselves
+    // come from the pool below
+    const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
     int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     {
-        // larger seed-cluster buffers (4x a slot's; 2x / 8x / 16x measured worse on the 400 Mb reference): a quarter of
-        // what is left of the HBM, at most one per wavefront
-        uint32_t n_big = opts ? opts->n_big : 0;
-        const uint64_t bc = (opts && opts->big_clusters) ? opts->big_clusters : 4ull * mcl;
-        if (n_big != 0xFFFFFFFFu && bc <= (1ull << 24)) {
-            // one larger buffer: leaves | directory | counts | payloads, as in a slot
-            const size_t leaves = (size_t)(bc / 16);
-            const size_t o_dir = leaves * 64 * sizeof(ClusterKey), o_cnt = o_dir + leaves * sizeof(ClusterKey);
-            const size_t o_pay = (o_cnt + leaves * 4 + 255) & ~(size_t)255;
-            const size_t per_big = (o_pay + (size_t)bc * sizeof(ClusterPay) + 255) & ~(size_t)255;
-            if (n_big == 0) {
-                size_t free_b = 0, total_b = 0;
-                HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                n_big = (uint32_t)std::min<size_t>(n_waves, free_b / 4 / per_big);
-                // small mappers (tests, traces) and small references re-map the rare read instead: below 2^28 index rows
-                // (chr20 and smaller) hardly any read fills a slot, and the plain kernel instantiation is 5 % faster
-                if (n_slots <= n_waves || n_big < 8 || ix->seq_len < (1ull << 28)) n_big = 0;
-            }
-            if (n_big) {
-                uint32_t cap = 64;
-                while (cap < n_big) cap <<= 1;
-                DevBig &B = m->bigbuf;
-                B.cap_mask = cap - 1; B.n_big = n_big; B.max_clusters = (uint32_t)bc;
-                B.buf_bytes = per_big; B.off_dir = (uint32_t)o_dir; B.off_cnt = (uint32_t)o_cnt; B.off_pay = (uint32_t)o_pay;
-                HIPCHK(hipMalloc((void **)&B.base, (size_t)n_big * per_big));
-                HIPCHK(hipMalloc((void **)&B.q, sizeof(SchedQueue)));
-                HIPCHK(hipMalloc((void **)&B.cells, (size_t)cap * sizeof(SchedCell)));
-                bytes += (size_t)n_big * per_big + (size_t)cap * sizeof(SchedCell);
-            }
+        // the leaf pool: 8 chunks (1.5 MB, about 25 000 clusters) per read in flight on average, 64 (200 000 clusters) on
+        // references of 2^28 index rows and more, where off-target reads collect hundreds of thousands; at most half of
+        // what is left of the HBM.  A read that finds the pool dry is mapped again after the batch (below).
+        uint32_t n_chunks = opts ? opts->pool_chunks : 0;
+        if (n_chunks == 0) {
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            const size_t chunk_bytes = (size_t)CHUNK_LEAVES * (LEAF_BYTES + 4);
+            const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 28) ? 64 : 8);
+            n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 2 / chunk_bytes));
         }
+        int rc2 = alloc_pool(m->pool, n_chunks, &bytes);
+        if (rc2) return rc2;
     }
     if (n_slots > n_waves) {
         uint32_t cap = 64;
@@ -717,10 +724,9 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     const uint32_t grid = n_reads < m->n_waves ? n_reads : m->n_waves;
     const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
     if (sliced) launch_sched_init(m->sched, st);
-    if (m->bigbuf.n_big) launch_big_init(m->bigbuf, st);
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, nullptr,
-               reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile,
-               m->bigbuf.n_big ? &m->bigbuf : nullptr);
+    launch_pool_init(m->pool, st);       // every chunk free: nothing outlives a batch
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, m->pool,
+               nullptr, reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
@@ -737,9 +743,9 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->ix->device));
         m->wave_busy = (grid && m->ms_map > 0 && khz > 0) ? (double)ticks / ((double)grid * (double)m->ms_map * (double)khz) : 0.0;
     }
-    // The reference's SeedTracker is an unbounded std::set.  Reads whose seed clusters outgrew the per-slot array are
-    // mapped again, on the device, with 16x the room, until they fit.  The larger scratch is sized so that every such
-    // read gets a wavefront at once (within a quarter of the free HBM) and is kept for the following batches.
+    // The reference's SeedTracker is an unbounded std::set.  A read that found the leaf pool dry, or whose directory of
+    // leaves is full, is mapped again after the batch: first on the same scratch with the whole pool to itself and its few
+    // fellows, then with a 16x longer directory and a quarter of the reads in flight per round, until it fits.
     {
         std::vector<uint32_t> redo;
         for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) redo.push_back(i);
@@ -747,29 +753,38 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         m->remap_ms = 0;
         const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
-        while (!redo.empty() && cap < (1ull << 23)) {   // 2^23 clusters = 0.9 GB per read: the 32-bit offset limit
-            cap *= 16;
-            const size_t want = std::min<size_t>(std::max<size_t>(redo.size(), 256), m->n_waves);
-            if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
-                free_scratch(m->big);
-                m->big_cap = 0; m->big_slots = 0;
-                size_t free_b = 0, total_b = 0;
-                HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths);
-                const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
-                const size_t slots = std::min(want, fit);
-                int rc2 = alloc_scratch(m->big, m->P, slots, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
-                if (rc2) { free_scratch(m->big); return rc2; }
-                m->big_cap = cap; m->big_slots = slots; m->big_at_limit = slots == fit;
+        size_t limit = m->n_waves;
+        for (int round = 0; !redo.empty() && cap <= (1ull << 26); ++round, limit = std::max<size_t>(1, limit / 4)) {
+            const DevScratch *sc = &m->sc;
+            size_t slots = std::min<size_t>(redo.size(), m->n_slots);
+            if (round > 0) {
+                cap *= 16;
+                if (cap > (1ull << 26)) break;
+                const size_t want = std::min<size_t>(std::max<size_t>(redo.size(), 64), m->n_waves);
+                if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
+                    free_scratch(m->big);
+                    m->big_cap = 0; m->big_slots = 0;
+                    size_t free_b = 0, total_b = 0;
+                    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+                    const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths);
+                    const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
+                    const size_t n = std::min(want, fit);
+                    int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
+                    if (rc2) { free_scratch(m->big); return rc2; }
+                    m->big_cap = cap; m->big_slots = n; m->big_at_limit = n == fit;
+                }
+                sc = &m->big;
+                slots = std::min(m->big_slots, redo.size());
             }
-            const size_t slots = std::min(m->big_slots, redo.size());
+            slots = std::min<size_t>(slots, limit);
             uint32_t *d_list = nullptr;
             HIPCHK(hipMalloc((void **)&d_list, redo.size() * 4));
             HIPCHK(hipMemcpyAsync(d_list, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
+            launch_pool_init(m->pool, st);
             DevReads rd2 = rd;
             rd2.n_reads = (uint32_t)redo.size();
-            launch_map(m->ix->dev, m->big, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, d_list);
+            launch_map(m->ix->dev, *sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, m->pool, d_list);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
             std::vector<uint32_t> still;
@@ -787,7 +802,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
         if (hits[i].status) worst = UNC_ERR_OVERFLOW;
     }
-    if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise max_clusters/max_seed_paths");
+    if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise pool_chunks / max_clusters / max_seed_paths");
     return UNC_OK;
 }
 
@@ -802,7 +817,7 @@ extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? 
 extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
 extern "C" void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5) {
     out5[0] = m->n_waves; out5[1] = m->n_slots; out5[2] = m->sched.ctl ? m->slice_events : 0u;
-    out5[3] = m->bigbuf.n_big; out5[4] = m->bigbuf.max_clusters;
+    out5[3] = m->pool.n_chunks; out5[4] = m->sc.max_clusters;
 }
 extern "C" void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms) {
     if (n_reads) *n_reads = m ? m->remap_reads : 0;
@@ -866,6 +881,7 @@ extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, 
     int rc = stage_batch(m, 1, raw, offsets, calib, 0, st, &rd);
     if (rc) return rc;
     launch_events(rd, m->P, st, m->ev_rpw);
+    launch_pool_init(m->pool, st);      // the traced read starts with every chunk free
     SlotState s0;
     memset(&s0, 0, sizeof s0);
     s0.max_map.rstart = 1; s0.max_map.evt_st = 1;   // NULL_ALN
@@ -888,7 +904,7 @@ extern "C" int unc_trace_step(unc_mapper_t *m, uint32_t n_events, int *done) {
     HIPCHK(hipSetDevice(m->ix->device));
     DevReads rd;
     trace_reads(m, &rd);
-    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, nullptr, 1, m->stream);
+    launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, n_events, 1, nullptr, 1, m->stream, m->pool);
     HIPCHK(hipGetLastError());
     SlotState s;
     HIPCHK(hipMemcpyAsync(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost, m->stream));
@@ -948,25 +964,26 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
     HIPCHK(hipMemcpy(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost));
-    // flatten the two-level set (directory order, then slot order inside each leaf)
-    const uint32_t max_leaves = m->sc.max_clusters / 16;
-    std::vector<ClusterKey> dir(s.n_leaves ? s.n_leaves : 1), leaves((size_t)(s.n_alloc ? s.n_alloc : 1) * 64), keys;
-    std::vector<uint32_t> cnt(s.n_alloc ? s.n_alloc : 1);
-    std::vector<ClusterPay> pay(s.n_pay ? s.n_pay : 1);
-    (void)max_leaves;
-    HIPCHK(hipMemcpy(dir.data(), m->sc.base + m->sc.off_cl_dir, (size_t)s.n_leaves * sizeof(ClusterKey), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(leaves.data(), m->sc.base + m->sc.off_cl_keys, (size_t)s.n_alloc * 64 * sizeof(ClusterKey), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cnt.data(), m->sc.base + m->sc.off_cl_cnt, (size_t)s.n_alloc * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(pay.data(), m->sc.base + m->sc.off_cl_pay, (size_t)s.n_pay * sizeof(ClusterPay), hipMemcpyDeviceToHost));
-    for (uint32_t L = 0; L < s.n_leaves; ++L)
-        for (uint32_t e = 0; e < cnt[dir[L].pidx]; ++e) keys.push_back(leaves[(size_t)dir[L].pidx * 64 + e]);
-    if (keys.size() != s.n_clusters) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: %zu keys, %u clusters", keys.size(), s.n_clusters);
-    if (keys.empty()) keys.resize(1);
-    for (uint32_t i = 0; i < s.n_clusters && i < cap; ++i) {
-        const ClusterPay &p = pay[keys[i].pidx];
-        out[i].ref_st = p.ref_st; out[i].ref_en_start = keys[i].rstart; out[i].ref_en_end = p.rend;
-        out[i].evt_st = p.evt_st; out[i].evt_en = keys[i].evt_en; out[i].total_len = p.total_len; out[i].pad = 0;
+    // flatten the two-level set (directory order, then slot order inside each leaf: hot keys, then cold parts)
+    std::vector<DirEnt> dir(s.n_leaves ? s.n_leaves : 1);
+    HIPCHK(hipMemcpy(dir.data(), m->sc.base + m->sc.off_cl_dir, (size_t)s.n_leaves * sizeof(DirEnt), hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    std::vector<char> leaf(LEAF_BYTES);
+    for (uint32_t L = 0; L < s.n_leaves; ++L) {
+        uint32_t c = 0;
+        HIPCHK(hipMemcpy(&c, m->pool.cnt + dir[L].leaf, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(leaf.data(), m->pool.leaves + (size_t)dir[L].leaf * LEAF_BYTES, LEAF_BYTES, hipMemcpyDeviceToHost));
+        if (c == 0 || c > LEAF_KEYS) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: leaf %u holds %u clusters", L, c);
+        const ClusterKey *hot = reinterpret_cast<const ClusterKey *>(leaf.data());
+        const ClusterCold *cold = reinterpret_cast<const ClusterCold *>(leaf.data() + LEAF_COLD_OFF);
+        if (hot[0].rstart != dir[L].rstart || hot[0].evt_en != dir[L].evt_en) return fail(UNC_ERR_HIP, "seed-cluster directory entry %u is stale", L);
+        for (uint32_t e = 0; e < c; ++e, ++n) {
+            if (n >= cap) continue;
+            out[n].ref_st = cold[e].ref_st; out[n].ref_en_start = hot[e].rstart; out[n].ref_en_end = cold[e].rend;
+            out[n].evt_st = cold[e].evt_st; out[n].evt_en = hot[e].evt_en; out[n].total_len = hot[e].total_len; out[n].pad = 0;
+        }
     }
+    if (n != s.n_clusters) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: %u keys, %u clusters", n, s.n_clusters);
     *n_out = s.n_clusters;
     if (max_map) {
         max_map->ref_st = s.max_map.ref_st; max_map->ref_en_start = s.max_map.rstart; max_map->ref_en_end = s.max_map.rend;
@@ -1001,6 +1018,7 @@ struct unc_rt {
     unc_params_t P;
     uint32_t n_channels = 0;
     DevScratch sc;
+    DevPool pool{};               // leaves of the channels' seed-cluster sets (a channel keeps its chunks until its next read)
     RtChan *d_chans = nullptr;
     float *d_ring = nullptr;
     RtChunkDesc *d_desc = nullptr;
@@ -1022,6 +1040,7 @@ struct unc_rt {
 extern "C" void unc_rt_free(unc_rt_t *rt) {
     if (!rt) return;
     (void)hipSetDevice(rt->ix->device);
+    free_pool(rt->pool);
     void *ptrs[] = {rt->sc.base,
                     rt->d_chans, rt->d_ring, rt->d_desc, rt->d_info, rt->d_ring0, rt->d_newread, rt->d_slotmap, rt->d_next, rt->d_moff,
                     rt->d_results, rt->d_raw};
@@ -1045,9 +1064,12 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     const size_t S = n_channels;
     size_t bytes = 0;
     {
-        int rc = alloc_scratch(rt->sc, *p, S, 65536, 2 * p->max_paths, &bytes);
+        int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes);
         if (rc) return rc;
         HIPCHK(hipMemset(rt->sc.base, 0, bytes));
+        // 16 chunks (about 50 000 clusters) per channel on average; a read that finds the pool dry fails with its status set
+        rc = alloc_pool(rt->pool, (uint32_t)std::max<size_t>(64, S * 16), &bytes);
+        if (rc) return rc;
     }
 #define RALLOC(ptr, type, count)                                   \
     do {                                                           \
@@ -1175,7 +1197,7 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
         rd.means = rt->d_ring; rd.moff = rt->d_moff; rd.info = rt->d_info; rd.n_reads = n_act;
         rd.tgt_mean = rt->ix->model_mean; rd.tgt_stdv = rt->ix->model_stdv;
         rd.ring0 = rt->d_ring0; rd.new_read = rt->d_newread; rd.ring_mod = NORM_LEN;
-        launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st);
+        launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st, rt->pool);
         HIPCHK(hipEventRecord(rt->ev[2], st));
         HIPCHK(hipGetLastError());
         rt->h_info.resize(n_act);

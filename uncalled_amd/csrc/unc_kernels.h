@@ -10,15 +10,10 @@ void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc
                       const unc_params_t &P, float tgt_mean, float tgt_stdv, unc_evt_info_t *info, uint32_t *ring0_out, hipStream_t st);
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const uint32_t *read_list = nullptr, unsigned long long *wave_ticks = nullptr, const DevSched *sched = nullptr, bool profile = false, const DevBig *big = nullptr);
-void launch_map_plain(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
-                      uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                      const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big);
-void launch_map_big(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
-                    uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                    const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile, const DevBig *big);
+                const DevPool &pool, const uint32_t *read_list = nullptr, unsigned long long *wave_ticks = nullptr,
+                const DevSched *sched = nullptr, bool profile = false);
 void launch_sched_init(const DevSched &S, hipStream_t st);
-void launch_big_init(const DevBig &B, hipStream_t st);
+void launch_pool_init(const DevPool &B, hipStream_t st);
 uint32_t map_kernel_waves_per_cu();
 void launch_kmer_ranges(const DevIndex &ix, uint64_t *out2048, hipStream_t st);
 void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
