@@ -201,6 +201,8 @@ __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, 
 }
 
 // remove entry `slot` of directory position L, whose leaf has pool index `id` and `c` clusters; keeps the directory's first keys right
+// (the structural paths -- directory shifts, erase, the insert that may split -- stay inline: out of line, with the tracker
+// passed through the stack, the gfx950 build returned wrong results on the device while the emulator agreed with the oracle)
 __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
     char *lp = tm_leaf_ptr(M, id);
     ClusterKey k;
@@ -225,7 +227,7 @@ __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, u
 
 // insert a cluster at (L, slot); L == n_leaves means "after everything".  Returns false when no leaf can be had.
 __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, const ClusterKey &nk,
-                                               const ClusterCold &nc, int lane) {
+                                                   const ClusterCold &nc, int lane) {
     if (T.n_leaves == 0) {
         const uint32_t id = tracker_new_leaf(T, M, lane);
         if (id == LEAF_NONE) return false;
@@ -760,6 +762,9 @@ template <bool PROF>
 __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
+    // SeedTracker's scalars between the events that touch them (phases T / G run only when an event has seeds): parked in
+    // LDS, so that the extension / sort / walk loops do not carry twenty uniform values through their register allocation
+    __shared__ Tracker s_T;
     // one carved buffer for the per-pass staging of phase E (7.5 KB), reused as the source list in phase F: with the
     // probs table the wavefront stays under 12 KB of LDS, i.e. 13 wavefronts per CU fit the 160 KB (12 are resident)
     constexpr int RES_BITS = 30;                       // packed FM result: start << 30 | row count (0 = empty range)
@@ -788,6 +793,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     for (;;) {
         // ---------------- fetch or resume a read ----------------
         uint32_t r = 0, event_i, n_parents, cur;
+        uint32_t tstatus = 0;                        // UNC_READ_* bits (mirror of the tracker's status)
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
         uint64_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -827,9 +833,12 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         const uint32_t ukeys_off = A.sc.off_keys, skeys_off = A.sc.off_keys + A.sc.keys_cap * (uint32_t)sizeof(SortKey);
         const uint32_t seedp_off = A.sc.off_seedp, tasks_off = A.sc.off_tasks;
         SlotState *const st = reinterpret_cast<SlotState *>(sb + A.sc.off_state);
-        TrackerMem TM;
-        TM.sb = sb; TM.off_dir = A.sc.off_cl_dir; TM.off_chunks = A.sc.off_cl_chunks; TM.max_leaves = A.sc.max_clusters / 16;
-        TM.pool = A.pool;
+        auto tracker_mem = [&]() {                   // built where it is used: its pointers need not live across the phases
+            TrackerMem M;
+            M.sb = sb; M.off_dir = A.sc.off_cl_dir; M.off_chunks = A.sc.off_cl_chunks; M.max_leaves = A.sc.max_clusters / 16;
+            M.pool = A.pool;
+            return M;
+        };
 
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if ((A.resume && !fresh) || restore) {
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             {   // a new read takes the channel over: what the previous one still holds goes back to the pool
                 Tracker old;
                 old.n_alloc = uniform32(st->n_alloc);
-                tracker_release(old, TM, lane);
+                tracker_release(old, tracker_mem(), lane);
             }
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
@@ -865,6 +874,9 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
             if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
         }
+        tstatus = uniform32(T.status);
+        wave_sync();
+        if (lane == 0) s_T = T;
         wave_sync();
         const unc_evt_info_t inf = A.rd.info[r];
         const uint32_t n_events = inf.n_events;
@@ -877,8 +889,8 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         float next_mean = event_i < n_events ? MEAN_AT(event_i) : 0.0f;
         while (!done && steps < A.max_steps) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
-            if (ring_mod && event_i >= n_events && event_i < P.max_events && !T.status) break;   // chunk mapped: park
-            if (event_i >= n_events || event_i >= P.max_events || T.status) { done = 2; break; }
+            if (ring_mod && event_i >= n_events && event_i < P.max_events && !tstatus) break;   // chunk mapped: park
+            if (event_i >= n_events || event_i >= P.max_events || tstatus) { done = 2; break; }
             ++steps;
 
             // ---------------- P: match log-probs ----------------
@@ -1064,7 +1076,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 wave_sync();
                 PHASE_END(11);
             }
-            if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
+            if (n_seedp > A.sc.max_seed_paths) { tstatus |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             wave_sync();
 
             PHASE_END(1);
@@ -1243,7 +1255,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     if (n_src > room) n_src = room;
                     if (kl) bq1 = i + 2 * WAVE < n ? ukeys[kq1 & 0xFFFFu].b : 0ull;
                 }
-                if (n_seedp > A.sc.max_seed_paths) { T.status |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
+                if (n_seedp > A.sc.max_seed_paths) { tstatus |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             }
             wave_sync();
 
@@ -1287,49 +1299,66 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
 
             PHASE_END(4);
             // ---------------- T: seeds ----------------
-            for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
-                const uint32_t si = sb0 + (uint32_t)lane;
-                SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
-                if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
-                uint32_t ttot;
-                const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
-                for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), sp.start + j);
-                wave_sync();
-                for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
-                    const uint32_t ti = t0 + (uint32_t)lane;
-                    if (ti < ttot) {
-                        uint32_t lf;
-                        const uint64_t row = gld<uint64_t>(sb, tasks_off + (ti << 3));
-                        const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
-                        gst(sb, tasks_off + (ti << 3), ix.seq_len - sa);    // sa_end, mapper.cpp:678
-                        c_sa++;
-                        c_lf += lf;
-                    }
-                }
-                wave_sync();
-                PHASE_END(5);
-                const uint32_t nl = n_seedp - sb0 < WAVE ? n_seedp - sb0 : WAVE;
-                for (uint32_t l = 0; l < nl; ++l) {
-                    const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
-                    const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
-                    for (uint32_t j = 0; j < cnt; ++j) {
-                        const uint64_t sa_end = uniform64(gld<uint64_t>(sb, tasks_off + ((o + j) << 3)));
-                        add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane);
-                    }
-                }
-                PHASE_END(6);
-            }
-
-            // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
+            // (nothing to add: the tracker, and with it the confidence test below, is where the last event left it)
             bool conf = false;
-            if (T.mm.total_len >= P.min_map_len && T.n_lens >= 2) {
-                const float mean_len = __fdiv_rn(T.len_sum, (float)T.n);
-                const float second_len = (float)T.max2;
-                const float ml = (float)T.mm.total_len;
-                conf = (P.min_mean_conf > 0 && __fdiv_rn(ml, mean_len) >= P.min_mean_conf) ||
-                       (P.min_top_conf > 0 && __fdiv_rn(ml, second_len) >= P.min_top_conf);
+            if (n_seedp > 0 && !tstatus) {
+                Tracker T;
+                {
+                    const Tracker v = s_T;      // uniform values: back into scalar registers
+                    T.n = uniform32(v.n); T.n_lens = uniform32(v.n_lens); T.max1 = uniform32(v.max1); T.max2 = uniform32(v.max2);
+                    T.status = uniform32(v.status); T.n_leaves = uniform32(v.n_leaves); T.n_alloc = uniform32(v.n_alloc);
+                    T.len_sum = __uint_as_float(uniform32(__float_as_uint(v.len_sum)));
+                    T.mm.ref_st = uniform64(v.mm.ref_st); T.mm.rstart = uniform64(v.mm.rstart); T.mm.rend = uniform64(v.mm.rend);
+                    T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
+                }
+                const TrackerMem TM = tracker_mem();
+                for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
+                    const uint32_t si = sb0 + (uint32_t)lane;
+                    SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
+                    if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
+                    uint32_t ttot;
+                    const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
+                    for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), sp.start + j);
+                    wave_sync();
+                    for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
+                        const uint32_t ti = t0 + (uint32_t)lane;
+                        if (ti < ttot) {
+                            uint32_t lf;
+                            const uint64_t row = gld<uint64_t>(sb, tasks_off + (ti << 3));
+                            const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
+                            gst(sb, tasks_off + (ti << 3), ix.seq_len - sa);    // sa_end, mapper.cpp:678
+                            c_sa++;
+                            c_lf += lf;
+                        }
+                    }
+                    wave_sync();
+                    PHASE_END(5);
+                    const uint32_t nl = n_seedp - sb0 < WAVE ? n_seedp - sb0 : WAVE;
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
+                        const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
+                        for (uint32_t j = 0; j < cnt; ++j) {
+                            const uint64_t sa_end = uniform64(gld<uint64_t>(sb, tasks_off + ((o + j) << 3)));
+                            add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane);
+                        }
+                    }
+                    PHASE_END(6);
+                }
+
+                // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
+                if (T.mm.total_len >= P.min_map_len && T.n_lens >= 2) {
+                    const float mean_len = __fdiv_rn(T.len_sum, (float)T.n);
+                    const float second_len = (float)T.max2;
+                    const float ml = (float)T.mm.total_len;
+                    conf = (P.min_mean_conf > 0 && __fdiv_rn(ml, mean_len) >= P.min_mean_conf) ||
+                           (P.min_top_conf > 0 && __fdiv_rn(ml, second_len) >= P.min_top_conf);
+                }
+                tstatus |= T.status;
+                wave_sync();
+                if (lane == 0) s_T = T;
+                wave_sync();
             }
-            if (T.status) { done = 2; }
+            if (tstatus) { done = 2; }
             else if (conf) { done = 1; }
             else {
                 // ---------------- M: every 4th event the rings of the live paths are brought up to date (PathRec) ----------------
@@ -1378,6 +1407,9 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
 
         // ---------------- publish / park ----------------
         const uint64_t t_nbr = wave_sum64(c_nbr), t_sa = wave_sum64(c_sa), t_lf = wave_sum64(c_lf);
+        T = s_T;
+        T.status |= tstatus;
+        T.n_alloc = uniform32(T.n_alloc);
         if (done && lane == 0) {
             DevResult res;
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
@@ -1386,7 +1418,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
             A.results[r] = res;
         }
-        if (done && !A.resume) tracker_release(T, TM, lane);   // batch mode: the leaves go back to the pool at once
+        if (done && !A.resume) tracker_release(T, tracker_mem(), lane);   // batch mode: the leaves go back to the pool at once
         if (A.resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
