@@ -203,7 +203,9 @@ __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, 
 // remove entry `slot` of directory position L, whose leaf has pool index `id` and `c` clusters; keeps the directory's first keys right
 // (the structural paths -- directory shifts, erase, the insert that may split -- stay inline: out of line, with the tracker
 // passed through the stack, the gfx950 build returned wrong results on the device while the emulator agreed with the oracle)
-__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane) {
+__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane,
+                                              uint32_t &top_n) {
+    if (c == 1 || slot == 0) top_n = 0;      // the directory changes: its LDS sample is stale
     char *lp = tm_leaf_ptr(M, id);
     ClusterKey k;
     ClusterCold cc;
@@ -227,7 +229,8 @@ __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, u
 
 // insert a cluster at (L, slot); L == n_leaves means "after everything".  Returns false when no leaf can be had.
 __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, const ClusterKey &nk,
-                                                   const ClusterCold &nc, int lane) {
+                                                   const ClusterCold &nc, int lane, uint32_t &top_n) {
+    top_n = 0;
     if (T.n_leaves == 0) {
         const uint32_t id = tracker_new_leaf(T, M, lane);
         if (id == LEAF_NONE) return false;
@@ -279,7 +282,8 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
 // The same insert when the caller already holds the target leaf (directory position L, pool index id, count c < LEAF, lane
 // l's hot key k and cold part cc): no load at all, what sits at and behind `slot` moves up one and the new cluster goes in.
 __device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, const ClusterKey &k,
-                                                    const ClusterCold &cc, const ClusterKey &nk, const ClusterCold &nc, int lane) {
+                                                    const ClusterCold &cc, const ClusterKey &nk, const ClusterCold &nc, int lane, uint32_t &top_n) {
+    if (slot == 0) top_n = 0;
     char *lp = tm_leaf_ptr(M, id);
     if ((uint32_t)lane >= slot && (uint32_t)lane < c) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
     if (lane == 0) {
@@ -291,14 +295,37 @@ __device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_
 }
 
 // SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
+#ifndef UNC_TOP_MIN
+#define UNC_TOP_MIN 64      // (tests build the emulator library with 1: the small test sets then take the sampled path too)
+#endif
+constexpr uint32_t TOP_MIN = UNC_TOP_MIN;
+// s_top / top_n: 64 evenly spaced directory entries kept in LDS (valid for a directory of top_n leaves, 0 = stale): the
+// first level of the search costs no memory round trip on the large sets of a human-sized reference.
 static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
-                                int lane) {
+                                int lane, DirEnt *s_top, uint32_t &top_n) {
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
     const uint32_t e2 = evt;
 
     // ---- lower_bound(new_seed): leaves whose first key sorts before the seed (64-ary search), then inside one leaf
     uint32_t lo = 0, hi = T.n_leaves;
+    if (hi > TOP_MIN) {
+        const uint32_t step = (hi + 63) / 64;
+        const uint32_t idx = (uint32_t)lane * step;
+        if (top_n != hi) {
+            DirEnt e; e.rstart = 0; e.evt_en = 0; e.leaf = 0;     // past the end: never sorts before a seed
+            if (idx < hi) e = tm_dir(M, idx);
+            wave_sync();
+            s_top[lane] = e;
+            top_n = hi;
+            wave_sync();
+        }
+        const DirEnt te = s_top[lane];
+        const bool less = idx < hi && key_less(te, r2, e2);
+        const uint32_t c = (uint32_t)__popcll(__ballot(less));
+        lo = c ? (c - 1) * step + 1 : 0;
+        hi = c * step < hi ? c * step : hi;
+    }
     while (hi - lo > 64) {
         uint32_t step = (hi - lo + 63) / 64;
         uint32_t idx = lo + (uint32_t)lane * step;
@@ -421,13 +448,14 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
                 lf_hot_st(mlp, mS, nk); lf_cold_st(mlp, mS, nc);
                 if (mS == 0) tm_dir_first(M, mL, nk, m_id);
             }
+            if (mS == 0) top_n = 0;
             wave_sync();
         } else if (exists_at_lb) {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // the re-insert collides: the cluster is dropped
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane, top_n);     // the re-insert collides: the cluster is dropped
             T.n--;
         } else {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane);     // lb sorts before the match: its position is unaffected
-            if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            tracker_erase(T, M, mL, mS, m_id, m_c, lane, top_n);     // lb sorts before the match: its position is unaffected
+            if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane, top_n)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
     } else {
         // new cluster (:218-228): the bookkeeping happens even when the set insert collides
@@ -444,8 +472,8 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             if (d > 0 && c0 < LEAF && (lb_in_leaf0 || lbL == T.n_leaves)) {
                 // into the leaf loaded above (the lower bound lies in it, or the seed sorts after everything and is appended
                 // to the last leaf = directory position d - 1): nothing to reload
-                tracker_insert_held(M, d - 1, lb_in_leaf0 ? lbS : c0, id0, c0, lk, lc, nk, nc, lane);
-            } else if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+                tracker_insert_held(M, d - 1, lb_in_leaf0 ? lbS : c0, id0, c0, lk, lc, nk, nc, lane, top_n);
+            } else if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane, top_n)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             T.n++;
         }
     }
@@ -1312,6 +1340,8 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
                 }
                 const TrackerMem TM = tracker_mem();
+                DirEnt *const s_top = reinterpret_cast<DirEnt *>(s_e);      // the staging buffer of phase E is idle here
+                uint32_t top_n = 0;
                 for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
                     const uint32_t si = sb0 + (uint32_t)lane;
                     SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
@@ -1339,7 +1369,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
                         for (uint32_t j = 0; j < cnt; ++j) {
                             const uint64_t sa_end = uniform64(gld<uint64_t>(sb, tasks_off + ((o + j) << 3)));
-                            add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane);
+                            add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane, s_top, top_n);
                         }
                     }
                     PHASE_END(6);
