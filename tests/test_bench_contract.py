@@ -8,28 +8,47 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 
 
+def _line(name):
+    txt = (ROOT / "profiles" / name).read_text().strip()
+    return json.loads(txt[txt.index("{"):].splitlines()[-1] if txt.lstrip().startswith("{\"metric") else txt)
+
+
 def test_committed_bench_line_has_every_contract_field():
-    b = json.loads((ROOT / "profiles" / "r01_bench_default_final.json").read_text())
+    b = _line("r02_bench_default_final.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "verify", "secondary"):
         assert k in b, k
     assert b["metric"] == "reads_mapped_per_sec" and b["unit"] == "reads/s" and b["higher_is_better"] is True
     assert b["scaling"] == "weak" and b["vs_baseline"] is None and b["data"] == "synthetic" and b["n_gpus"] == 1
-    assert "workload" in b["config"] and "model" not in b["config"]
+    assert "workload" in b["config"] and "model" not in b["config"] and b["config"]["reads_per_gpu_per_step"] == 50000
     # value is whole-job throughput over the timed steps
     assert abs(b["value"] - b["config"]["reads_per_gpu_per_step"] * b["n_gpus"] / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6
-    r = b["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
-    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
-    c = b["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["paf_mismatches_vs_gpu"] == 0
+    blocks = [("ecoli", b)] + [(k, v) for k, v in b["secondary"].items()]
+    assert {k for k, _ in blocks} == {"ecoli", "grch38", "chr20"}
+    for name, blk in blocks:
+        r = blk["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0, name
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+        assert r["traffic"] is None or r["traffic"] > 0
+        c = blk["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0, name
+        assert c["paf_mismatches_vs_gpu"] == 0 and c["paf_reads_checked"] >= 256, name
+        assert c["cores"] <= c["host_threads_available"] and str(c["cores"]) in c["thread_sweep_reads_per_sec"]
+        assert c["value"] >= 0.9 * max(c["thread_sweep_reads_per_sec"].values()) or c["seconds"] >= 10      # the best of the sweep is what is stated
+        assert "ms_per_read" in c and c["ms_per_read"]["mean"] > 0 and c["b2_mappool_reads_per_sec"] > 0
+        v = blk["verify"]
+        assert v["all_steps_identical"] and v["steps_hashed"] >= 1 and v["paf_mismatches"] == 0 and len(v["hits_sha256"]) == 64
+        assert blk["config"]["remapped_reads"]["n"] >= 0
+    assert b["secondary"]["grch38"]["config"]["index_seq_len"] == 6200000000
+    assert b["verify"]["steps_hashed"] == b["steps"]
     # the rocprofv3 summary of the same command agrees with the HIP-event launch time
-    stats = (ROOT / "profiles" / "r01_rocprofv3_kernel_stats_final.csv").read_text().splitlines()
+    stats = (ROOT / "profiles" / "r02_rocprofv3_kernel_stats.csv").read_text().splitlines()
     row = next(l for l in stats if "k_map<false>" in l)
-    avg_ms = float(row.split(",")[-5]) * 1e-6       # AverageNs
-    assert abs(avg_ms - r["launch_ms"]) / r["launch_ms"] < 0.02
+    cols = [c.strip('"') for c in row.split(",")]
+    hdr = [c.strip('"') for c in stats[0].split(",")]
+    avg_ms = float(cols[hdr.index("AverageNs")]) * 1e-6
+    assert abs(avg_ms - b["roofline"]["launch_ms"]) / b["roofline"]["launch_ms"] < 0.03
 
 
 def test_algorithmic_bytes_formula():

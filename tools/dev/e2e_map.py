@@ -30,7 +30,7 @@ t0 = time.time()
 files = []
 for f0 in range(0, n, per_file):
     reads = [dict(id="r%07d" % i, channel=1 + i % 512, number=i, start=0, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
-                  signal=raw[int(off[i]):int(off[i + 1])].tolist()) for i in range(f0, min(n, f0 + per_file))]
+                  signal=raw[int(off[i]):int(off[i + 1])]) for i in range(f0, min(n, f0 + per_file))]
     fn = d / ("batch_%03d.fast5" % (f0 // per_file))
     unc.write_fast5(str(fn), reads, True, 4000.0)
     files.append(fn)

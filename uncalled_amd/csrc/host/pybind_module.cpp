@@ -1,5 +1,6 @@
 // pybind11 module `_uncalled_amd`: the subset of the reference's `_uncalled` (src/pybinder.cpp:14-91) that
 // `uncalled map` touches -- Conf, MapPool, Paf -- with the same names, properties and methods.
+#include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -75,7 +76,12 @@ PYBIND11_MODULE(_uncalled_amd, m) {
                   r.calib.range = d["range"].cast<float>();
                   r.calib.offset = d["offset"].cast<float>();
                   r.calib.digitisation = d["digitisation"].cast<float>();
-                  r.signal = d["signal"].cast<std::vector<int16_t>>();
+                  if (py::isinstance<py::array>(d["signal"])) {          // numpy int16: one memcpy instead of a cast per sample
+                      auto a = py::array_t<int16_t, py::array::c_style | py::array::forcecast>::ensure(d["signal"]);
+                      r.signal.assign(a.data(), a.data() + a.size());
+                  } else {
+                      r.signal = d["signal"].cast<std::vector<int16_t>>();
+                  }
                   rs.push_back(std::move(r));
               }
               return write_fast5(path, rs, multi, sample_rate);

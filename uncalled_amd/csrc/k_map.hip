@@ -202,7 +202,7 @@ __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, 
 
 // remove entry `slot` of directory position L, whose leaf has pool index `id` and `c` clusters; keeps the directory's first keys right
 // (the structural paths -- directory shifts, erase, the insert that may split -- stay inline: out of line, with the tracker
-// passed through the stack, the gfx950 build returned wrong results on the device while the emulator agreed with the oracle)
+// passed through the stack, the gfx950 build returned wrong results on the device while the emulator build of the same sources did not)
 __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane,
                                               uint32_t &top_n) {
     if (c == 1 || slot == 0) top_n = 0;      // the directory changes: its LDS sample is stale
