@@ -279,3 +279,27 @@ def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2,
     assert m3.last_remap()[0] == 0
     for name in hits.dtype.names:
         assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]), name
+
+
+def case_big_forests(lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
+    """Path forests of more than 512 children per event on the small index (permissive thresholds): the sorts beyond one
+    register block -- 512-key blocks + stages through memory -- in both key modes, against the oracle."""
+    import shutil
+    for suf in (".amb", ".ann", ".bwt", ".pac", ".sa"):
+        shutil.copy(str(example["prefix"]) + suf, str(tmp_path / ("loose" + suf)))
+    (tmp_path / "loose.uncl").write_text("default\t-10.07,-5.5,-5.0,-4.6,-4.3,-4.1\t0.3\t115.000\n")
+    prefix = tmp_path / "loose"
+    n = 3
+    off_all = goldens["sim_offsets"]
+    raw = np.concatenate([goldens["sim_signal"][int(off_all[i]):int(off_all[i]) + 5000] for i in range(n)])
+    off = (np.arange(n + 1) * 5000).astype(np.uint64)
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    want = oracle_hits(oracle_lib.Index(prefix), raw, off, cal)
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("UNC_WIDE_KEYS", "1")
+        ix = capi.Index(prefix, lib=lib)
+        hits = capi.Mapper(ix, n_slots=n).map_batch(raw, off, cal)
+        assert_hits_equal(hits, want, "big forests, wide keys" if wide else "big forests")
+        assert (hits["n_nbr"] / np.maximum(hits["event_i"], 1)).min() > 1000        # ~600 parents, well over 512 children per event
+    monkeypatch.delenv("UNC_WIDE_KEYS")

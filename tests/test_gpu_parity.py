@@ -157,3 +157,7 @@ def test_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slic
 @pytest.mark.parametrize("pool_chunks,n_waves", [(3, 2), (1, 1)])
 def test_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
     pc.case_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves)
+
+
+def test_big_forests(hip_lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
+    pc.case_big_forests(hip_lib, oracle_lib, example, goldens, tmp_path, monkeypatch)

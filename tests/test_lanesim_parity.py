@@ -60,6 +60,10 @@ def test_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunk
     pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=6)
 
 
+def test_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
+    pc.case_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatch)
+
+
 @pytest.fixture(scope="module")
 def sim_lib_top():
     """The emulator library built with UNC_TOP_MIN=1: add_seed's LDS-sampled directory level, which production sets only

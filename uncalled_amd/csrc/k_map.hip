@@ -556,6 +556,7 @@ static __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, in
     block_store<E>(a, b, out, 0, n, lane);
 }
 
+constexpr int GS_BATCH = 4;     // passes of a global sort stage whose loads are issued together (N / 2 / 64 >= 8 passes)
 // n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
 static __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
     constexpr int E = 8;
@@ -571,13 +572,23 @@ static __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, 
     wave_sync();
     for (uint32_t k = 2 * B; k <= N; k <<= 1) {
         for (uint32_t j = k >> 1; j >= B; j >>= 1) {
-            for (uint32_t t = (uint32_t)lane; t < N / 2; t += 64) {
-                uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                uint32_t p = i | j;
-                SortKey x = out[i], y = out[p];
-                bool up = (i & k) == 0;
-                bool gt = key_gt(x.a, x.b, y.a, y.b);
-                if (up ? gt : !gt) { out[i] = y; out[p] = x; }
+            // the pairs of one stage are disjoint: four passes' worth of loads are in flight before the first store (the
+            // stage is otherwise one dependent memory round trip per 64 pairs)
+            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
+                SortKey x[GS_BATCH], y[GS_BATCH];
+                uint32_t ii[GS_BATCH];
+#pragma unroll
+                for (int u = 0; u < GS_BATCH; ++u) {
+                    const uint32_t t = t0 + 64u * u + (uint32_t)lane;
+                    ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    x[u] = out[ii[u]]; y[u] = out[ii[u] | j];
+                }
+#pragma unroll
+                for (int u = 0; u < GS_BATCH; ++u) {
+                    const bool up = (ii[u] & k) == 0;
+                    const bool gt = key_gt(x[u].a, x[u].b, y[u].a, y[u].b);
+                    if (up ? gt : !gt) { out[ii[u]] = y[u]; out[ii[u] | j] = x[u]; }
+                }
             }
             wave_sync();
         }
@@ -697,36 +708,59 @@ static __device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t 
     }
     wave_sync();
     for (uint32_t k = 2 * B; k <= N; k <<= 1) {
-        // flip: i against i ^ (k - 1); a pair whose upper element is padding (>= n) has nothing to exchange
-        for (uint32_t t0 = 0; t0 < N / 2; t0 += 64) {
-            const uint32_t t = t0 + (uint32_t)lane;
-            const uint32_t i = ((t & ~((k >> 1) - 1)) << 1) | (t & ((k >> 1) - 1));
-            const uint32_t p = i ^ (k - 1);
-            if (p < n) {
-                const uint64_t x = out[i], y = out[p];
-                if (x > y) { out[i] = y; out[p] = x; }
+        // flip: i against i ^ (k - 1); a pair whose upper element is padding (>= n) has nothing to exchange.  The pairs of
+        // one stage are disjoint: four passes' worth of loads are in flight before the first store (a stage is otherwise one
+        // dependent memory round trip per 64 pairs, and three such stages were most of this sort's time)
+        for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
+            uint64_t x[GS_BATCH], y[GS_BATCH];
+            uint32_t ii[GS_BATCH], pp[GS_BATCH];
+#pragma unroll
+            for (int u = 0; u < GS_BATCH; ++u) {
+                const uint32_t t = t0 + 64u * u + (uint32_t)lane;
+                ii[u] = ((t & ~((k >> 1) - 1)) << 1) | (t & ((k >> 1) - 1));
+                pp[u] = ii[u] ^ (k - 1);
+                x[u] = 0; y[u] = 0;
+                if (pp[u] < n) { x[u] = out[ii[u]]; y[u] = out[pp[u]]; }
             }
+#pragma unroll
+            for (int u = 0; u < GS_BATCH; ++u)
+                if (pp[u] < n && x[u] > y[u]) { out[ii[u]] = y[u]; out[pp[u]] = x[u]; }
         }
         wave_sync();
         for (uint32_t j = k >> 2; j >= B; j >>= 1) {
-            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64) {
-                const uint32_t t = t0 + (uint32_t)lane;
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t p = i | j;
-                if (uniform32(p) >= n) continue;            // p grows with the lane: the whole pass is padding
-                if (p < n) {
-                    const uint64_t x = out[i], y = out[p];
-                    if (x > y) { out[i] = y; out[p] = x; }
+            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
+                if (uniform32((((t0 & ~(j - 1)) << 1) | (t0 & (j - 1))) | j) >= n) continue;   // p grows with t: the whole batch is padding
+                uint64_t x[GS_BATCH], y[GS_BATCH];
+                uint32_t ii[GS_BATCH];
+#pragma unroll
+                for (int u = 0; u < GS_BATCH; ++u) {
+                    const uint32_t t = t0 + 64u * u + (uint32_t)lane;
+                    ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    x[u] = 0; y[u] = 0;
+                    if ((ii[u] | j) < n) { x[u] = out[ii[u]]; y[u] = out[ii[u] | j]; }
                 }
+#pragma unroll
+                for (int u = 0; u < GS_BATCH; ++u)
+                    if ((ii[u] | j) < n && x[u] > y[u]) { out[ii[u]] = y[u]; out[ii[u] | j] = x[u]; }
             }
             wave_sync();
         }
-        for (uint32_t base = 0; base < n; base += B) {
+        // the register stages of this merge, two blocks per trip to memory where a second one with real keys exists
+        for (uint32_t base = 0; base < n; base += 2 * B) {
+            const bool two = base + B < n;
+            uint64_t b2[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
+            for (int e = 0; e < E; ++e) {
+                a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
+                b2[e] = two ? out[base + B + (uint32_t)lane * E + (uint32_t)e] : ~0ull;
+            }
             asc_stages64<E>(a, B >> 1, lane);
+            if (two) asc_stages64<E>(b2, B >> 1, lane);
 #pragma unroll
-            for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
+            for (int e = 0; e < E; ++e) {
+                out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
+                if (two) out[base + B + (uint32_t)lane * E + (uint32_t)e] = b2[e];
+            }
         }
         wave_sync();
     }
@@ -1348,28 +1382,34 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
                     uint32_t ttot;
                     const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
-                    for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), sp.start + j);
+                    // one task per FM row of a seed path: the row (40 bits) with the seed's event (16 bits) and move count on top,
+                    // so that the serial part below gets everything about 64 seeds from one coalesced load
+                    {
+                        const uint64_t tag = ((uint64_t)(sp.evt & 0xFFFFu) << 40) | ((uint64_t)sp.ref_len << 56);
+                        for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), (sp.start + j) | tag);
+                    }
                     wave_sync();
                     for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
                         const uint32_t ti = t0 + (uint32_t)lane;
                         if (ti < ttot) {
                             uint32_t lf;
-                            const uint64_t row = gld<uint64_t>(sb, tasks_off + (ti << 3));
+                            const uint64_t v = gld<uint64_t>(sb, tasks_off + (ti << 3));
+                            const uint64_t row = v & ((1ull << 40) - 1ull);
                             const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
-                            gst(sb, tasks_off + (ti << 3), ix.seq_len - sa);    // sa_end, mapper.cpp:678
+                            gst(sb, tasks_off + (ti << 3), (ix.seq_len - sa) | (v & ~((1ull << 40) - 1ull)));    // sa_end, mapper.cpp:678
                             c_sa++;
                             c_lf += lf;
                         }
                     }
                     wave_sync();
                     PHASE_END(5);
-                    const uint32_t nl = n_seedp - sb0 < WAVE ? n_seedp - sb0 : WAVE;
-                    for (uint32_t l = 0; l < nl; ++l) {
-                        const uint32_t cnt = bcast32(sp.count, (int)l), o = bcast32(toff, (int)l);
-                        const uint32_t ev = bcast32(sp.evt, (int)l), rl = bcast32(sp.ref_len, (int)l);
-                        for (uint32_t j = 0; j < cnt; ++j) {
-                            const uint64_t sa_end = uniform64(gld<uint64_t>(sb, tasks_off + ((o + j) << 3)));
-                            add_seed(T, TM, P.min_map_len, sa_end, rl, ev, lane, s_top, top_n);
+                    // SeedTracker::add_seed in the reference's order = task order (seed paths in list order, their rows ascending)
+                    for (uint32_t t0 = 0; t0 < ttot && !T.status; t0 += WAVE) {
+                        const uint32_t nt = ttot - t0 < WAVE ? ttot - t0 : WAVE;
+                        const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
+                        for (uint32_t j = 0; j < nt; ++j) {
+                            const uint64_t v = bcast64(mine, (int)j);
+                            add_seed(T, TM, P.min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane, s_top, top_n);
                         }
                     }
                     PHASE_END(6);

@@ -532,6 +532,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     if (p->max_paths == 0 || p->max_paths > 65535) return fail(UNC_ERR_ARG, "max_paths must be in 1..65535");
     if (p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT) return fail(UNC_ERR_ARG, "max_rep_copy must be <= %d", MAX_REP_COPY_LIMIT);
     if (p->max_consec_stay > 255) return fail(UNC_ERR_ARG, "max_consec_stay must be <= 255");
+    if (p->max_events > 65535) return fail(UNC_ERR_ARG, "max_events must be <= 65535");
     HIPCHK(hipSetDevice(ix->device));
     unc_mapper *m = new unc_mapper();
     struct Guard { unc_mapper *p; ~Guard() { if (p) unc_mapper_free(p); } } guard{m};
@@ -1055,7 +1056,8 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     *out = nullptr;
     if (p->seed_len != UNC_SEED_LEN || p->window_length1 != UNC_WINDOW1 || p->window_length2 != UNC_WINDOW2)
         return fail(UNC_ERR_ARG, "seed_len/window lengths must be %d/%d/%d", UNC_SEED_LEN, UNC_WINDOW1, UNC_WINDOW2);
-    if (p->max_paths == 0 || p->max_paths > 65535 || p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT || p->max_consec_stay > 255)
+    if (p->max_paths == 0 || p->max_paths > 65535 || p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT || p->max_consec_stay > 255 ||
+        p->max_events > 65535)
         return fail(UNC_ERR_ARG, "unsupported parameter value");
     HIPCHK(hipSetDevice(ix->device));
     unc_rt *rt = new unc_rt();
