@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         const uint32_t nt = ttot - t0 < WAVE ? ttot - t0 : WAVE;
                         const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
                         for (uint32_t j = 0; j < nt; ++j) {
-                            const uint64_t v = bcast64(mine, (int)j);
+                            const uint64_t v = uniform64(bcast64(mine, (int)j));     // scalar, as every argument of add_seed must be
                             add_seed(T, TM, P.min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane, s_top, top_n);
                         }
                     }
