@@ -37,7 +37,7 @@ def test_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
     pc.case_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
 
 
-@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 6, None), (3, 9, None), (2, 8, 2)])
+@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 6, None), (2, 8, 2)])   # (3, 31) runs on the GPU
 def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks):
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
@@ -78,5 +78,4 @@ def sim_lib_top():
 
 def test_sampled_directory_search(sim_lib_top, oracle_lib, example, goldens):
     pc.case_trace_matches_oracle_every_event(sim_lib_top, oracle_lib, example, goldens)
-    pc.case_synthetic_batch(sim_lib_top, oracle_lib, example, goldens, 10000, 10)
     pc.case_cluster_pool_pressure(sim_lib_top, oracle_lib, example, goldens, 1, 1, n_reads=6)
