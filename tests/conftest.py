@@ -69,8 +69,13 @@ def goldens():
 @pytest.fixture(scope="session")
 def sim_lib():
     """The product's kernel sources compiled against tests/lanesim (CPU SIMT emulator)."""
-    subprocess.run(["make", "-s", "-C", str(ROOT / "tests" / "lanesim")], check=True)
+    import os
     from uncalled_amd import capi
+    extra = os.environ.get("UNC_LANESIM_EXTRA")      # dev: the emulator suite over a variant build (extra -D flags)
+    if extra:
+        subprocess.run(["make", "-s", "-C", str(ROOT / "tests" / "lanesim"), "OUT=_build_extra", "EXTRA=" + extra], check=True)
+        return capi.load(ROOT / "tests" / "lanesim" / "_build_extra" / "libuncalled_sim.so")
+    subprocess.run(["make", "-s", "-C", str(ROOT / "tests" / "lanesim")], check=True)
     return capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
 
 

@@ -168,6 +168,24 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     return __lanesim_shfl_abs(v, __lanesim_lane() ^ mask);
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __lanesim_shfl_abs(v, 0); }
+// v_mov_b32_dpp as the kernels use it (row_shr:n, row_shl:n, row_bcast:15, row_bcast:31, wave_shr:1, wave_shl:1).  A lane whose
+// source does not exist (or whose row / bank is masked off) keeps an undefined destination on the hardware when
+// bound_ctrl is clear: the emulator hands such lanes a poison value, so that a kernel relying on it fails its parity test.
+static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const uint64_t *t = lanesim::wave_exchange((uint64_t)(uint32_t)v);
+    const int base = __lanesim_wave_base(), l = __lanesim_lane(), row = l >> 4, rl = l & 15;
+    int src = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (rl >= n) src = l - n; }
+    else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; if (rl + n < 16) src = l + n; }
+    else if (ctrl == 0x142) { if (row >= 1) src = row * 16 - 1; }
+    else if (ctrl == 0x143) { if (row >= 2) src = 31; }
+    else if (ctrl == 0x138) { if (l >= 1) src = l - 1; }
+    else if (ctrl == 0x130) { if (l < 63) src = l + 1; }
+    else std::abort();
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (rl >> 2)) & 1)) src = -1;
+    if (src < 0) return bound_ctrl ? 0 : (int)0xDEADBEEF;
+    return (int)(uint32_t)t[base + src];
+}
 
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned acc) {
     int l = __lanesim_lane();

@@ -15,7 +15,9 @@ from tools.simulate_reads import CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION
 n = int(sys.argv[1])
 names, lens, codes = synthetic_genome(1, 4641652, seed=1)
 pre = Path("/tmp/ub/ecoli_syn"); pre.parent.mkdir(exist_ok=True)
-if not Path(str(pre) + ".sa").exists():
+if (ROOT / "data" / "ecoli_p.sa").exists():       # a parameterised index left by an earlier build: travels with the snapshot
+    pre = ROOT / "data" / "ecoli_p"
+elif not Path(str(pre) + ".sa").exists():
     build_from_codes(pre, names, [""], lens, codes)
     from uncalled_amd.index_params import parameterize
     _ix = capi.Index(pre); parameterize(_ix, pre); _ix.close()
@@ -23,7 +25,7 @@ sim = simulate_reads_torch(codes, lens, n, seed=42, device="cuda:0")
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 first = None
 for spec in sys.argv[2:]:
-    # lib.so[@n_slots[@slice_events[@events_reads_per_wave]]]: n_slots 0 = library default, 1 = one slot per wavefront (no time slicing)
+    # lib.so[@n_slots[@slice_events[@events_reads_per_wave[@n_waves]]]]: n_slots 0 = library default, 1 = one slot per wavefront (no time slicing)
     lib, *rest = spec.split("@")
     kw = {}
     if rest and int(rest[0]) == 1:
@@ -32,8 +34,12 @@ for spec in sys.argv[2:]:
         kw = dict(n_slots=int(rest[0]), n_waves=256 * 12)
     if len(rest) > 1 and int(rest[1]):
         kw["slice_events"] = int(rest[1])
-    if len(rest) > 2:
+    if len(rest) > 2 and int(rest[2]):
         kw["events_reads_per_wave"] = int(rest[2])
+    if len(rest) > 3 and int(rest[3]):          # wavefronts in flight (0 = what the kernel's occupancy gives)
+        kw["n_waves"] = int(rest[3])
+        if kw.get("n_slots") is None and rest and int(rest[0]) == 0:
+            kw["n_slots"] = 4 * int(rest[3])
     try:
         L = capi.load(lib)
         ix = capi.Index(pre, lib=L)
@@ -47,7 +53,8 @@ for spec in sys.argv[2:]:
             te.append(m.last_timing()[0])
             t.append(m.last_timing()[1])
         busy = m.last_wave_busy() if hasattr(L, "unc_mapper_last_wave_busy") else -1
-        if hasattr(L, "unc_mapper_set_profile"):   # phase shares from one extra pass of the counting instantiation
+        import os
+        if hasattr(L, "unc_mapper_set_profile") and not os.environ.get("AB_NOPROF"):   # phase shares from one extra pass of the counting instantiation
             m.set_profile(True)
             m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
             t.append(-m.last_timing()[1])

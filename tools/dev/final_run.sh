@@ -8,7 +8,7 @@
 #   rt       realtime workload (512 channels), E. coli and chr20 thresholds
 #   e2e      python -m uncalled_amd map on multi-fast5 files (end to end: HDF5 -> staging -> GPU -> PAF text)
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
-STAGES=${@:-tests bench stats pmc rt e2e}
+STAGES=${@:-tests pmc bench stats rt e2e}   # pmc before bench: the bench line reads `traffic` from the summary the pmc stage writes
 for s in $STAGES; do
 case $s in
 tests)

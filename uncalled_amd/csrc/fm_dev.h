@@ -93,23 +93,48 @@ __device__ __forceinline__ uint64_t fm_part_rank(const FmPart &b, uint64_t kk, u
     return b.cnt + n;
 }
 
-// BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c (bwt_2occ).  Like bwt_2occ, the two
-// rank queries share the block when s - 1 and e fall into the same one (nearly always for the short ranges that make
-// up most of the path forest).
+// BwaIndex::get_neighbor: one backward-search step of the range [s,e] with base c (bwt_2occ), in two halves so that a caller
+// can have several look-ups in flight: fm_nbr_issue requests the block words (nothing waits on them), fm_nbr_finish
+// computes the two ranks.  Like bwt_2occ, the two rank queries share the block when s - 1 and e fall into the same one
+// (nearly always for the short ranges that make up most of the path forest); when they do not (young paths, sources), both
+// blocks are requested before either rank is computed -- one memory round trip, not two in a row.
+struct FmNbr {
+    FmPart bl, bk;
+    uint64_t kk, ll, ok, ol;      // sentinel-adjusted positions; ok / ol preset for the positions that need no block
+    uint32_t c;
+    bool k_plain, l_plain, shared;
+};
+__device__ __forceinline__ FmNbr fm_nbr_issue(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c) {
+    FmNbr q;
+    const uint64_t k = s - 1, l = e;
+    q.c = c;
+    q.k_plain = k != ix.seq_len && k != ~0ull; q.l_plain = l != ix.seq_len && l != ~0ull;
+    q.kk = k - (k >= ix.primary ? 1 : 0); q.ll = l - (l >= ix.primary ? 1 : 0);
+    q.ok = k == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0; q.ol = l == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0;
+    q.shared = q.k_plain && q.l_plain && q.kk <= q.ll && (q.kk >> 7) == (q.ll >> 7);   // the words loaded for l serve k
+    q.bl.cnt = 0; q.bl.lo = q.bl.hi = make_uint4(0u, 0u, 0u, 0u);
+    q.bk = q.bl;
+    if (q.l_plain) q.bl = fm_load_part(ix, q.ll, c);
+    if (q.k_plain && !q.shared) q.bk = fm_load_part(ix, q.kk, c);
+    return q;
+}
+__device__ __forceinline__ void fm_nbr_finish(const DevIndex &ix, const FmNbr &q, uint64_t *os, uint64_t *oe) {
+    uint64_t ok = q.ok, ol = q.ol;
+    if (q.l_plain) ol = fm_part_rank(q.bl, q.ll, q.c);
+    if (q.k_plain) {
+        FmPart pk;               // the block of k: the one loaded for l when they share it
+        pk.cnt = q.shared ? q.bl.cnt : q.bk.cnt;
+        pk.lo = q.shared ? q.bl.lo : q.bk.lo;
+        pk.hi = q.shared ? q.bl.hi : q.bk.hi;
+        ok = fm_part_rank(pk, q.kk, q.c);
+    }
+    *os = ix.L2[q.c] + ok + 1;
+    *oe = ix.L2[q.c] + ol;
+}
 __device__ __forceinline__ void fm_get_neighbor(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c,
                                                 uint64_t *os, uint64_t *oe) {
-    const uint64_t k = s - 1, l = e;
-    const bool k_plain = k != ix.seq_len && k != ~0ull, l_plain = l != ix.seq_len && l != ~0ull;
-    const uint64_t kk = k - (k >= ix.primary ? 1 : 0), ll = l - (l >= ix.primary ? 1 : 0);
-    uint64_t ok = k == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0, ol = l == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0;
-    FmPart bl;
-    if (l_plain) { bl = fm_load_part(ix, ll, c); ol = fm_part_rank(bl, ll, c); }
-    if (k_plain) {
-        if (l_plain && kk <= ll && (kk >> 7) == (ll >> 7)) ok = fm_part_rank(bl, kk, c);    // its words are loaded
-        else { const FmPart bk = fm_load_part(ix, kk, c); ok = fm_part_rank(bk, kk, c); }
-    }
-    *os = ix.L2[c] + ok + 1;
-    *oe = ix.L2[c] + ol;
+    const FmNbr q = fm_nbr_issue(ix, s, e, c);
+    fm_nbr_finish(ix, q, os, oe);
 }
 
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps

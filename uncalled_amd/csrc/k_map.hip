@@ -1118,10 +1118,9 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                             cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
                             ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
                         }
-                        if (klb && cs == ce) {
-                            const ulonglong2 kr = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[ck];
-                            if (cs == kr.x || cs == kr.y) bchild = true;
-                        }
+                        // the k-mer's own range, for the boundary test after the record is out: requested here, without a
+                        // condition, so that the record arithmetic below runs while it is on its way
+                        const ulonglong2 kr = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[ck];
                         SortKey key;
                         const uint32_t gi = nchild + li;
                         const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
@@ -1132,6 +1131,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         gst(sb, co + 32u, rec);
                         gst(sb, co + 48u, sec);
                         gst(sb, ukeys_off + (gi << 4), key);
+                        if (klb && cs == ce && (cs == kr.x || cs == kr.y)) bchild = true;
                     }
                 }
                 nchild += nwrite;
@@ -1446,13 +1446,26 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                                    w2 = ((event_i - 1u) % PS_RING) << 2, w3 = (event_i % PS_RING) << 2;
                     const uint32_t r0 = ((event_i + 2u) % PS_RING) << 2, r1 = ((event_i + 3u) % PS_RING) << 2,
                                    r2 = ((event_i + 4u) % PS_RING) << 2, r3 = ((event_i + 5u) % PS_RING) << 2;
+                    // list entry two passes ahead, ring index and recent sums one pass ahead of their use (the records of a
+                    // pass are distinct from the next pass's: what this pass stores is not what the next one has loaded)
+                    uint32_t idx_c = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, lst_off + ((uint32_t)lane << 2)) : 0u;
+                    uint32_t idx_n = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, lst_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
+                    uint32_t oring_c = RING_NONE;
+                    float4 rc_c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((uint32_t)lane < n_parents) {
+                        oring_c = gld<uint32_t>(sb, rec_off + (idx_c << 6) + 28u); rc_c = gld<float4>(sb, rec_off + (idx_c << 6) + 32u);
+                    }
                     for (uint32_t k0 = 0; k0 < n_parents; k0 += WAVE) {
                         const uint32_t k = k0 + (uint32_t)lane;
+                        const uint32_t idx = idx_c, oring = oring_c;
+                        const float4 rc = rc_c;
+                        idx_c = idx_n;
+                        if (k + WAVE < n_parents) {
+                            oring_c = gld<uint32_t>(sb, rec_off + (idx_c << 6) + 28u); rc_c = gld<float4>(sb, rec_off + (idx_c << 6) + 32u);
+                        }
+                        if (k + 2 * WAVE < n_parents) idx_n = gld<uint32_t>(sb, lst_off + ((k + 2 * WAVE) << 2));
                         if (k < n_parents) {
-                            const uint32_t idx = gld<uint32_t>(sb, lst_off + (k << 2));
                             const uint32_t ro = rec_off + (idx << 6);
-                            const uint32_t oring = gld<uint32_t>(sb, ro + 28u);
-                            const float4 rc = gld<float4>(sb, ro + 32u);
                             const uint32_t no = nring_off + idx * (RING_FLOATS * 4u);
                             if (oring != RING_NONE) {
                                 const uint32_t oo = oring_off + oring * (RING_FLOATS * 4u);
