@@ -100,7 +100,7 @@ class Index:
         self.size = lib().unc_o_index_size(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # module globals are gone at interpreter shutdown
             lib().unc_o_index_free(self.h)
             self.h = None
 
@@ -181,7 +181,7 @@ class Mapper:
             raise RuntimeError("oracle: unsupported params")
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().unc_o_mapper_free(self.h)
             self.h = None
 
