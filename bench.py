@@ -208,7 +208,10 @@ def measured_traffic(a, workload):
     d = json.loads(pmc.read_text())
     if d.get("workload") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload):
         return None, f"{pmc.name} was collected on {d.get('workload')} / {d.get('reads_per_launch')} reads"
-    return float(d["hbm_bytes_per_launch"]), f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; calibrated, see the file)"
+    src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; calibrated, see the file)"
+    if d.get("kernel_state"):
+        src += "; " + d["kernel_state"]
+    return float(d["hbm_bytes_per_launch"]), src
 
 
 def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, dist, barrier, cache, lib, dev_name, extras, cpu_budget):
