@@ -1,7 +1,10 @@
-"""Dev tool: time k_map of several builds of the library on the same E. coli batch and check that they agree.
+"""Dev tool: time k_map of several builds of the library on the same batch and check that they agree.
 
-    python tools/dev/ab_libs.py <n_reads> <lib.so> [<lib.so> ...]
-The first library's hits are the reference the others are compared with (all fields, bit for bit)."""
+    python tools/dev/ab_libs.py <n_reads>[:workload] <lib.so> [<lib.so> ...]
+workload: ecoli (default), chr20, hs400 (400 Mb in 8 contigs: where add_seed is a third of the time) -- bench.py's references.
+The first library's hits are the reference the others are compared with (all fields, bit for bit).
+AB_NOPROF=1 skips the extra pass with the profiling instantiation (phase shares)."""
+import os
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
@@ -12,15 +15,21 @@ from uncalled_amd.build_index import build_from_codes, synthetic_genome
 from tools.simulate_reads_torch import simulate_reads_torch
 from tools.simulate_reads import CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION
 
-n = int(sys.argv[1])
-names, lens, codes = synthetic_genome(1, 4641652, seed=1)
-pre = Path("/tmp/ub/ecoli_syn"); pre.parent.mkdir(exist_ok=True)
-if (ROOT / "data" / "ecoli_p.sa").exists():       # a parameterised index left by an earlier build: travels with the snapshot
-    pre = ROOT / "data" / "ecoli_p"
-elif not Path(str(pre) + ".sa").exists():
-    build_from_codes(pre, names, [""], lens, codes)
-    from uncalled_amd.index_params import parameterize
-    _ix = capi.Index(pre); parameterize(_ix, pre); _ix.close()
+n, _, workload = sys.argv[1].partition(":")
+n = int(n)
+workload = workload or "ecoli"
+if workload == "ecoli":
+    names, lens, codes = synthetic_genome(1, 4641652, seed=1)
+    pre = Path("/tmp/ub/ecoli_syn"); pre.parent.mkdir(exist_ok=True)
+    if (ROOT / "data" / "ecoli_p.sa").exists():       # a parameterised index left by an earlier build: travels with the snapshot
+        pre = ROOT / "data" / "ecoli_p"
+    elif not Path(str(pre) + ".sa").exists():
+        build_from_codes(pre, names, [""], lens, codes)
+        from uncalled_amd.index_params import parameterize
+        _ix = capi.Index(pre); parameterize(_ix, pre); _ix.close()
+else:
+    import bench       # its index cache and builders (GPU suffix sort + `uncalled index` parameterisation)
+    pre, codes, lens = bench.ensure_index(Path("/tmp/uncalled_amd_bench"), 0, lambda: None, workload, "cuda:0")
 sim = simulate_reads_torch(codes, lens, n, seed=42, device="cuda:0")
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 first = None
@@ -53,7 +62,6 @@ for spec in sys.argv[2:]:
             te.append(m.last_timing()[0])
             t.append(m.last_timing()[1])
         busy = m.last_wave_busy() if hasattr(L, "unc_mapper_last_wave_busy") else -1
-        import os
         if hasattr(L, "unc_mapper_set_profile") and not os.environ.get("AB_NOPROF"):   # phase shares from one extra pass of the counting instantiation
             m.set_profile(True)
             m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
