@@ -28,7 +28,7 @@ def test_example_read_full_path(sim_lib, oracle_lib, example, goldens):
     pc.case_example_read_full_path(sim_lib, oracle_lib, example, goldens)
 
 
-@pytest.mark.parametrize("max_paths,n_reads", [(10000, 10), (300, 8), (97, 6)])
+@pytest.mark.parametrize("max_paths,n_reads", [(10000, 8), (300, 8), (97, 6)])
 def test_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads):
     pc.case_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads)
 
@@ -37,7 +37,7 @@ def test_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
     pc.case_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
 
 
-@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 6, None), (2, 8, 2)])   # (3, 31) runs on the GPU
+@pytest.mark.parametrize("n_channels,n_reads,max_chunks", [(1, 4, None), (2, 6, 2)])   # (3, 31) runs on the GPU
 def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks):
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
@@ -52,7 +52,7 @@ def test_wide_sort_keys(sim_lib, oracle_lib, example, goldens, monkeypatch):
 
 @pytest.mark.parametrize("max_paths,slice_events,n_slots,n_waves", [(10000, 37, 5, 2), (300, 11, 3, 1)])
 def test_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves):
-    pc.case_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves, n_reads=8)
+    pc.case_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves, n_reads=6)
 
 
 @pytest.mark.parametrize("pool_chunks,n_waves", [(1, 1)])

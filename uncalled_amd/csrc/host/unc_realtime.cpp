@@ -81,9 +81,9 @@ void RealtimePool::start_read(Chan &c, Chunk &chunk) {   // Mapper::new_read(Chu
     c.has_pending = true; c.pending_first = true; c.active = false;
 }
 
-static void remember_old(RealtimePool *, bool &give_up, std::string &old_id, uint32_t &old_number, uint64_t &old_start, uint64_t &old_raw_len,
-                         const std::string &id, uint32_t number, uint64_t start, uint64_t raw_len) {
-    give_up = true; old_id = id; old_number = number; old_start = start; old_raw_len = raw_len;
+// request_reset on the read the channel is mapping: what the next update() reports unmapped + ended
+static void remember_old(RealtimePool::Chan &c) {
+    c.give_up = true; c.old_id = c.id; c.old_number = c.number; c.old_start = c.start; c.old_raw_len = c.raw_len;
 }
 
 // realtime_pool.cpp:74-110
@@ -96,7 +96,7 @@ bool RealtimePool::add_chunk(Chunk &chunk) {
     if (busy && c.number != chunk.get_number()) {
         // the previous read is still aligning: it is reset (reported unmapped + ended by the next update), the chunk
         // of the new read waits in the channel's buffer; a chunk already waiting there is dropped (buffer_chunk)
-        if (c.active) remember_old(this, c.give_up, c.old_id, c.old_number, c.old_start, c.old_raw_len, c.id, c.number, c.start, c.raw_len);
+        if (c.active) remember_old(c);
         start_read(c, chunk);
         return true;
     }
@@ -117,7 +117,7 @@ bool RealtimePool::try_add_chunk(Chunk &chunk) {
     if (chunk.empty()) {
         // all chunks of the read were handed out: give up once the last one is mapped and the read is still undecided
         if (c.active && !c.has_pending) {
-            remember_old(this, c.give_up, c.old_id, c.old_number, c.old_start, c.old_raw_len, c.id, c.number, c.start, c.raw_len);
+            remember_old(c);
             c.active = false;
         }
         return false;
@@ -137,7 +137,7 @@ void RealtimePool::end_read(uint16_t ch, uint32_t number) {
     if (ch >= chans_.size()) return;
     Chan &c = chans_[ch];
     if ((c.active || c.has_pending) && c.number == number) {
-        if (c.active) remember_old(this, c.give_up, c.old_id, c.old_number, c.old_start, c.old_raw_len, c.id, c.number, c.start, c.raw_len);
+        if (c.active) remember_old(c);
         c.active = false; c.has_pending = false; c.pending.clear();
     }
 }

@@ -61,7 +61,6 @@ public:
     uint32_t active_count() const;
     float last_round_ms() const { return last_ms_; }
 
-private:
     struct Chan {
         bool active = false;         // a read is being mapped (Mapper state MAPPING; its last chunk is fully mapped)
         bool has_pending = false;    // a chunk waits for the next update()
@@ -74,6 +73,7 @@ private:
         // the read a give_up refers to when a new read has already taken the channel over
         std::string old_id; uint32_t old_number = 0; uint64_t old_start = 0, old_raw_len = 0;
     };
+private:
     void start_read(Chan &c, Chunk &chunk);
     Paf unmapped_paf(const std::string &id, uint16_t ch_idx, uint64_t start, uint64_t raw_len) const;
     Conf conf_;
