@@ -158,14 +158,23 @@ def case_map_pool_pipeline(unc, po, tmp_path, goldens):
     reads = [dict(id="sim-%d" % i, channel=1 + i, number=i, start=100 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
                   signal=goldens["sim_signal"][int(off[i]):int(off[i + 1])].tolist()) for i in range(n)]
     assert unc.write_fast5(str(tmp_path / "a.fast5"), reads[:4], True, 4000.0)
-    assert unc.write_fast5(str(tmp_path / "b.fast5"), reads[4:], True, 4000.0)
-    pool = unc.MapPool(_conf(unc, 512, batch_reads=3))          # 3 + 3 + 1
+    assert unc.write_fast5(str(tmp_path / "b.fast5"), reads[4:6], True, 4000.0)
+    assert unc.write_fast5(str(tmp_path / "c.fast5"), reads[6:], True, 4000.0)
+    pool = unc.MapPool(_conf(unc, 512, batch_reads=3))          # 3 + 3, later 1
     pool.add_fast5(str(tmp_path / "a.fast5"))
     pool.add_fast5(str(tmp_path / "b.fast5"))
     assert pool.running()
     lines = []
     import time
     t0 = time.time()
+    while pool.running():
+        lines += [str(p) for p in pool.update()]
+        time.sleep(0.01)
+        assert time.time() - t0 < 600
+    assert len(lines) == 6
+    # the worker threads live until stop() (map_pool.cpp:31-42,83-97): a file added after the pool ran dry is mapped too
+    pool.add_fast5(str(tmp_path / "c.fast5"))
+    assert pool.running()
     while pool.running():
         lines += [str(p) for p in pool.update()]
         time.sleep(0.01)

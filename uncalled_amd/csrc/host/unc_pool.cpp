@@ -314,6 +314,7 @@ MapPool::~MapPool() {
 void MapPool::add_fast5(const std::string &fname) {
     std::lock_guard<std::mutex> lk(mtx_);
     new_files_.push_back(fname);
+    cv_.notify_all();       // an idle loader picks it up
 }
 
 bool MapPool::grow(Batch &b, uint64_t need) {
@@ -328,7 +329,8 @@ bool MapPool::grow(Batch &b, uint64_t need) {
     return true;
 }
 
-// fast5 files -> staged batches (flattened int16 samples in page-locked memory + per-read offsets / calibration)
+// fast5 files -> staged batches (flattened int16 samples in page-locked memory + per-read offsets / calibration).  Like the
+// reference's worker threads (map_pool.cpp:31-42) the two threads live until stop(): files may be added at any time.
 void MapPool::loader_main() {
     for (;;) {
         int bi;
@@ -352,19 +354,19 @@ void MapPool::loader_main() {
             b.cal.push_back(r.calib);
             b.meta.push_back(ReadMeta{r.id, r.channel_idx, r.start_sample});
         }
-        std::lock_guard<std::mutex> lk(mtx_);
-        if (b.meta.empty()) {          // the files ran dry
+        std::unique_lock<std::mutex> lk(mtx_);
+        if (b.meta.empty()) {          // the files ran dry: idle until another one is added
             free_.push_front(bi);
-            loader_done_ = true;
+            loader_idle_ = true;
             cv_.notify_all();
-            break;
+            cv_.wait(lk, [&] { return stopped_ || !new_files_.empty(); });
+            loader_idle_ = false;
+            if (stopped_) break;
+            continue;
         }
         staged_.push_back(bi);
         cv_.notify_all();
     }
-    std::lock_guard<std::mutex> lk(mtx_);
-    loader_done_ = true;
-    cv_.notify_all();
 }
 
 void MapPool::mapper_main() {
@@ -372,10 +374,11 @@ void MapPool::mapper_main() {
         int bi;
         {
             std::unique_lock<std::mutex> lk(mtx_);
-            cv_.wait(lk, [&] { return stopped_ || !staged_.empty() || loader_done_; });
-            if (stopped_ || (staged_.empty() && loader_done_)) break;
+            cv_.wait(lk, [&] { return stopped_ || !staged_.empty(); });
+            if (stopped_) break;
             bi = staged_.front();
             staged_.pop_front();
+            mapper_busy_ = true;
         }
         Batch &b = bufs_[bi];
         const size_t n = b.meta.size();
@@ -404,11 +407,9 @@ void MapPool::mapper_main() {
         std::lock_guard<std::mutex> lk(mtx_);
         for (Paf &p : out) done_.push_back(std::move(p));
         free_.push_back(bi);
+        mapper_busy_ = false;
         cv_.notify_all();
     }
-    std::lock_guard<std::mutex> lk(mtx_);
-    mapper_done_ = true;
-    cv_.notify_all();
 }
 
 std::vector<Paf> MapPool::update() {
@@ -427,7 +428,8 @@ bool MapPool::running() {
     std::lock_guard<std::mutex> lk(mtx_);
     if (stopped_) return false;
     if (!started_) return !new_files_.empty() || !reader_.empty();
-    return !(mapper_done_ && done_.empty());
+    // MapPool::running, map_pool.cpp:71-81: files left, a thread at work, or records not yet handed out
+    return !(loader_idle_ && new_files_.empty() && staged_.empty() && !mapper_busy_ && done_.empty());
 }
 
 void MapPool::stop() {

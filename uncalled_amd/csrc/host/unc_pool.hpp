@@ -104,7 +104,8 @@ bool write_fast5(const std::string &path, const std::vector<RawRead> &reads, boo
 
 // MapPool (map_pool.cpp:28-158) on one GPU.  The reference hands reads to worker threads and update() never blocks; here
 // a loader thread reads fast5 files into page-locked staging buffers (two of them: batch k+1 is read and flattened while
-// batch k is on the GPU), a mapper thread feeds them to unc_map_batch, and update() returns whatever has finished.
+// batch k is on the GPU), a mapper thread feeds them to unc_map_batch, and update() returns whatever has finished.  Both
+// threads live until stop(): add_fast5 works at any time, running() turns true again when it does.
 class MapPool {
 public:
     explicit MapPool(const Conf &conf);
@@ -140,7 +141,7 @@ private:
     std::mutex mtx_;
     std::condition_variable cv_;
     std::thread loader_, mapper_thread_;
-    bool started_ = false, stopped_ = false, loader_done_ = false, mapper_done_ = false;
+    bool started_ = false, stopped_ = false, loader_idle_ = false, mapper_busy_ = false;
 };
 
 }  // namespace unc_host
