@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): who is right at GRCh38 scale?  Device batch vs oracle restatement vs the reference's own object code
+"""TEST INFRASTRUCTURE (uses the oracle as the checker).  Dev tool (GPU box): who is right at GRCh38 scale?  Device batch vs oracle restatement vs the reference's own object code
 on the same reads, then a per-event trace (device single-slot trace API vs oracle) of the first read that differs."""
 import os
 import sys

@@ -1,4 +1,4 @@
-"""Dev tool: run the parity cases against an explicitly named build of the HIP library (codegen experiments)."""
+"""TEST INFRASTRUCTURE (uses the oracle as the checker).  Dev tool: run the parity cases against an explicitly named build of the HIP library (codegen experiments)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]

@@ -55,3 +55,18 @@ def test_product_package_does_not_reference_the_oracle():
         txt = f.read_text(errors="ignore")
         assert "oracle" not in txt.replace("no CPU", "") or f.name == "r94_model_table.h", f
         assert "unc_o_" not in txt and "pyoracle" not in txt and "pyref" not in txt, f
+
+
+def test_only_the_allowed_places_use_the_oracle():
+    """Besides the product package (above): `tools/` (data tooling, dev scripts) does not import the oracle either -- scripts
+    that use it as a checker live under tests/.  bench.py touches it only in its cpu_baseline leg, __graft_entry__ only in
+    build() (compiling the checker) and smoke()."""
+    import re
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    for f in (ROOT / "tools").rglob("*.py"):
+        assert not pat.search(f.read_text()), f
+    bench = (ROOT / "bench.py").read_text()
+    uses = [m.start() for m in pat.finditer(bench)]
+    leg = bench.index("def cpu_baseline(")
+    end = bench.index("\ndef ", bench.index("def cpu_baseline_subprocess("))
+    assert uses and all(leg < u < end for u in uses), "bench.py imports the oracle outside its cpu_baseline leg"
