@@ -203,3 +203,40 @@ def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, golden
         assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), i
         assert (hu, int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (ru, r.event_i, r.n_nbr, r.n_sa, r.n_lf), i
     pr.lib().ref_set_max_chunks(1000000)
+
+
+def test_edge_case_reads_equal_live_reference(oracle_lib, ref_lib, example):
+    """The reads of parity_cases.case_events_edge_cases (shorter than the detector windows, flat, negative samples, every
+    head / tail length of the device kernel's blocked loop) through the reference's own EventDetector / Normalizer and,
+    where a read yields events at all, through Mapper::map_read: the oracle the kernels are compared with on these reads is
+    itself pinned on them.  Skipped where /root/reference is absent."""
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    rng = np.random.default_rng(5)
+    reads = [np.array([500], np.int16), rng.integers(300, 700, 12).astype(np.int16),
+             np.full(400, 512, np.int16), rng.integers(-200, 900, 700).astype(np.int16),
+             np.repeat(rng.integers(350, 650, 60), 9).astype(np.int16)]
+    for ln in list(range(13, 42)) + [63, 64, 65, 127, 129, 1000, 1003]:
+        reads.append(np.repeat(rng.integers(330, 680, ln // 5 + 1), 5)[:ln].astype(np.int16) + rng.integers(-6, 7, ln).astype(np.int16))
+    ix = po.Index(example["prefix"])
+    om, rm = po.Mapper(ix), pr.Mapper()
+    mapped_some = 0
+    for i, r in enumerate(reads):
+        sig = po.calibrate(r, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+        ev, mel, tot = po.detect_events(sig)
+        rev, rmel, rtot = pr.events(sig)
+        assert len(ev) == len(rev) and tot == rtot, i
+        assert np.array_equal(ev["mean"], rev["mean"]), i
+        if len(ev) == 0:
+            continue
+        assert np.float32(mel) == np.float32(rmel), i
+        lv, sc, sh = po.normalize(ev["mean"])
+        rlv, _, _ = pr.norm_levels(ev["mean"])         # levels = Normalizer::pop -> at() (normalizer.cpp:114-118), what map_next consumes;
+        assert np.array_equal(lv, rlv, equal_nan=True), i   # get_scale() divides by a float-rounded stdv and is not on the mapping path
+        if not np.all(np.isfinite(lv)):
+            continue                                   # a flat or one-event read: no levels to map
+        h, q = om.map_read(sig), rm.map_read(sig)
+        assert po.hit_paf_cols(h, ix.ref_names()) == q.paf_cols(), i
+        assert (int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (q.event_i, q.n_nbr, q.n_sa, q.n_lf), i
+        mapped_some += 1
+    assert mapped_some > 20
