@@ -79,3 +79,19 @@ def sim_lib_top():
 def test_sampled_directory_search(sim_lib_top, oracle_lib, example, goldens):
     pc.case_trace_matches_oracle_every_event(sim_lib_top, oracle_lib, example, goldens)
     pc.case_cluster_pool_pressure(sim_lib_top, oracle_lib, example, goldens, 1, 1, n_reads=6)
+
+
+@pytest.fixture(scope="module")
+def sim_lib_norepair():
+    """The emulator library built with UNC_MERGE_REPAIR=0: the runs of child keys reach the merge with their out-of-order
+    pairs still in them, so the merge's own check has to notice and send the event through the bitonic network."""
+    import subprocess
+    from pathlib import Path
+    from uncalled_amd import capi
+    root = Path(__file__).resolve().parents[1]
+    subprocess.run(["make", "-s", "-C", str(root / "tests" / "lanesim"), "OUT=_build_norepair", "EXTRA=-DUNC_MERGE_REPAIR=0"], check=True)
+    return capi.load(root / "tests" / "lanesim" / "_build_norepair" / "libuncalled_sim.so")
+
+
+def test_merge_check_and_fallback(sim_lib_norepair, oracle_lib, example, goldens, tmp_path, monkeypatch):
+    pc.case_big_forests(sim_lib_norepair, oracle_lib, example, goldens, tmp_path, monkeypatch, wide_too=False)

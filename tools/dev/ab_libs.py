@@ -57,7 +57,7 @@ for spec in sys.argv[2:]:
         except TypeError:
             m = capi.Mapper(ix)
         t, te = [], []
-        for i in range(2):
+        for i in range(int(os.environ.get("AB_RUNS", 2))):
             hits = m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
             te.append(m.last_timing()[0])
             t.append(m.last_timing()[1])

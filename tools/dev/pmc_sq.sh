@@ -1,0 +1,24 @@
+#!/bin/bash
+# Dev tool (GPU box): SQ counters of k_map on the bench's own 50 k-read E. coli batch, one rocprofv3 pass per group
+# (--pmc with --kernel-trace only).  Each pass maps the batch ONCE with the given library (tools/dev/ab_libs.py, one run).
+#   bash tools/dev/pmc_sq.sh <outdir> [lib.so] [reads] [groups...]
+OUT=${1:-gpurun_out/pmc_sq}; LIB=${2:-uncalled_amd/libuncalled_hip.so}; READS=${3:-50000}; shift 3
+GROUPS_=${@:-a b c d}
+ROOT=$(pwd); mkdir -p $ROOT/$OUT; cd /tmp; export TMPDIR=/tmp
+run() { name=$1; shift
+  AB_NOPROF=1 AB_RUNS=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/$OUT/$name -o pmc -- \
+        python $ROOT/tools/dev/ab_libs.py $READS $ROOT/$LIB > $ROOT/$OUT/$name.log 2>&1 || echo "pass $name failed"; tail -1 $ROOT/$OUT/$name.log; }
+for g in $GROUPS_; do
+case $g in
+a) run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM ;;
+b) run b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH ;;
+c) run c SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES ;;
+d) run d SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS ;;
+e) run e SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_IFETCH SQ_IFETCH_LEVEL SQ_LEVEL_WAVES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE ;;
+f) run f FETCH_SIZE ;;
+w) run w WRITE_SIZE ;;
+esac
+done
+cd $ROOT
+find $OUT -name "*_kernel_trace.csv" -size +3M -delete
+python tools/dev/summarise_sq.py $OUT $READS

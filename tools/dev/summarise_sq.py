@@ -1,0 +1,48 @@
+"""Dev tool: rocprofv3 --pmc passes of tools/dev/pmc_sq.sh -> one JSON summary (counter totals over the k_map dispatches of each
+pass, the pass's own k_map duration from the SAME directory's kernel trace, derived shares).
+
+    python tools/dev/summarise_sq.py gpurun_out/pmc_sq 50000 [out.json]"""
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+src, reads = Path(sys.argv[1]), int(sys.argv[2])
+out = Path(sys.argv[3]) if len(sys.argv) > 3 else src / "summary.json"
+tot, passes = {}, {}
+for d in sorted(p for p in src.iterdir() if p.is_dir()):
+    cc = glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True)
+    kt = glob.glob(str(d / "**" / "*kernel_trace.csv"), recursive=True)
+    disp, names = set(), set()
+    for f in cc:
+        for r in csv.DictReader(open(f)):
+            if "k_map" in r.get("Kernel_Name", ""):
+                tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                disp.add(r.get("Dispatch_Id")); names.add(r["Counter_Name"])
+    dur = []
+    for f in kt:
+        if cc and Path(f).stat().st_mtime + 600 < Path(cc[0]).stat().st_mtime:
+            raise SystemExit(f"{f} is older than the counters of its own pass")
+        for r in csv.DictReader(open(f)):
+            if "k_map" in r.get("Kernel_Name", ""):
+                dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+    passes[d.name] = {"counters": sorted(names), "k_map_dispatches": len(disp), "k_map_ms_under_pmc": dur}
+res = {"reads_per_launch": reads, "kernel": "unc::k_map<false>", "passes": passes, "counters": tot,
+       "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (MI355X_MICROARCH.md); one k_map dispatch per pass"}
+g = tot.get
+der = {}
+if g("SQ_WAVE_CYCLES"):
+    wc = g("SQ_WAVE_CYCLES")
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS"):
+        if g(k) is not None:
+            der["wave_cycle_share_" + k[3:].lower()] = g(k) / wc
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_FLAT",
+          "SQ_INSTS_BRANCH", "SQ_INSTS", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"):
+    if g(k) is not None:
+        der[k[3:].lower() + "_per_read"] = g(k) / reads
+if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INST_CYCLES_VALU"):
+    der["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INST_CYCLES_VALU"))
+res["derived"] = der
+out.write_text(json.dumps(res, indent=1))
+print(json.dumps(res, indent=1))

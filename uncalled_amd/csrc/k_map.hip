@@ -673,24 +673,55 @@ __device__ __forceinline__ void block_sort64(uint64_t (&a)[E], int lane) {
     }
 }
 
-// in: the children's SortKey records (.a = packed key); out: compact sorted uint64 array
+// ---- narrow keys arrive as RUNS.  Phase E files a child's key by what it is: stays and the moves with base 0..3 of the
+// sorted survivors (five runs that come out ascending: a stay keeps its parent's range, and one backward-search step with a
+// fixed base maps ascending ranges to ascending ranges; the four bases' rows are disjoint blocks of the index in base
+// order), and the children of sources (run 5, no order).  KeyArr<R> is a sequence made of R such runs back to back; every
+// field is uniform.
+template <int R> struct KeyArr {
+    uint32_t adj[R];    // byte offset of run r inside the slot, minus 8 * (first index of run r)
+    uint32_t cum[R];    // first index of run r (cum[0] = 0)
+    uint32_t n;
+};
+template <int R> __device__ __forceinline__ uint64_t ka_load(const char *sb, const KeyArr<R> &K, uint32_t i) {
+    uint32_t a = K.adj[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
+    return gld<uint64_t>(sb, a + (i << 3));
+}
+template <int R> __device__ __forceinline__ KeyArr<R> ka_uniform(const KeyArr<R> &K) {
+    KeyArr<R> U;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { U.adj[r] = uniform32(K.adj[r]); U.cum[r] = uniform32(K.cum[r]); }
+    U.n = uniform32(K.n);
+    return U;
+}
+__device__ __forceinline__ KeyArr<1> ka_single(uint32_t off, uint32_t n) { KeyArr<1> K; K.adj[0] = off; K.cum[0] = 0; K.n = n; return K; }
+
+// n <= 64 * E keys of K -> out (byte offset in the slot), sorted
 template <int E>
-static __device__ void sort_regs64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+static __device__ __noinline__ void sort_regs64(char *sb, KeyArr<6> K_, uint32_t out_off, int lane) {
+    const KeyArr<6> K = ka_uniform(K_);
+    const uint32_t n = K.n;
     uint64_t a[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        a[e] = i < n ? in[i].a : ~0ull;
+        a[e] = i < n ? ka_load(sb, K, i) : ~0ull;
     }
     block_sort64<E>(a, lane);
+    wave_sync();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) out[i] = a[e];
+        if (i < n) gst(sb, out_off + (i << 3), a[e]);
     }
 }
 
-static __device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t n, int lane) {
+static __device__ __noinline__ void sort_hybrid64(char *sb, KeyArr<6> K_, uint32_t out_off, int lane) {
+    const KeyArr<6> K = ka_uniform(K_);
+    const uint32_t n = K.n;
+    uint64_t *const out = reinterpret_cast<uint64_t *>(sb + uniform32(out_off));
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -700,9 +731,10 @@ static __device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t 
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-            a[e] = i < n ? in[i].a : ~0ull;
+            a[e] = i < n ? ka_load(sb, K, i) : ~0ull;
         }
         block_sort64<E>(a, lane);
+        wave_sync();                                          // (in place: the block is loaded before any of it is stored)
 #pragma unroll
         for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
     }
@@ -766,6 +798,175 @@ static __device__ void sort_hybrid64(const SortKey *in, uint64_t *out, uint32_t 
     }
 }
 
+// any number of keys, by size class
+static __device__ __noinline__ void sort_any64(char *sb, KeyArr<6> K, uint32_t out_off, int lane) {
+    const uint32_t n = uniform32(K.n);
+    if (n <= 64) sort_regs64<1>(sb, K, out_off, lane);
+    else if (n <= 128) sort_regs64<2>(sb, K, out_off, lane);
+    else if (n <= 256) sort_regs64<4>(sb, K, out_off, lane);
+    else if (n <= 512) sort_regs64<8>(sb, K, out_off, lane);
+    else sort_hybrid64(sb, K, out_off, lane);
+}
+
+// ---- merging two ascending runs (merge path).  The output is cut into tiles of MERGE_TILE keys; a tile's share of A
+// and B is staged in LDS, each lane finds where its MERGE_C outputs start by a binary search on its diagonal and merges
+// them sequentially.  Work per key: one LDS read and a dozen lane instructions, against ~60 compare-exchanges of the
+// bitonic network -- provided the inputs ARE ascending.  The caller checks the result (`verify`) and sorts the keys the
+// hard way if it is not (an event where the runs of phase E were not ascending after all).
+#ifndef UNC_V_MERGEMIN
+#define UNC_V_MERGEMIN 256
+#endif
+constexpr uint32_t MERGE_MIN = UNC_V_MERGEMIN;     // fewer children than this go straight through the bitonic network
+#ifndef UNC_MERGE_REPAIR
+#define UNC_MERGE_REPAIR 1              // (tests build the emulator library with 0: the runs then reach the merge unrepaired, its check
+#endif                                  //  must notice and the event must take the bitonic network instead, with the same result)
+constexpr bool MERGE_REPAIR = UNC_MERGE_REPAIR != 0;
+constexpr uint32_t MERGE_C = 12;
+constexpr uint32_t MERGE_TILE = MERGE_C * WAVE;
+// LDS slot of tile element i: one pad slot per 8 keys, so that lanes whose reading positions are a multiple of 8 keys
+// apart (the typical distance) do not all fall on the same banks
+__device__ __forceinline__ uint32_t mslot(uint32_t i) { return i + (i >> 3); }
+constexpr uint32_t MERGE_LDS_KEYS = MERGE_TILE + MERGE_TILE / 8 + 1;
+
+// how many of the first d keys of merge(A, B) come from A (keys distinct): the first mid with !(A[mid] < B[d - 1 - mid]),
+// 64 probes per memory round trip
+template <int RA, int RB>
+__device__ __forceinline__ uint32_t merge_split(const char *sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
+    uint32_t lo = d > B.n ? d - B.n : 0u, hi = d < A.n ? d : A.n;
+    while (lo < hi) {
+        const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint32_t p = lo + (uint32_t)lane * step;
+        bool less = false;
+        if (p < hi) less = ka_load(sb, A, p) < ka_load(sb, B, d - 1u - p);
+        const uint32_t c = (uint32_t)__popcll(__ballot(less));       // the predicate is monotone: the first c probes hold
+        const uint32_t nlo = c ? lo + (c - 1u) * step + 1u : lo;
+        const uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
+        lo = nlo; hi = c ? nhi : lo;
+    }
+    return lo;
+}
+
+template <int RA, int RB>
+static __device__ __noinline__ uint32_t merge_runs(char *sb, KeyArr<RA> A_, KeyArr<RB> B_, uint32_t out_off_, uint64_t *s_tile, int lane,
+                                                   uint32_t verify_) {
+    const KeyArr<RA> A = ka_uniform(A_);
+    const KeyArr<RB> B = ka_uniform(B_);
+    const uint32_t out_off = uniform32(out_off_), verify = uniform32(verify_);
+    const uint32_t n = A.n + B.n;
+    uint32_t a0 = 0, b0 = 0;
+    uint64_t prev_last = 0;          // (keys are > 0: idx and length fields aside, start >= 1)
+    bool bad = false;
+    for (uint32_t o0 = 0; o0 < n; o0 += MERGE_TILE) {
+        const uint32_t d1 = o0 + MERGE_TILE < n ? o0 + MERGE_TILE : n;
+        const uint32_t a1 = d1 == n ? A.n : merge_split(sb, A, B, d1, lane);
+        const uint32_t b1 = d1 - a1;
+        const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
+        // stage the tile: every load is requested before the first key goes into LDS (one memory round trip, not twelve)
+        {
+            uint64_t v[MERGE_C];
+#pragma unroll
+            for (uint32_t c = 0; c < MERGE_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                v[c] = 0;
+                if (i < na) v[c] = ka_load(sb, A, a0 + i);
+                else if (i < tn) v[c] = ka_load(sb, B, b0 + (i - na));
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < MERGE_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                if (i < tn) s_tile[mslot(i)] = v[c];
+            }
+        }
+        wave_sync();
+        // this lane's outputs [d, d + cnt)
+        const uint32_t d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
+        const uint32_t cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
+        uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+        while (__any(lo < hi)) {
+            if (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_tile[mslot(mid)] < s_tile[mslot(na + d - 1u - mid)]) lo = mid + 1u; else hi = mid;
+            }
+        }
+        uint32_t ia = lo, ib = d - lo;
+        uint64_t va = ia < na ? s_tile[mslot(ia)] : ~0ull, vb = ib < nb ? s_tile[mslot(na + ib)] : ~0ull;
+        uint64_t o[MERGE_C];
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c) {
+            const bool ta = va < vb;
+            o[c] = ta ? va : vb;
+            if (ta) ++ia; else ++ib;
+            const uint32_t idx = ta ? ia : na + ib;
+            const bool ok = ta ? ia < na : ib < nb;
+            uint64_t x = ~0ull;
+            if (ok && c + 1u < cnt) x = s_tile[mslot(idx)];
+            if (ta) va = x; else vb = x;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c)
+            if (c < cnt) gst(sb, out_off + ((o0 + d + c) << 3), o[c]);
+        if (verify) {
+            uint64_t last = o[0];
+            bool w = false;
+#pragma unroll
+            for (uint32_t c = 1; c < MERGE_C; ++c)
+                if (c < cnt) { w = w || !(o[c] > last); last = o[c]; }
+            uint64_t pl = (uint64_t)__shfl_up((unsigned long long)last, 1);
+            if (lane == 0) pl = prev_last;
+            if (cnt > 0 && !(o[0] > pl)) w = true;
+            if (__any(w)) bad = true;
+            const uint32_t ll = (tn - 1u) / MERGE_C;        // the last lane with outputs (tn > 0)
+            prev_last = bcast64(last, (int)ll);
+        }
+        a0 = a1; b0 = b1;
+        wave_sync();
+    }
+    return bad ? 0u : 1u;
+}
+
+// The moves of one base (run r of the streams) are ascending by START; two of them with equal starts can be out of order
+// when their parents were nested ranges (the outer parent comes first and its child can be the longer range).  A key that
+// is smaller than one before it is moved to the unsorted run: what is left is ascending.  Nearly every 64-key chunk has
+// no such key (one compare with the neighbour lane says so); a chunk that has one takes the exact running maximum.
+static __device__ __noinline__ uint32_t repair_run(char *sb, uint32_t run_off_, uint32_t n_, uint32_t x_off_, uint32_t nx_, int lane) {
+    const uint32_t run_off = uniform32(run_off_), n = uniform32(n_), x_off = uniform32(x_off_);
+    uint32_t nx = uniform32(nx_), shift = 0;
+    uint64_t carry = 0;              // the largest key so far (keys are > 0)
+    uint64_t knext = (uint32_t)lane < n ? gld<uint64_t>(sb, run_off + ((uint32_t)lane << 3)) : 0ull;
+    for (uint32_t c0 = 0; c0 < n; c0 += WAVE) {
+        const uint32_t i = c0 + (uint32_t)lane;
+        const bool have = i < n;
+        const uint64_t k = knext;
+        // the next chunk is requested before this one is worked on (what this pass stores lies below what the next one reads)
+        knext = i + WAVE < n ? gld<uint64_t>(sb, run_off + ((i + WAVE) << 3)) : 0ull;
+        uint64_t pk = (uint64_t)__shfl_up((unsigned long long)k, 1);
+        if (lane == 0) pk = carry;
+        bool viol = have && k < pk;
+        const uint32_t nvalid = n - c0 < (uint32_t)WAVE ? n - c0 : (uint32_t)WAVE;
+        if (__any(viol)) {
+            const uint64_t inc = seg_incl_max64(k, lane == 0);
+            uint64_t ex = (uint64_t)__shfl_up((unsigned long long)inc, 1);
+            if (lane == 0) ex = 0;
+            if (ex < carry) ex = carry;
+            viol = have && k < ex;
+            const uint64_t top = bcast64(inc, WAVE - 1);
+            if (top > carry) carry = top;
+        } else carry = bcast64(k, (int)nvalid - 1);
+        const uint64_t vm = __ballot(viol);
+        if (vm == 0 && shift == 0) continue;
+        wave_sync();
+        const uint32_t before = (uint32_t)prefix_popc(vm);
+        if (have) {
+            if (viol) gst(sb, x_off + ((nx + before) << 3), k);
+            else gst(sb, run_off + ((i - shift - before) << 3), k);
+        }
+        const uint32_t nv = (uint32_t)__popcll(vm);
+        shift += nv; nx += nv;
+        wave_sync();
+    }
+    return shift;
+}
+
 __device__ __forceinline__ uint32_t float_orderable(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -820,7 +1021,9 @@ __device__ __forceinline__ void f4_set(float4 &v, uint32_t j, float x) { if (j =
 #define UNC_LB 3
 #endif
 // PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
-template <bool PROF>
+// NARROW: the index allows 64-bit sort keys (DevIndex::key_len_bits > 0: E. coli, chr20): the children's keys leave phase E
+// as sorted runs and are merged; the other instantiation (human-sized references) sorts 128-bit keys
+template <bool PROF, bool NARROW>
 __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
     __shared__ uint32_t s_flags[NKMER / 32];
@@ -839,6 +1042,8 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
     uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
     uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
     static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
+    static_assert(sizeof(s_e) >= MERGE_LDS_KEYS * sizeof(uint64_t), "a merge tile must fit the staging buffer");
+    __shared__ uint16_t s_ckpos[NARROW ? CHILD_MAX : 1];         // narrow keys: a child's position in its run
 
     const int lane = lane_id();
     const uint64_t wave_t0 = (uint64_t)wall_clock64();
@@ -849,12 +1054,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
 
     const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
     const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
-    const uint32_t klb = ix.key_len_bits;            // 0: 128-bit sort keys; else narrow 64-bit keys (see sort_regs64)
+    const uint32_t klb = NARROW ? ix.key_len_bits : 0u;   // 0: 128-bit sort keys; else narrow 64-bit keys (see sort_regs64)
     const uint32_t kvalid = ix.kmer_valid[lane];     // bit j: k-mer j*64+lane occurs in the reference
 
     for (;;) {
         // ---------------- fetch or resume a read ----------------
         uint32_t r = 0, event_i, n_parents, cur;
+        uint32_t n_surv_par = 0;                     // the first n_surv_par parents are the last walk's survivors (sorted)
         uint32_t tstatus = 0;                        // UNC_READ_* bits (mirror of the tracker's status)
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
@@ -905,6 +1111,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
         if ((A.resume && !fresh) || restore) {
             r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
+            n_surv_par = uniform32(st->n_surv);
             T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
             T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
@@ -957,7 +1164,13 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
 
             // ---------------- P: match log-probs ----------------
             uint64_t tk = PROF ? (uint64_t)clock64() : 0ull, tn = 0;
+#ifdef UNC_V_SORTPROF
+#define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[(i) >= 8 ? 1 : (i)] += tn - tk; tk = tn; } else (void)tn
+#define SPHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
+#else
 #define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
+#define SPHASE_END(i) (void)tn
+#endif
             const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
             if (event_i + 1 < n_events) next_mean = MEAN_AT(event_i + 1);
 #pragma unroll 4
@@ -979,6 +1192,9 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             // ---------------- E: extend parents ----------------
             uint32_t nchild = 0, n_seedp = 0;
             bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort below)
+            // narrow keys: keys filed so far in each run (stays / moves by base of the sorted survivors; children of sources)
+            uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
+            const uint32_t run_bytes = max_paths << 3;
             // parent index list and record headers are fetched one / two passes ahead of their use
             uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
             uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
@@ -1056,7 +1272,51 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 else
                     for (uint32_t j = 0; j < ncand; ++j)
                         if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
-                {
+                if constexpr (NARROW) {
+                    // creation position (inside this pass) of this lane's child of each type: stay, bases 0..3
+                    const bool is_src = pi >= n_surv_par;          // children of sources: the unsorted run
+                    uint32_t cpos[5], cres[5];
+                    bool ex[5];
+                    ex[0] = stay_ok; cpos[0] = choff; cres[0] = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t jj = (uint32_t)__popc(mask & ((1u << b) - 1u));
+                        ex[b + 1] = ((mask >> b) & 1u) && ((vmask >> jj) & 1u);
+                        cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << jj) - 1u));
+                        cres[b + 1] = coff + jj;
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < 5; ++t) ex[t] = ex[t] && cpos[t] < nwrite;      // the max_paths cut-off
+                    const bool pass_has_surv = base < n_surv_par, pass_has_src = base + WAVE > n_surv_par;
+                    uint32_t kp[5] = {0, 0, 0, 0, 0};
+                    if (pass_has_surv) {
+                        // a run takes at most one child per parent: position = keys filed + fitting children of earlier lanes
+                        const uint64_t m0 = __ballot(ex[0] && !is_src), m1 = __ballot(ex[1] && !is_src), m2 = __ballot(ex[2] && !is_src),
+                                       m3 = __ballot(ex[3] && !is_src), m4 = __ballot(ex[4] && !is_src);
+                        kp[0] = scnt0 + (uint32_t)prefix_popc(m0); kp[1] = scnt1 + (uint32_t)prefix_popc(m1);
+                        kp[2] = scnt2 + (uint32_t)prefix_popc(m2); kp[3] = scnt3 + (uint32_t)prefix_popc(m3);
+                        kp[4] = scnt4 + (uint32_t)prefix_popc(m4);
+                        scnt0 += (uint32_t)__popcll(m0); scnt1 += (uint32_t)__popcll(m1); scnt2 += (uint32_t)__popcll(m2);
+                        scnt3 += (uint32_t)__popcll(m3); scnt4 += (uint32_t)__popcll(m4);
+                    }
+                    if (pass_has_src) {
+                        // the unsorted run keeps creation order
+                        const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
+                        uint32_t xtot;
+                        uint32_t xo = scntx + excl_sum_bits<3>(nfit, &xtot);
+                        if (is_src) {
+#pragma unroll
+                            for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
+                        }
+                        scntx += xtot;
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < 5; ++t)
+                        if (ex[t]) {
+                            s_cdesc[cpos[t]] = (uint32_t)lane | (t << 6) | (cres[t] << 9) | (is_src ? 1u << 18 : 0u);
+                            s_ckpos[cpos[t]] = (uint16_t)kp[t];
+                        }
+                } else {
                     uint32_t w = choff;
                     if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
                     uint32_t jj = 0;
@@ -1104,7 +1364,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     const uint32_t li = l0 + (uint32_t)lane;
                     if (li < nwrite) {
                         const uint32_t d = s_cdesc[li];
-                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = d >> 9;
+                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (d >> 9) & 511u;
                         const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
                         float4 rec = s_prec[pl];
                         const float4 sec = s_psec[pl];
@@ -1130,8 +1390,14 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                         gst(sb, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, s_pring[pl]));
                         gst(sb, co + 32u, rec);
                         gst(sb, co + 48u, sec);
-                        gst(sb, ukeys_off + (gi << 4), key);
-                        if (klb && cs == ce && (cs == kr.x || cs == kr.y)) bchild = true;
+                        if constexpr (NARROW) {
+                            const uint32_t run = (d >> 18) ? 5u : type;
+                            gst(sb, A.sc.off_streams + run * run_bytes + ((uint32_t)s_ckpos[li] << 3), key.a);
+                            gst(sb, A.sc.off_info + (gi << 3), key.b);
+                            if (cs == ce && (cs == kr.x || cs == kr.y)) bchild = true;
+                        } else {
+                            gst(sb, ukeys_off + (gi << 4), key);
+                        }
                     }
                 }
                 nchild += nwrite;
@@ -1148,13 +1414,64 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             if (n > 0) {
                 SortKey *const ukeys = reinterpret_cast<SortKey *>(sb + ukeys_off), *const skeys = reinterpret_cast<SortKey *>(sb + skeys_off);
                 uint64_t *const skeys64 = reinterpret_cast<uint64_t *>(skeys);
+                const uint64_t *const infow = reinterpret_cast<const uint64_t *>(sb + A.sc.off_info);   // narrow keys: info words by creation index
                 uint32_t kl = klb;     // key mode of THIS event
-                if (kl) {
-                    if (n <= 64) sort_regs64<1>(ukeys, skeys64, n, lane);
-                    else if (n <= 128) sort_regs64<2>(ukeys, skeys64, n, lane);
-                    else if (n <= 256) sort_regs64<4>(ukeys, skeys64, n, lane);
-                    else if (n <= 512) sort_regs64<8>(ukeys, skeys64, n, lane);
-                    else sort_hybrid64(ukeys, skeys64, n, lane);
+                if constexpr (NARROW) {
+                    const uint64_t *const info = reinterpret_cast<const uint64_t *>(sb + A.sc.off_info);
+                    const uint32_t str_off = A.sc.off_streams, sk_off = skeys_off;
+                    uint32_t nx = scntx;
+                    bool sorted_ok = false;
+                    if (n > MERGE_MIN) {
+                        // moves of one base: ascending but for the odd pair of nested parents (repair_run); then the unsorted
+                        // run is sorted, merged with the moves, and the result with the stays
+                        const uint32_t x_off = str_off + 5u * run_bytes;
+                        if constexpr (MERGE_REPAIR) {
+                        if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); scnt1 -= v; nx += v; }
+                        if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); scnt2 -= v; nx += v; }
+                        if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); scnt3 -= v; nx += v; }
+                        if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); scnt4 -= v; nx += v; }
+                        }
+                        wave_sync();
+                        SPHASE_END(8);
+                        if (nx > 1) {
+                            KeyArr<6> KX;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
+                            KX.n = nx;
+                            sort_any64(sb, KX, x_off, lane);          // in place
+                            wave_sync();
+                        }
+                        SPHASE_END(9);
+                        KeyArr<4> KM;       // the moves, base by base
+                        KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
+                        KM.n = KM.cum[3] + scnt4;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
+                        KeyArr<4> KB = KM;  // what the stays are merged with
+                        if (nx > 0) {
+                            if (KM.n > 0) {
+                                merge_runs<4, 1>(sb, KM, ka_single(x_off, nx), A.sc.off_tmp, s_e, lane, 0u);
+                                wave_sync();
+                                KB.adj[0] = A.sc.off_tmp;
+                            } else KB.adj[0] = x_off;
+                            KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
+                            KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
+                        }
+                        SPHASE_END(10);
+                        sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, s_e, lane, 1u) != 0u;
+                        wave_sync();
+                        SPHASE_END(11);
+                    }
+                    if (!sorted_ok) {
+                        // few children, or runs that were not ascending after all: the bitonic network over all of them
+                        KeyArr<6> K6;
+                        const uint32_t c[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
+                        uint32_t cum = 0;
+#pragma unroll
+                        for (uint32_t r = 0; r < 6; ++r) { K6.cum[r] = cum; K6.adj[r] = str_off + r * run_bytes - (cum << 3); cum += c[r]; }
+                        K6.n = cum;
+                        sort_any64(sb, K6, sk_off, lane);
+                    }
                     // BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can
                     // share a boundary row and two children with the SAME one-row range may carry DIFFERENT k-mers.  The
                     // reference then walks them in seed_prob order (mapper.cpp:543-563 runs per position), which the narrow
@@ -1166,14 +1483,16 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                             const uint32_t i = base + (uint32_t)lane;
                             if (i + 1 < n) {
                                 const uint64_t ki = skeys64[i], kn = skeys64[i + 1];
-                                if ((ki >> 16) == (kn >> 16) &&
-                                    ((ukeys[ki & 0xFFFFu].b ^ ukeys[kn & 0xFFFFu].b) & META_KMER_MASK)) mixed = true;
+                                if ((ki >> 16) == (kn >> 16) && ((info[ki & 0xFFFFu] ^ info[kn & 0xFFFFu]) & META_KMER_MASK)) mixed = true;
                             }
                         }
                         if (__any(mixed)) {
                             for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
-                                const uint64_t ri = ukeys[i].a >> 16;
-                                ukeys[i].a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
+                                const uint64_t k = skeys64[i], ri = k >> 16;
+                                SortKey w;
+                                w.a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
+                                w.b = info[k & 0xFFFFu];
+                                ukeys[i] = w;
                             }
                             kl = 0;
                             wave_sync();
@@ -1200,8 +1519,8 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                 if (kl) {
                     if ((uint32_t)lane < n) kq0 = skeys64[lane];
                     if ((uint32_t)lane + WAVE < n) kq1 = skeys64[lane + WAVE];
-                    if ((uint32_t)lane < n) bq0 = ukeys[kq0 & 0xFFFFu].b;
-                    if ((uint32_t)lane + WAVE < n) bq1 = ukeys[kq1 & 0xFFFFu].b;
+                    if ((uint32_t)lane < n) bq0 = infow[kq0 & 0xFFFFu];
+                    if ((uint32_t)lane + WAVE < n) bq1 = infow[kq1 & 0xFFFFu];
                 }
                 // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
                 ulonglong2 krq = make_ulonglong2(1ull, 0ull);
@@ -1315,7 +1634,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
                     carry_U = bcast64(U, (int)nv - 1);
                     n_src += stot;
                     if (n_src > room) n_src = room;
-                    if (kl) bq1 = i + 2 * WAVE < n ? ukeys[kq1 & 0xFFFFu].b : 0ull;
+                    if (kl) bq1 = i + 2 * WAVE < n ? infow[kq1 & 0xFFFFu] : 0ull;
                 }
                 if (n_seedp > A.sc.max_seed_paths) { tstatus |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
             }
@@ -1356,6 +1675,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             const uint32_t nsrc_total = ent - n;
             for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) gst(sb, nord_off + ((n_surv + q) << 2), n + q);
             n_parents = n_surv + nsrc_total;
+            n_surv_par = n_surv;
             cur ^= 1u;
             wave_sync();
 
@@ -1505,6 +1825,7 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         if (A.resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
+                st->n_surv = n_surv_par;
                 st->status = T.status; st->n_clusters = T.n; st->n_lens = T.n_lens;
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
@@ -1540,8 +1861,11 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
     a.pool = pool;
-    if (profile) hipLaunchKernelGGL(UNC_KMAP<true>, dim3(grid), dim3(WAVE), 0, st, a);
-    else hipLaunchKernelGGL(UNC_KMAP<false>, dim3(grid), dim3(WAVE), 0, st, a);
+    const bool narrow = ix.key_len_bits != 0;
+    if (profile && narrow) hipLaunchKernelGGL((UNC_KMAP<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (profile) hipLaunchKernelGGL((UNC_KMAP<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((UNC_KMAP<false, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL((UNC_KMAP<false, false>), dim3(grid), dim3(WAVE), 0, st, a);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {

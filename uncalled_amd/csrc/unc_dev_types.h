@@ -83,7 +83,8 @@ struct alignas(16) SlotState {
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
     uint32_t n_clusters, n_lens, len_max1, len_max2, n_leaves, n_alloc;   // n_alloc: leaves taken from the read's own chunks so far
-    uint32_t pad_[2];
+    uint32_t n_surv;         // the first n_surv parents are the last walk's survivors, in sorted order (sources follow)
+    uint32_t pad_[1];
     float len_sum;
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
@@ -148,7 +149,10 @@ struct DevScratch {
     uint32_t off_cl_dir;   // DirEnt  [max_clusters / 16]: sorted directory of the read's leaves (first key + pool index)
     uint32_t off_cl_chunks;  // u32   [max_clusters / 16 / 64 + 1]: the pool chunks this read holds
     uint32_t off_state;    // SlotState
-    uint32_t pad_;
+    // narrow sort keys (DevIndex::key_len_bits > 0): the children's 64-bit keys leave phase E as sorted streams
+    uint32_t off_streams;  // u64     [6][max_paths]: stays, moves by base 0..3 (children of the sorted survivors), the rest
+    uint32_t off_info;     // u64     [max_paths]: a child's info word (SortKey::b) by creation index
+    uint32_t off_tmp;      // u64     [max_paths]: intermediate run of the merge
 };
 
 // ---- chunked (realtime) path: state a Mapper keeps per channel between chunks (mapper.hpp:209-226) ----

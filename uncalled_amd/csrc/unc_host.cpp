@@ -460,10 +460,14 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     const uint64_t o_cld = region(leaves * sizeof(DirEnt));
     const uint64_t o_clc = region((leaves / CHUNK_LEAVES + 1) * 4);
     const uint64_t o_state = region(sizeof(SlotState));
+    const uint64_t o_streams = region(6ull * sc.max_paths * 8);
+    const uint64_t o_info = region((uint64_t)sc.max_paths * 8);
+    const uint64_t o_tmp = region((uint64_t)sc.max_paths * 8);
     if (off >= (1ull << 32)) return fail(UNC_ERR_ARG, "per-read scratch of %llu bytes does not fit 32-bit offsets (max_clusters %u)", (unsigned long long)off, max_clusters);
     sc.off_paths = (uint32_t)o_paths; sc.off_rings = (uint32_t)o_rings; sc.off_order = (uint32_t)o_order; sc.off_keys = (uint32_t)o_keys;
     sc.off_seedp = (uint32_t)o_seedp; sc.off_tasks = (uint32_t)o_tasks; sc.off_cl_dir = (uint32_t)o_cld; sc.off_cl_chunks = (uint32_t)o_clc;
     sc.off_state = (uint32_t)o_state;
+    sc.off_streams = (uint32_t)o_streams; sc.off_info = (uint32_t)o_info; sc.off_tmp = (uint32_t)o_tmp;
     sc.slot_bytes = off;
     return UNC_OK;
 }
