@@ -33,6 +33,8 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
+#define UNC_AS_GLOBAL          /* address-space markers of the kernel sources (wave_prims.h): one flat memory here */
+#define UNC_AS_CONST
 
 struct dim3 {
     unsigned x, y, z;
@@ -68,6 +70,8 @@ extern thread_local Block *g_blk;
 extern "C" void lanesim_switch(void **save_sp, void *load_sp);
 void yield_lane();
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
+extern thread_local const void *g_kernarg;   // address of the running kernel's first argument (its argument block)
+template <class T, class... R> static inline void set_kernarg(const T &first, const R &...) { g_kernarg = &first; }
 
 // Wave-scope rendezvous: deposit `v`, wait until every live lane of this wave has deposited the
 // same generation, return the table of that generation (valid until the caller's next rendezvous).
@@ -217,6 +221,9 @@ template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 0
+template <class T> static inline T __lanesim_fetch_or(T *p, T v) { T o = *p; *p = o | v; return o; }
+#define __hip_atomic_fetch_or(p, v, order, scope) __lanesim_fetch_or((p), (v))
 template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
@@ -279,4 +286,5 @@ constexpr int hipMemoryTypeHost = 0, hipMemoryTypeDevice = 1;
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeDevice; return 0; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    lanesim::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
+    (lanesim::set_kernarg(__VA_ARGS__), lanesim::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); }))
+static inline const void *__builtin_amdgcn_kernarg_segment_ptr() { return lanesim::g_kernarg; }

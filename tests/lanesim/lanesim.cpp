@@ -4,6 +4,7 @@
 namespace lanesim {
 
 thread_local Block *g_blk = nullptr;
+thread_local const void *g_kernarg = nullptr;
 
 // void lanesim_switch(void **save_sp, void *load_sp): save callee-saved regs on the current
 // stack, publish the stack pointer, adopt the other stack, restore its registers, return into it.

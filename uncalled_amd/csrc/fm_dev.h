@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "unc_dev_types.h"
+#include "wave_prims.h"
 
 namespace unc {
 
@@ -15,12 +16,25 @@ __device__ __forceinline__ uint32_t occ32(uint64_t y, uint32_t c) {
     return (uint32_t)__popcll((hi >> 1) & lo & 0x5555555555555555ull);
 }
 
+
+// 16 / 8 bytes at a pointer of any address space (one dwordx4 / dwordx2 load)
+template <class P> __device__ __forceinline__ uint4 ld16(P p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+template <class P> __device__ __forceinline__ uint64_t ld8(P p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
 struct FmBlock { uint4 q0, q1, q2, q3; };  // counts A,C | counts G,T | symbols 0..63 | symbols 64..127
 
-__device__ __forceinline__ FmBlock fm_load_block(const DevIndex &ix, uint64_t kk) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(ix.bwt + ((kk >> 7) << 4));
+template <class IX> __device__ __forceinline__ FmBlock fm_load_block(const IX &ix, uint64_t kk) {
+    const auto p = ix.bwt + ((kk >> 7) << 4);
     FmBlock b;
-    b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3];
+    b.q0 = ld16(p); b.q1 = ld16(p + 4); b.q2 = ld16(p + 8); b.q3 = ld16(p + 12);
     return b;
 }
 
@@ -47,7 +61,7 @@ __device__ __forceinline__ uint32_t fm_block_rank(const FmBlock &b, uint64_t kk,
 }
 
 // bwt_occ: occurrences of c in BWT rows [0..k] of the matrix that includes the sentinel row
-__device__ __forceinline__ uint64_t fm_occ(const DevIndex &ix, uint64_t k, uint32_t c) {
+template <class IX> __device__ __forceinline__ uint64_t fm_occ(const IX &ix, uint64_t k, uint32_t c) {
     if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
     if (k == ~0ull) return 0;
     uint64_t kk = k - (k >= ix.primary ? 1 : 0);
@@ -61,13 +75,13 @@ __device__ __forceinline__ uint64_t fm_occ(const DevIndex &ix, uint64_t k, uint3
 // upper half of the block.
 struct FmPart { uint64_t cnt; uint4 lo, hi; };
 
-__device__ __forceinline__ FmPart fm_load_part(const DevIndex &ix, uint64_t kk, uint32_t c) {
-    const uint32_t *p = ix.bwt + ((kk >> 7) << 4);
+template <class IX> __device__ __forceinline__ FmPart fm_load_part(const IX &ix, uint64_t kk, uint32_t c) {
+    const auto p = ix.bwt + ((kk >> 7) << 4);
     FmPart b;
-    b.cnt = *reinterpret_cast<const uint64_t *>(p + 2 * c);
-    b.lo = reinterpret_cast<const uint4 *>(p)[2];
+    b.cnt = ld8(p + 2 * c);
+    b.lo = ld16(p + 8);
     b.hi = make_uint4(0u, 0u, 0u, 0u);
-    if (kk & 64) b.hi = reinterpret_cast<const uint4 *>(p)[3];
+    if (kk & 64) b.hi = ld16(p + 12);
     return b;
 }
 
@@ -104,7 +118,7 @@ struct FmNbr {
     uint32_t c;
     bool k_plain, l_plain, shared;
 };
-__device__ __forceinline__ FmNbr fm_nbr_issue(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c) {
+template <class IX> __device__ __forceinline__ FmNbr fm_nbr_issue(const IX &ix, uint64_t s, uint64_t e, uint32_t c) {
     FmNbr q;
     const uint64_t k = s - 1, l = e;
     q.c = c;
@@ -118,7 +132,7 @@ __device__ __forceinline__ FmNbr fm_nbr_issue(const DevIndex &ix, uint64_t s, ui
     if (q.k_plain && !q.shared) q.bk = fm_load_part(ix, q.kk, c);
     return q;
 }
-__device__ __forceinline__ void fm_nbr_finish(const DevIndex &ix, const FmNbr &q, uint64_t *os, uint64_t *oe) {
+template <class IX> __device__ __forceinline__ void fm_nbr_finish(const IX &ix, const FmNbr &q, uint64_t *os, uint64_t *oe) {
     uint64_t ok = q.ok, ol = q.ol;
     if (q.l_plain) ol = fm_part_rank(q.bl, q.ll, q.c);
     if (q.k_plain) {
@@ -131,14 +145,47 @@ __device__ __forceinline__ void fm_nbr_finish(const DevIndex &ix, const FmNbr &q
     *os = ix.L2[q.c] + ok + 1;
     *oe = ix.L2[q.c] + ol;
 }
-__device__ __forceinline__ void fm_get_neighbor(const DevIndex &ix, uint64_t s, uint64_t e, uint32_t c,
+template <class IX> __device__ __forceinline__ void fm_get_neighbor(const IX &ix, uint64_t s, uint64_t e, uint32_t c,
                                                 uint64_t *os, uint64_t *oe) {
     const FmNbr q = fm_nbr_issue(ix, s, e, c);
     fm_nbr_finish(ix, q, os, oe);
 }
 
+
+// ---- The rank table k_map works on when the reference has fewer than 2^32 rows (DevIndex::fm32; built from the BWA blocks
+// at index load, k_taps.hip): one 32-byte block per 64 BWT symbols =
+//   4 x u32   L2[c] + occurrences of c before the block  (so a rank needs neither the L2 table nor 64-bit arithmetic)
+//   4 x u32   the 64 symbols as two bit planes: hi.lo, hi.hi, lo.lo, lo.hi (bit j = high / low bit of symbol 64 b + j)
+// A rank is the count word of its base (one 4-byte load), one 16-byte load, two XORs per plane word and two popcounts.
+// Same function as bwt_2occ behind BwaIndex::get_neighbor (bwa_index.hpp:158-162); the row k = seq_len needs no special
+// case here (it is the last symbol's block), the row k = -1 cannot occur (path ranges start at row 1 or later).
+__device__ __forceinline__ uint32_t fm32_rank(uint32_t cnt, const uint4 &pl, uint32_t xh, uint32_t xl, uint32_t kk) {
+    const uint32_t r = kk & 63u;
+    const uint64_t mask = (2ull << r) - 1ull;                       // symbols 0 .. r of the block (r = 63: all)
+    const uint32_t m_lo = (pl.x ^ xh) & (pl.z ^ xl) & (uint32_t)mask;
+    const uint32_t m_hi = (pl.y ^ xh) & (pl.w ^ xl) & (uint32_t)(mask >> 32);
+    return cnt + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+}
+// one backward-search step of the rows [s, e] with base c: *os > *oe when no row is left
+template <class IX> __device__ __forceinline__ void fm32_get_neighbor(const IX &ix, uint32_t s, uint32_t e, uint32_t c, uint32_t *os, uint32_t *oe) {
+    const uint32_t primary = (uint32_t)ix.primary;
+    const uint32_t k = s - 1u, l = e;
+    const uint32_t kk = k - (k >= primary ? 1u : 0u), ll = l - (l >= primary ? 1u : 0u);
+    const uint32_t bk = kk >> 6, bl = ll >> 6;
+    const auto w = ix.fm32;
+    // both blocks are requested before either rank is computed; nearly always they are one and the same
+    const uint32_t cl = w[(bl << 3) + c];
+    const uint4 pl = ld16(w + (bl << 3) + 4u);
+    uint32_t ck = cl;
+    uint4 pk = pl;
+    if (bk != bl) { ck = w[(bk << 3) + c]; pk = ld16(w + (bk << 3) + 4u); }
+    const uint32_t xh = (c & 2u) ? 0u : ~0u, xl = (c & 1u) ? 0u : ~0u;     // plane word ^ x: bit set where the symbol's bit equals c's
+    *os = fm32_rank(ck, pk, xh, xl, kk) + 1u;
+    *oe = fm32_rank(cl, pl, xh, xl, ll);
+}
+
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps
-__device__ __forceinline__ uint64_t fm_sa(const DevIndex &ix, uint64_t k, uint32_t *steps) {
+template <class IX> __device__ __forceinline__ uint64_t fm_sa(const IX &ix, uint64_t k, uint32_t *steps) {
     uint32_t n = 0;
     while (k & 31) {
         ++n;
@@ -158,7 +205,7 @@ __device__ __forceinline__ uint64_t fm_sa(const DevIndex &ix, uint64_t k, uint32
 // SA look-up through the dense table built at index load (k_dense_sa): entry = SA value (40 bits) | LF steps the
 // BWA-format walk above would have taken << 40 (kept so that the SURVEY 8(d) work counters stay those of
 // the reference's algorithm).  One 8-byte read instead of ~31 dependent 64-byte reads.
-__device__ __forceinline__ uint64_t fm_sa_dense(const DevIndex &ix, uint64_t k, uint32_t *steps) {
+template <class IX> __device__ __forceinline__ uint64_t fm_sa_dense(const IX &ix, uint64_t k, uint32_t *steps) {
     const uint64_t v = ix.sa_dense[k];
     *steps = (uint32_t)(v >> 40);
     return v & ((1ull << 40) - 1ull);

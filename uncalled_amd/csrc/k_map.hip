@@ -22,19 +22,29 @@
 // operation at a time (compile with -ffp-contract=off; the reference is built without FMA).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fm_dev.h"
 #include "unc_dev_types.h"
 #include "wave_prims.h"
 
-#define UNC_KMAP k_map
-#define UNC_MAPARGS MapArgs
 
 namespace unc {
 
+
+// ---- LDS of a wavefront (a workgroup is one wavefront): file scope, so that the phases of an event, which are separate
+// functions, all see it as LDS ----
 constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
 constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
+__shared__ __attribute__((aligned(16))) float s_probs[NKMER];      // match log-probs of the current event
+__shared__ uint32_t s_flags[NKMER / 32];                            // sources_added_
+// one carved buffer for the per-pass staging of phase E (7.5 KB), reused as the merge tile of the sort, the source list of
+// phase F and the sampled directory of add_seed: with the probs table the wavefront stays under 13 KB of LDS (12 per CU)
+constexpr uint32_t S_E_WORDS = CAND_MAX + 2 * WAVE + 4 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4;
+__shared__ __attribute__((aligned(16))) uint64_t s_e[S_E_WORDS];
+__shared__ uint16_t s_ckpos[CHILD_MAX];                             // narrow keys: a child's position in its run
 
-struct UNC_MAPARGS {
+struct MapArgs {
     DevIndex ix;
     DevScratch sc;
     DevReads rd;
@@ -91,18 +101,25 @@ struct Tracker {
 // split; nothing is ever O(#clusters) but the directory shift of a split (256 entries per memory round trip).
 constexpr uint32_t LEAF = LEAF_KEYS;
 constexpr uint32_t LEAF_NONE = 0xFFFFFFFFu;
+struct PoolView {          // DevPool with its arrays typed as global memory
+    gptr_t leaves;
+    UNC_AS_GLOBAL uint32_t *cnt;
+    SchedQueue *q;
+    SchedCell *cells;
+    uint32_t cap_mask;
+};
 struct TrackerMem {
-    char *sb;              // the read's slot: directory and chunk list live there
+    gptr_t sb;             // the read's slot: directory and chunk list live there
     uint32_t off_dir;      // DirEnt [max_leaves]
     uint32_t off_chunks;   // u32 [max_leaves / 64 + 1]
     uint32_t max_leaves;
-    DevPool pool;          // leaves
+    PoolView pool;         // leaves
 };
-__device__ __forceinline__ char *tm_leaf_ptr(const TrackerMem &M, uint32_t leaf) { return M.pool.leaves + (size_t)leaf * LEAF_BYTES; }
-__device__ __forceinline__ ClusterKey lf_hot(const char *lp, uint32_t slot) { return gld<ClusterKey>(lp, slot << 4); }
-__device__ __forceinline__ ClusterCold lf_cold(const char *lp, uint32_t slot) { return gld<ClusterCold>(lp, LEAF_COLD_OFF + (slot << 5)); }
-__device__ __forceinline__ void lf_hot_st(char *lp, uint32_t slot, const ClusterKey &k) { gst(lp, slot << 4, k); }
-__device__ __forceinline__ void lf_cold_st(char *lp, uint32_t slot, const ClusterCold &c) { gst(lp, LEAF_COLD_OFF + (slot << 5), c); }
+__device__ __forceinline__ gptr_t tm_leaf_ptr(const TrackerMem &M, uint32_t leaf) { return M.pool.leaves + (size_t)leaf * LEAF_BYTES; }
+__device__ __forceinline__ ClusterKey lf_hot(cgptr_t lp, uint32_t slot) { return gld<ClusterKey>(lp, slot << 4); }
+__device__ __forceinline__ ClusterCold lf_cold(cgptr_t lp, uint32_t slot) { return gld<ClusterCold>(lp, LEAF_COLD_OFF + (slot << 5)); }
+__device__ __forceinline__ void lf_hot_st(gptr_t lp, uint32_t slot, const ClusterKey &k) { gst(lp, slot << 4, k); }
+__device__ __forceinline__ void lf_cold_st(gptr_t lp, uint32_t slot, const ClusterCold &c) { gst(lp, LEAF_COLD_OFF + (slot << 5), c); }
 __device__ __forceinline__ DirEnt tm_dir(const TrackerMem &M, uint32_t i) { return gld<DirEnt>(M.sb, M.off_dir + (i << 4)); }
 __device__ __forceinline__ void tm_dir_st(const TrackerMem &M, uint32_t i, const DirEnt &k) { gst(M.sb, M.off_dir + (i << 4), k); }
 __device__ __forceinline__ void tm_dir_first(const TrackerMem &M, uint32_t i, const ClusterKey &k, uint32_t leaf) {
@@ -206,7 +223,7 @@ __device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, 
 __device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane,
                                               uint32_t &top_n) {
     if (c == 1 || slot == 0) top_n = 0;      // the directory changes: its LDS sample is stale
-    char *lp = tm_leaf_ptr(M, id);
+    const gptr_t lp = tm_leaf_ptr(M, id);
     ClusterKey k;
     ClusterCold cc;
     const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
@@ -235,7 +252,7 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
         const uint32_t id = tracker_new_leaf(T, M, lane);
         if (id == LEAF_NONE) return false;
         if (lane == 0) {
-            char *lp = tm_leaf_ptr(M, id);
+            const gptr_t lp = tm_leaf_ptr(M, id);
             lf_hot_st(lp, 0, nk); lf_cold_st(lp, 0, nc);
             tm_cnt_st(M, id, 1);
             tm_dir_first(M, 0, nk, id);
@@ -250,7 +267,7 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
         // split: the upper half moves to a fresh leaf that follows this one in the directory
         const uint32_t nid = tracker_new_leaf(T, M, lane);
         if (nid == LEAF_NONE) return false;
-        char *src = tm_leaf_ptr(M, id), *dst = tm_leaf_ptr(M, nid);
+        const gptr_t src = tm_leaf_ptr(M, id), dst = tm_leaf_ptr(M, nid);
         if (lane >= (int)(LEAF / 2)) { lf_hot_st(dst, lane - LEAF / 2, lf_hot(src, lane)); lf_cold_st(dst, lane - LEAF / 2, lf_cold(src, lane)); }
         wave_sync();
         dir_shift_up(M, L + 1, T.n_leaves, lane);
@@ -263,7 +280,7 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
         if (slot > LEAF / 2) { L = L + 1; slot -= LEAF / 2; id = nid; }
         c = LEAF / 2;
     }
-    char *lp = tm_leaf_ptr(M, id);
+    const gptr_t lp = tm_leaf_ptr(M, id);
     ClusterKey k;
     ClusterCold cc;
     const bool mv = (uint32_t)lane >= slot && (uint32_t)lane < c;
@@ -284,7 +301,7 @@ __device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, 
 __device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, const ClusterKey &k,
                                                     const ClusterCold &cc, const ClusterKey &nk, const ClusterCold &nc, int lane, uint32_t &top_n) {
     if (slot == 0) top_n = 0;
-    char *lp = tm_leaf_ptr(M, id);
+    const gptr_t lp = tm_leaf_ptr(M, id);
     if ((uint32_t)lane >= slot && (uint32_t)lane < c) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
     if (lane == 0) {
         lf_hot_st(lp, slot, nk); lf_cold_st(lp, slot, nc);
@@ -302,7 +319,8 @@ constexpr uint32_t TOP_MIN = UNC_TOP_MIN;
 // s_top / top_n: 64 evenly spaced directory entries kept in LDS (valid for a directory of top_n leaves, 0 = stale): the
 // first level of the search costs no memory round trip on the large sets of a human-sized reference.
 static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
-                                int lane, DirEnt *s_top, uint32_t &top_n) {
+                                int lane, uint32_t &top_n) {
+    DirEnt *const s_top = reinterpret_cast<DirEnt *>(s_e);      // the staging buffer of phase E is idle while seeds are added
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
     const uint32_t e2 = evt;
@@ -354,7 +372,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
     ClusterCold lc; lc.ref_st = 0; lc.rend = 0; lc.evt_st = 0; lc.pad[0] = lc.pad[1] = lc.pad[2] = 0;
     if (d > 0) {
         id0 = d - 1 >= lo ? bcast32(dk.leaf, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).leaf);   // window starts after it
-        const char *lp0 = tm_leaf_ptr(M, id0);
+        const cgptr_t lp0 = tm_leaf_ptr(M, id0);
         lk = lf_hot(lp0, lane);           // slots past the count hold stale keys: masked by c0
         lc = lf_cold(lp0, lane);
         c0 = tm_cnt(M, id0);
@@ -416,7 +434,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
     }
 
     if (mL != 0xFFFFFFFFu) {
-        char *mlp = tm_leaf_ptr(M, m_id);
+        const gptr_t mlp = tm_leaf_ptr(M, m_id);
         const ClusterCold mp = lf_cold(mlp, mS);
         ClusterVal a;
         a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
@@ -530,26 +548,29 @@ __device__ __forceinline__ void merge_stages(uint64_t (&a)[E], uint64_t (&b)[E],
 }
 
 template <int E>
-__device__ __forceinline__ void block_load(uint64_t (&a)[E], uint64_t (&b)[E], const SortKey *in, uint32_t base, uint32_t n, int lane) {
+__device__ __forceinline__ void block_load(uint64_t (&a)[E], uint64_t (&b)[E], const UNC_AS_GLOBAL SortKey *in, uint32_t base, uint32_t n, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) { SortKey k = in[i]; a[e] = k.a; b[e] = k.b; }
+        if (i < n) { const SortKey k = g_load(in + i); a[e] = k.a; b[e] = k.b; }
         else { a[e] = ~0ull; b[e] = ~0ull; }
     }
 }
 template <int E>
-__device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64_t (&b)[E], SortKey *out, uint32_t base, uint32_t lim, int lane) {
+__device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64_t (&b)[E], UNC_AS_GLOBAL SortKey *out, uint32_t base, uint32_t lim, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-        if (i < lim) { SortKey k; k.a = a[e]; k.b = b[e]; out[i] = k; }
+        if (i < lim) { SortKey k; k.a = a[e]; k.b = b[e]; g_store(out + i, k); }
     }
 }
 
 // n <= 64*E: the whole sort in registers
 template <int E>
-static __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+static __device__ __noinline__ void sort_regs(const UNC_AS_GLOBAL SortKey *in_, UNC_AS_GLOBAL SortKey *out_, uint32_t n_, int lane) {
+    const UNC_AS_GLOBAL SortKey *const in = uniform_ptr(in_);
+    UNC_AS_GLOBAL SortKey *const out = uniform_ptr(out_);
+    const uint32_t n = uniform32(n_);
     uint64_t a[E], b[E];
     block_load<E>(a, b, in, 0, n, lane);
     for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages<E>(a, b, 0, k, k >> 1, lane);
@@ -558,7 +579,10 @@ static __device__ void sort_regs(const SortKey *in, SortKey *out, uint32_t n, in
 
 constexpr int GS_BATCH = 4;     // passes of a global sort stage whose loads are issued together (N / 2 / 64 >= 8 passes)
 // n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
-static __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, int lane) {
+static __device__ __noinline__ void sort_hybrid(const UNC_AS_GLOBAL SortKey *in_, UNC_AS_GLOBAL SortKey *out_, uint32_t n_, int lane) {
+    const UNC_AS_GLOBAL SortKey *const in = uniform_ptr(in_);
+    UNC_AS_GLOBAL SortKey *const out = uniform_ptr(out_);
+    const uint32_t n = uniform32(n_);
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -581,13 +605,13 @@ static __device__ void sort_hybrid(const SortKey *in, SortKey *out, uint32_t n, 
                 for (int u = 0; u < GS_BATCH; ++u) {
                     const uint32_t t = t0 + 64u * u + (uint32_t)lane;
                     ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    x[u] = out[ii[u]]; y[u] = out[ii[u] | j];
+                    x[u] = g_load(out + ii[u]); y[u] = g_load(out + (ii[u] | j));
                 }
 #pragma unroll
                 for (int u = 0; u < GS_BATCH; ++u) {
                     const bool up = (ii[u] & k) == 0;
                     const bool gt = key_gt(x[u].a, x[u].b, y[u].a, y[u].b);
-                    if (up ? gt : !gt) { out[ii[u]] = y[u]; out[ii[u] | j] = x[u]; }
+                    if (up ? gt : !gt) { g_store(out + ii[u], y[u]); g_store(out + (ii[u] | j), x[u]); }
                 }
             }
             wave_sync();
@@ -683,7 +707,7 @@ template <int R> struct KeyArr {
     uint32_t cum[R];    // first index of run r (cum[0] = 0)
     uint32_t n;
 };
-template <int R> __device__ __forceinline__ uint64_t ka_load(const char *sb, const KeyArr<R> &K, uint32_t i) {
+template <int R> __device__ __forceinline__ uint64_t ka_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
     uint32_t a = K.adj[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
@@ -700,7 +724,9 @@ __device__ __forceinline__ KeyArr<1> ka_single(uint32_t off, uint32_t n) { KeyAr
 
 // n <= 64 * E keys of K -> out (byte offset in the slot), sorted
 template <int E>
-static __device__ __noinline__ void sort_regs64(char *sb, KeyArr<6> K_, uint32_t out_off, int lane) {
+static __device__ __noinline__ void sort_regs64(gptr_t sb_, KeyArr<6> K_, uint32_t out_off_, int lane) {
+    const gptr_t sb = uniform_ptr(sb_);
+    const uint32_t out_off = uniform32(out_off_);
     const KeyArr<6> K = ka_uniform(K_);
     const uint32_t n = K.n;
     uint64_t a[E];
@@ -718,10 +744,11 @@ static __device__ __noinline__ void sort_regs64(char *sb, KeyArr<6> K_, uint32_t
     }
 }
 
-static __device__ __noinline__ void sort_hybrid64(char *sb, KeyArr<6> K_, uint32_t out_off, int lane) {
+static __device__ __noinline__ void sort_hybrid64(gptr_t sb_, KeyArr<6> K_, uint32_t out_off, int lane) {
+    const gptr_t sb = uniform_ptr(sb_);
     const KeyArr<6> K = ka_uniform(K_);
     const uint32_t n = K.n;
-    uint64_t *const out = reinterpret_cast<uint64_t *>(sb + uniform32(out_off));
+    UNC_AS_GLOBAL uint64_t *const out = reinterpret_cast<UNC_AS_GLOBAL uint64_t *>(sb + uniform32(out_off));
     constexpr int E = 8;
     constexpr uint32_t B = 64u * E;
     uint32_t N = 2 * B;
@@ -799,7 +826,7 @@ static __device__ __noinline__ void sort_hybrid64(char *sb, KeyArr<6> K_, uint32
 }
 
 // any number of keys, by size class
-static __device__ __noinline__ void sort_any64(char *sb, KeyArr<6> K, uint32_t out_off, int lane) {
+static __device__ __noinline__ void sort_any64(gptr_t sb, KeyArr<6> K, uint32_t out_off, int lane) {
     const uint32_t n = uniform32(K.n);
     if (n <= 64) sort_regs64<1>(sb, K, out_off, lane);
     else if (n <= 128) sort_regs64<2>(sb, K, out_off, lane);
@@ -813,10 +840,7 @@ static __device__ __noinline__ void sort_any64(char *sb, KeyArr<6> K, uint32_t o
 // them sequentially.  Work per key: one LDS read and a dozen lane instructions, against ~60 compare-exchanges of the
 // bitonic network -- provided the inputs ARE ascending.  The caller checks the result (`verify`) and sorts the keys the
 // hard way if it is not (an event where the runs of phase E were not ascending after all).
-#ifndef UNC_V_MERGEMIN
-#define UNC_V_MERGEMIN 256
-#endif
-constexpr uint32_t MERGE_MIN = UNC_V_MERGEMIN;     // fewer children than this go straight through the bitonic network
+constexpr uint32_t MERGE_MIN = 256;     // fewer children than this go straight through the bitonic network
 #ifndef UNC_MERGE_REPAIR
 #define UNC_MERGE_REPAIR 1              // (tests build the emulator library with 0: the runs then reach the merge unrepaired, its check
 #endif                                  //  must notice and the event must take the bitonic network instead, with the same result)
@@ -831,7 +855,7 @@ constexpr uint32_t MERGE_LDS_KEYS = MERGE_TILE + MERGE_TILE / 8 + 1;
 // how many of the first d keys of merge(A, B) come from A (keys distinct): the first mid with !(A[mid] < B[d - 1 - mid]),
 // 64 probes per memory round trip
 template <int RA, int RB>
-__device__ __forceinline__ uint32_t merge_split(const char *sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
+__device__ __forceinline__ uint32_t merge_split(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
     uint32_t lo = d > B.n ? d - B.n : 0u, hi = d < A.n ? d : A.n;
     while (lo < hi) {
         const uint32_t span = hi - lo, step = (span + 63u) / 64u;
@@ -847,8 +871,9 @@ __device__ __forceinline__ uint32_t merge_split(const char *sb, const KeyArr<RA>
 }
 
 template <int RA, int RB>
-static __device__ __noinline__ uint32_t merge_runs(char *sb, KeyArr<RA> A_, KeyArr<RB> B_, uint32_t out_off_, uint64_t *s_tile, int lane,
-                                                   uint32_t verify_) {
+static __device__ __noinline__ uint32_t merge_runs(gptr_t sb_, KeyArr<RA> A_, KeyArr<RB> B_, uint32_t out_off_, int lane, uint32_t verify_) {
+    const gptr_t sb = uniform_ptr(sb_);
+    uint64_t *const s_tile = s_e;
     const KeyArr<RA> A = ka_uniform(A_);
     const KeyArr<RB> B = ka_uniform(B_);
     const uint32_t out_off = uniform32(out_off_), verify = uniform32(verify_);
@@ -902,9 +927,18 @@ static __device__ __noinline__ uint32_t merge_runs(char *sb, KeyArr<RA> A_, KeyA
             if (ok && c + 1u < cnt) x = s_tile[mslot(idx)];
             if (ta) va = x; else vb = x;
         }
+        // out through the tile buffer, so that each store instruction writes 512 consecutive bytes: a lane storing its own twelve
+        // keys (lanes 96 bytes apart) costs the CU's memory pipeline ten times as much (tools/dev/ubench_vmem.hip)
+        wave_sync();
 #pragma unroll
         for (uint32_t c = 0; c < MERGE_C; ++c)
-            if (c < cnt) gst(sb, out_off + ((o0 + d + c) << 3), o[c]);
+            if (c < cnt) s_tile[mslot(d + c)] = o[c];
+        wave_sync();
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c) {
+            const uint32_t i = (uint32_t)lane + c * WAVE;
+            if (i < tn) gst(sb, out_off + ((o0 + i) << 3), s_tile[mslot(i)]);
+        }
         if (verify) {
             uint64_t last = o[0];
             bool w = false;
@@ -928,7 +962,8 @@ static __device__ __noinline__ uint32_t merge_runs(char *sb, KeyArr<RA> A_, KeyA
 // when their parents were nested ranges (the outer parent comes first and its child can be the longer range).  A key that
 // is smaller than one before it is moved to the unsorted run: what is left is ascending.  Nearly every 64-key chunk has
 // no such key (one compare with the neighbour lane says so); a chunk that has one takes the exact running maximum.
-static __device__ __noinline__ uint32_t repair_run(char *sb, uint32_t run_off_, uint32_t n_, uint32_t x_off_, uint32_t nx_, int lane) {
+static __device__ __noinline__ uint32_t repair_run(gptr_t sb_, uint32_t run_off_, uint32_t n_, uint32_t x_off_, uint32_t nx_, int lane) {
+    const gptr_t sb = uniform_ptr(sb_);
     const uint32_t run_off = uniform32(run_off_), n = uniform32(n_), x_off = uniform32(x_off_);
     uint32_t nx = uniform32(nx_), shift = 0;
     uint64_t carry = 0;              // the largest key so far (keys are > 0)
@@ -973,11 +1008,12 @@ __device__ __forceinline__ uint32_t float_orderable(float f) {
 }
 
 // PathBuffer::make_child, mapper.cpp:775-807.  The prob sums are not copied (see PathRec): a child needs its parent's
-// newest sum `last` = prob_sums_[length_] and, once the window is full, `second` = prob_sums_[1].
-struct ChildHdr { uint32_t moves, meta; float seed_prob, appended; };
-__device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, float last, float second, uint64_t s, uint64_t e,
-                                               uint32_t kmer, float prob, uint32_t move, const unc_params_t &P,
-                                               uint32_t child_idx, uint32_t key_len_bits, SortKey &key) {
+// newest sum `last` = prob_sums_[length_] and, once the window is full, `subc` = the parent's prob_sums_[1], which the
+// parent lane has already worked out for all of its children together with the slid k-mer history `hist`.
+struct ChildHdr { uint32_t moves, meta; float seed_prob, last; uint64_t hist; };
+__device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, float last, float subc, uint64_t hist, uint64_t s, uint64_t e,
+                                               uint32_t kmer, float prob, uint32_t move, uint32_t p_seed_len, float p_min_seed_prob,
+                                               float p_max_stay, uint32_t child_idx, uint32_t key_len_bits, SortKey &key) {
     const uint32_t PATH_MASK = (1u << SEED_LEN) - 1u, PATH_TAIL_MOVE = 1u << (SEED_LEN - 1);
     const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u, pstay = (pmeta >> META_STAY_SHIFT) & 255u;
     const uint32_t stay = 1u - move;
@@ -986,76 +1022,817 @@ __device__ __forceinline__ ChildHdr make_child(uint32_t pmoves, uint32_t pmeta, 
     uint32_t moves = ((pmoves << 1) | move) & PATH_MASK;
     const uint32_t cstay = (pstay + stay) * stay;
     ChildHdr c;
-    c.appended = __fadd_rn(last, prob);
+    c.last = __fadd_rn(last, prob);
     // full window: (appended - prob_sums_[1]) / seed_len, else appended / len.  One IEEE division serves both cases.
-    const float num = full ? __fsub_rn(c.appended, second) : c.appended;
+    const float num = full ? __fsub_rn(c.last, subc) : c.last;
     c.seed_prob = __fdiv_rn(num, (float)(full ? (uint32_t)SEED_LEN : len));
     if (full) moves |= PATH_TAIL_MOVE;
     c.moves = moves;
     c.meta = kmer | (len << META_LEN_SHIFT) | (cstay << META_STAY_SHIFT) | (pmeta & META_SA_CHECKED) |
              ((!full && len == (uint32_t)SEED_LEN) ? META_FIRST_FULL : 0u);
+    // a move shifts its base into the history (the k-mer's newest base)
+    c.hist = move ? (hist & 0x3FFull) | ((((hist >> 10) << 2) | (kmer & 3u)) << 10) : hist;
     // is_seed_valid(path_ended = false), mapper.cpp:842-855, known at creation time
     const uint32_t move_count = (uint32_t)__popc(moves);
-    const bool seed_ok = len == P.seed_len && c.seed_prob >= P.min_seed_prob && s == e && (moves & 1u) == 1u &&
-                         (float)(len - move_count) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
+    const bool seed_ok = len == p_seed_len && c.seed_prob >= p_min_seed_prob && s == e && (moves & 1u) == 1u &&
+                         (float)(len - move_count) <= p_max_stay;      // p_max_stay = max_stay_frac * seed_len
     key.a = key_len_bits ? ((((s << key_len_bits) | (e - s)) << 16) | child_idx) : ((s << KEY_LEN_BITS) | (e - s));
     key.b = ((uint64_t)float_orderable(c.seed_prob) << 32) | ((uint64_t)child_idx << 16) | (move_count << KEYB_MOVES_SHIFT) |
             (seed_ok ? KEYB_SEED_FLAG : 0u) | kmer;
     return c;
 }
 
-// PathBuffer::make_source, mapper.cpp:751-772: prob_sums_ = {0, prob}; the path has no ring yet and its newest sum is prob
-// (every slot of recent[] gets it: only the creating event's slot is ever read before it is overwritten)
-__device__ __forceinline__ void write_source(void *buf, uint32_t idx, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
-    const uint32_t o = idx << 6;
-    gst(buf, o, make_uint4((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)e, (uint32_t)(e >> 32)));
-    gst(buf, o + 16u, make_uint4(1u, __float_as_uint(prob), kmer | (1u << META_LEN_SHIFT), RING_NONE));
-    gst(buf, o + 32u, make_float4(prob, prob, prob, prob));
+// PathBuffer::make_source, mapper.cpp:751-772: prob_sums_ = {0, prob}: last = prob, sub = 0, and the window's oldest event is
+// this one, with the source's k-mer.  NARROW: rows are 32-bit (start, end), else start << 30 | length - 1.
+template <bool NARROW>
+__device__ __forceinline__ void write_source(gptr_t buf, uint32_t idx, uint64_t s, uint64_t e, uint32_t kmer, float prob) {
+    const uint32_t o = idx << PATH_SHIFT;
+    const uint64_t r = NARROW ? (s | (e << 32)) : ((s << KEY_LEN_BITS) | (e - s));
+    gst(buf, o, make_uint4((uint32_t)r, (uint32_t)(r >> 32), 1u, kmer | (1u << META_LEN_SHIFT)));
+    gst(buf, o + 16u, make_uint4(__float_as_uint(prob), 0u, kmer, 0u));
 }
 
-// component j (uniform) of a float4
-__device__ __forceinline__ float f4_get(const float4 &v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-__device__ __forceinline__ void f4_set(float4 &v, uint32_t j, float x) { if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x; }
 
 #ifndef UNC_LB
 #define UNC_LB 3
 #endif
-// PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
-// NARROW: the index allows 64-bit sort keys (DevIndex::key_len_bits > 0: E. coli, chr20): the children's keys leave phase E
-// as sorted runs and are merged; the other instantiation (human-sized references) sorts 128-bit keys
-template <bool PROF, bool NARROW>
-__global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
-    __shared__ __attribute__((aligned(16))) float s_probs[NKMER];
-    __shared__ uint32_t s_flags[NKMER / 32];
-    // SeedTracker's scalars between the events that touch them (phases T / G run only when an event has seeds): parked in
-    // LDS, so that the extension / sort / walk loops do not carry twenty uniform values through their register allocation
-    __shared__ Tracker s_T;
-    // one carved buffer for the per-pass staging of phase E (7.5 KB), reused as the source list in phase F: with the
-    // probs table the wavefront stays under 12 KB of LDS, i.e. 13 wavefronts per CU fit the 160 KB (12 are resident)
-    constexpr int RES_BITS = 30;                       // packed FM result: start << 30 | row count (0 = empty range)
-    __shared__ __attribute__((aligned(16))) uint64_t s_e[CAND_MAX + 2 * WAVE + 4 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4];
-    uint64_t *const s_res = s_e;
-    uint64_t *const s_pstart = s_e + CAND_MAX, *const s_pend = s_pstart + WAVE;
-    float4 *const s_prec = reinterpret_cast<float4 *>(s_pend + WAVE), *const s_psec = s_prec + WAVE;   // parents' recent[] / second[]
-    uint32_t *const s_pmoves = reinterpret_cast<uint32_t *>(s_psec + WAVE), *const s_pmeta = s_pmoves + WAVE, *const s_pring = s_pmeta + WAVE;
-    uint32_t *const s_cdesc = s_pring + WAVE;
-    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
-    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
-    static_assert(sizeof(s_e) >= NKMER * sizeof(uint32_t), "source list must fit the staging buffer");
-    static_assert(sizeof(s_e) >= MERGE_LDS_KEYS * sizeof(uint64_t), "a merge tile must fit the staging buffer");
-    __shared__ uint16_t s_ckpos[NARROW ? CHILD_MAX : 1];         // narrow keys: a child's position in its run
 
+// ---- One event = a sequence of PHASES, each an out-of-line function.  Inlined into one kernel body, the phases kept every
+// loop-invariant address and parameter of every other phase alive in scalar registers: a fifth of the instructions the
+// hot loops issued were moves between SGPRs and the lanes of spill VGPRs (round 3, from the disassembly).  A phase function
+// reads what it needs from the kernel's argument block (constant address space, scalar loads) and from WaveCtx when it is
+// entered, and nothing else is live inside it.
+typedef const UNC_AS_CONST MapArgs *kargs_t;
+
+// What the phases hand to each other: uniform scalars in LDS.
+struct WaveCtx {
+    uint32_t event_i, n_parents, cur, n_surv_par;   // the read: next event, the parent list and which buffer holds it (SlotState)
+    uint32_t tstatus;                                // UNC_READ_* bits
+    uint32_t nchild, n_seedp;                        // this event: children made, seed paths listed
+    uint32_t bchild;                                 // a single-row child on the first / last row of its k-mer's range was made
+    uint32_t kl;                                     // key mode of this event's sorted keys (0: 128-bit)
+    uint32_t scnt[6];                                // narrow keys: keys filed in each run
+    uint32_t n_surv, n_src;                          // the walk: survivors, gap sources
+    uint32_t conf;                                   // the confidence test passed
+};
+__shared__ WaveCtx s_w;
+__shared__ Tracker s_T;       // SeedTracker's scalars between the events that touch them
+__shared__ uint64_t s_cyc[12];   // PROF: shader-clock cycles per phase (lane 0)
+
+__device__ __forceinline__ uint32_t ctx_get(const uint32_t &f) { return uniform32(f); }
+#define CTX_SET(field, v) do { if (lane == 0) s_w.field = (v); } while (0)
+
+template <bool PROF> struct PhaseClock {
+    uint64_t tk;
+    __device__ __forceinline__ PhaseClock() : tk(PROF ? (uint64_t)clock64() : 0ull) {}
+    __device__ __forceinline__ void reset() { if constexpr (PROF) tk = (uint64_t)clock64(); }
+    __device__ __forceinline__ void end(int i, int lane) {
+        if constexpr (PROF) {
+            const uint64_t tn = (uint64_t)clock64();
+            if (lane == 0) s_cyc[i] += tn - tk;
+            tk = tn;
+        }
+    }
+};
+
+__device__ __forceinline__ TrackerMem tracker_mem(kargs_t A, gptr_t sb) {
+    TrackerMem M;
+    M.sb = sb; M.off_dir = A->sc.off_cl_dir; M.off_chunks = A->sc.off_cl_chunks; M.max_leaves = A->sc.max_clusters / 16;
+    M.pool.leaves = (gptr_t)A->pool.leaves; M.pool.cnt = (UNC_AS_GLOBAL uint32_t *)A->pool.cnt;
+    M.pool.q = A->pool.q; M.pool.cells = A->pool.cells; M.pool.cap_mask = A->pool.cap_mask;
+    return M;
+}
+
+// ---------------- P: match log-probs of the normalised event (pore_model.hpp:163-165) -> s_probs ----------------
+static __device__ __noinline__ void phase_P(kargs_t A_, float level, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const UNC_AS_GLOBAL float *const model = (const UNC_AS_GLOBAL float *)A->ix.model;
+#pragma unroll 4
+    for (int j = 0; j < NKMER / WAVE; ++j) {
+        const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+        const float mu = model[k], v2 = model[NKMER + k], ld = model[2 * NKMER + k];
+        const float d = __fsub_rn(level, mu);
+        const double q = -((double)d * (double)d) / (double)v2;
+        s_probs[k] = (float)(q - (double)ld);
+    }
+    wave_sync();
+}
+
+// FM index as the phases see it (global-memory pointers; fm_dev.h takes any type with these members)
+struct FmView {
+    const UNC_AS_GLOBAL uint32_t *bwt;
+    const UNC_AS_GLOBAL uint32_t *fm32;
+    const UNC_AS_GLOBAL uint64_t *sa, *sa_dense;
+    const UNC_AS_CONST uint64_t *L2;
+    uint64_t primary, seq_len;
+};
+__device__ __forceinline__ FmView fm_view(kargs_t A) {
+    FmView v;
+    v.bwt = (const UNC_AS_GLOBAL uint32_t *)A->ix.bwt; v.fm32 = (const UNC_AS_GLOBAL uint32_t *)A->ix.fm32;
+    v.sa = (const UNC_AS_GLOBAL uint64_t *)A->ix.sa; v.sa_dense = (const UNC_AS_GLOBAL uint64_t *)A->ix.sa_dense;
+    v.L2 = A->ix.L2; v.primary = A->ix.primary; v.seq_len = A->ix.seq_len;
+    return v;
+}
+
+// ---------------- E: extend parents ----------------
+// parents, 64 per pass in the reference's visiting order: thresholds -> candidate (parent, base) pairs compacted through LDS
+// -> FM get_neighbor with every lane busy -> child slots by prefix sum (honouring the max_paths cut-off) -> one lane per
+// child writes a 64-byte record (the parent's staged in LDS: no global read), its sort key and its info word.
+// Returns this lane's share of the event's get_neighbor count.
+template <bool PROF, bool NARROW>
+static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    // NARROW: the reference has fewer than 2^32 rows (the host sets key_len_bits only then): rows are 32-bit, FM steps go through
+    // the 32-bit rank table (fm32_get_neighbor)
+    using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
+    constexpr int RES_BITS = 30;                       // wide rows: packed FM result start << 30 | row count (0 = empty range)
+    uint64_t *const s_res = s_e;
+    Row *const s_pstart = reinterpret_cast<Row *>(s_e + CAND_MAX), *const s_pend = reinterpret_cast<Row *>(s_e + CAND_MAX + WAVE);
+    uint64_t *const s_phist = s_e + CAND_MAX + 2 * WAVE;          // the parents' k-mer history, slid for their children
+    float *const s_plast = reinterpret_cast<float *>(s_phist + WAVE), *const s_psubc = s_plast + WAVE;   // prob_sums_[length_] / the children's prob_sums_[0]
+    uint32_t *const s_pmoves = reinterpret_cast<uint32_t *>(s_psubc + WAVE), *const s_pmeta = s_pmoves + WAVE;
+    uint32_t *const s_cdesc = s_pmeta + WAVE;
+    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
+
+    const FmView ix = fm_view(A);
+    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+    const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
+    const uint32_t event_i = ctx_get(s_w.event_i), n_parents = ctx_get(s_w.n_parents), cur = ctx_get(s_w.cur), n_surv_par = ctx_get(s_w.n_surv_par);
+    const float thr_lane = A->ix.thresholds[lane];   // lane l keeps prob_threshes_[l]
+    const uint32_t klb = NARROW ? A->ix.key_len_bits : 0u;
+    const uint32_t p_max_consec_stay = A->P.max_consec_stay, p_seed_len = A->P.seed_len, p_max_rep_copy = A->P.max_rep_copy, p_min_rep_len = A->P.min_rep_len;
+    const float p_min_seed_prob = A->P.min_seed_prob, p_max_stay = __fmul_rn(A->P.max_stay_frac, (float)A->P.seed_len);
+    // byte offsets (inside the slot) of this event's parent / child records and parent-order list
+    const uint32_t par_off = A->sc.off_paths + cur * (max_paths << PATH_SHIFT), chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT);
+    const uint32_t pord_off = A->sc.off_order + cur * (max_paths << 2);
+    const uint32_t seedp_off = A->sc.off_seedp, ukeys_off = A->sc.off_keys, str_off = A->sc.off_streams, info_off = A->sc.off_info;
+    const uint32_t run_bytes = max_paths << 3;
+    // a full-window parent's oldest event is 22 back from this one: its level, for the sum that drops out of the window
+    const float level_old = event_i >= (uint32_t)SEED_LEN ? gld<float>(sb, A->sc.off_levels + (((event_i - (uint32_t)SEED_LEN) & (LEVEL_RING - 1u)) << 2)) : 0.0f;
+    const UNC_AS_GLOBAL float *const model = (const UNC_AS_GLOBAL float *)A->ix.model;
+
+    PhaseClock<PROF> clk;
+    uint32_t c_nbr = 0;
+    uint32_t nchild = 0, n_seedp = 0;
+    bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort)
+    // narrow keys: keys filed so far in each run (stays / moves by base of the sorted survivors; children of sources)
+    uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
+    // parent index list and record headers are fetched one / two passes ahead of their use
+    uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
+    uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
+    uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
+    if ((uint32_t)lane < n_parents) {
+        q0c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
+    }
+    for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
+        const uint32_t pi = base + (uint32_t)lane;
+        const bool have = pi < n_parents;
+        const uint4 q0 = q0c, q1 = q1c;
+        phys_cur = phys_nxt;
+        if (pi + WAVE < n_parents) {
+            q0c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
+        }
+        if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * WAVE) << 2));
+        uint32_t pmoves = 0, pmeta = 0;
+        Row pstart = 1, pend = 1;
+        float plast = 0.0f, psub = 0.0f;
+        uint64_t phist = 0;
+        if (have) {
+            if constexpr (NARROW) { pstart = q0.x; pend = q0.y; }
+            else { const uint64_t r = ((uint64_t)q0.y << 32) | q0.x; pstart = r >> KEY_LEN_BITS; pend = pstart + (r & KEY_LEN_MASK); }
+            pmoves = q0.z; pmeta = q0.w;
+            plast = __uint_as_float(q1.x); psub = __uint_as_float(q1.y); phist = ((uint64_t)q1.w << 32) | q1.z;
+        }
+        // A full-window parent hands its children prob_sums_[1] = prob_sums_[0] + the match probability of the window's oldest
+        // event with the k-mer the lineage had then (the model row is requested here, the division runs behind the FM round trip)
+        const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
+        const bool pfull = plen == (uint32_t)SEED_LEN;
+        const uint32_t okmer = (uint32_t)phist & KMASK;
+        float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
+        if (pfull) { o_mu = model[okmer]; o_v2 = model[NKMER + okmer]; o_ld = model[2 * NKMER + okmer]; }
+        const Row plen_fm = pend - pstart + 1;
+        int thr_bin;                                                         // get_fm_bin = clzll(length), :161-163
+        if constexpr (NARROW) thr_bin = 32 + __clz((int)plen_fm); else thr_bin = __clzll((long long)plen_fm);
+        const float thr = __shfl(thr_lane, thr_bin);                          // get_prob_thresh, :165-167
+        const uint32_t kmer = pmeta & META_KMER_MASK;
+        const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
+        const bool stay_ok = have && stays < p_max_consec_stay && s_probs[kmer] >= thr;
+        // kmer_neighbor (bp.hpp:105-108): the four successors ((kmer << 2) & KMASK) | b are neighbours in the table
+        const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
+        uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
+        if (!have) mask = 0;
+        s_pstart[lane] = pstart; s_pend[lane] = pend; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta; s_plast[lane] = plast;
+        const uint32_t ncand = (uint32_t)__popc(mask);
+        uint32_t ctot;
+        const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
+        {
+            uint32_t w = coff;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
+        }
+        wave_sync();
+        clk.end(8, lane);
+        // FM look-ups, every lane busy
+        for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
+            const uint32_t ci = c0 + (uint32_t)lane;
+            if (ci < ctot) {
+                const uint32_t cd = s_cand[ci];
+                if constexpr (NARROW) {
+                    uint32_t ns, ne;
+                    fm32_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
+                    s_res[ci] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull;      // row count | first row
+                } else {
+                    uint64_t ns, ne;
+                    fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
+                    s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
+                }
+            }
+        }
+        wave_sync();
+        clk.end(9, lane);
+        // children per parent, in the reference's order: stay, then bases 0..3
+        // bit j: j-th candidate of this lane has a non-empty range (four unconditional reads; the staging buffer
+        // extends past the result slots, and whatever lies beyond this lane's candidates is masked off)
+        uint32_t vmask = (s_res[coff] != 0 ? 1u : 0u) | (s_res[coff + 1] != 0 ? 2u : 0u) | (s_res[coff + 2] != 0 ? 4u : 0u) |
+                         (s_res[coff + 3] != 0 ? 8u : 0u);
+        vmask &= (1u << ncand) - 1u;
+        const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
+        uint32_t chtot;
+        const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
+        const uint32_t room = max_paths - nchild;                 // > 0 here
+        const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
+        const bool visited = have && choff < room;                // reached before the buffer filled
+        // work counter: the get_neighbor calls the reference makes (it stops at the cut-off)
+        if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += ncand;   // every call precedes the cut-off
+        else
+            for (uint32_t j = 0; j < ncand; ++j)
+                if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
+        if constexpr (NARROW) {
+            // creation position (inside this pass) of this lane's child of each type: stay, bases 0..3
+            const bool is_src = pi >= n_surv_par;          // children of sources: the unsorted run
+            uint32_t cpos[5], cres[5];
+            bool ex[5];
+            ex[0] = stay_ok; cpos[0] = choff; cres[0] = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t jj = (uint32_t)__popc(mask & ((1u << b) - 1u));
+                ex[b + 1] = ((mask >> b) & 1u) && ((vmask >> jj) & 1u);
+                cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << jj) - 1u));
+                cres[b + 1] = coff + jj;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t) ex[t] = ex[t] && cpos[t] < nwrite;      // the max_paths cut-off
+            const bool pass_has_surv = base < n_surv_par, pass_has_src = base + WAVE > n_surv_par;
+            uint32_t kp[5] = {0, 0, 0, 0, 0};
+            if (pass_has_surv) {
+                // a run takes at most one child per parent: position = keys filed + fitting children of earlier lanes
+                const uint64_t m0 = __ballot(ex[0] && !is_src), m1 = __ballot(ex[1] && !is_src), m2 = __ballot(ex[2] && !is_src),
+                               m3 = __ballot(ex[3] && !is_src), m4 = __ballot(ex[4] && !is_src);
+                kp[0] = scnt0 + (uint32_t)prefix_popc(m0); kp[1] = scnt1 + (uint32_t)prefix_popc(m1);
+                kp[2] = scnt2 + (uint32_t)prefix_popc(m2); kp[3] = scnt3 + (uint32_t)prefix_popc(m3);
+                kp[4] = scnt4 + (uint32_t)prefix_popc(m4);
+                scnt0 += (uint32_t)__popcll(m0); scnt1 += (uint32_t)__popcll(m1); scnt2 += (uint32_t)__popcll(m2);
+                scnt3 += (uint32_t)__popcll(m3); scnt4 += (uint32_t)__popcll(m4);
+            }
+            if (pass_has_src) {
+                // the unsorted run keeps creation order
+                const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
+                uint32_t xtot;
+                uint32_t xo = scntx + excl_sum_bits<3>(nfit, &xtot);
+                if (is_src) {
+#pragma unroll
+                    for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
+                }
+                scntx += xtot;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t)
+                if (ex[t]) {
+                    s_cdesc[cpos[t]] = (uint32_t)lane | (t << 6) | (cres[t] << 9) | (is_src ? 1u << 18 : 0u);
+                    s_ckpos[cpos[t]] = (uint16_t)kp[t];
+                }
+        } else {
+            uint32_t w = choff;
+            if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
+            uint32_t jj = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                if (mask & (1u << b)) {
+                    if (vmask & (1u << jj)) {
+                        if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((coff + jj) << 9);
+                        ++w;
+                    }
+                    ++jj;
+                }
+            }
+        }
+        {
+            // the children's prob_sums_[0] and the history slid by one event: the window's oldest event drops out, and if the
+            // next one was a move its base (the oldest in the queue) joins the k-mer
+            float subc = psub;
+            uint64_t hist = phist;
+            if (pfull) {
+                const float d = __fsub_rn(level_old, o_mu);
+                const double q = -((double)d * (double)d) / (double)o_v2;
+                subc = __fadd_rn(psub, (float)(q - (double)o_ld));
+                if ((pmoves >> (SEED_LEN - 2)) & 1u) {
+                    const uint32_t cnt = (uint32_t)__popc(pmoves & ((1u << (SEED_LEN - 1)) - 1u));       // bases queued (>= 1 here)
+                    const uint32_t pos = 2u * (cnt - 1u);
+                    const uint64_t fifo = hist >> 10;
+                    const uint32_t nk = ((okmer << 2) & KMASK) | ((uint32_t)(fifo >> pos) & 3u);
+                    hist = (uint64_t)nk | ((fifo & ~(3ull << pos)) << 10);
+                }
+            }
+            s_psubc[lane] = subc; s_phist[lane] = hist;
+        }
+        // dead ends -> update_seeds(prev_path, true), :513-519 / is_seed_valid :842-863
+        bool ended_seed = false;
+        uint32_t e_count = 0, e_mc = 0;
+        if (visited && nch == 0 && !(pmeta & META_SA_CHECKED)) {
+            const uint32_t mc = (uint32_t)__popc(pmoves);
+            // seed_prob_ of a full-length path: (prob_sums_[22] - prob_sums_[0]) / 22 (prob_sums_[0] is 0 while the window has not slid)
+            const float pprob = __fdiv_rn(__fsub_rn(plast, psub), (float)SEED_LEN);
+            const bool base_ok = plen == p_seed_len && pprob >= p_min_seed_prob;
+            const bool uniq = plen_fm == 1 && (pmoves & 1u) == 1u && (float)(plen - mc) <= p_max_stay;
+            const bool rep = plen_fm <= (Row)p_max_rep_copy && mc >= p_min_rep_len;
+            ended_seed = base_ok && (uniq || rep);
+            e_count = (uint32_t)plen_fm;
+            e_mc = mc;
+        }
+        {
+            const uint64_t em = __ballot(ended_seed);
+            const uint32_t pos = n_seedp + (uint32_t)prefix_popc(em);
+            if (ended_seed) {
+                if (pos < max_seed_paths) {
+                    SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
+                    gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
+                }
+            }
+            n_seedp += (uint32_t)__popcll(em);
+        }
+        wave_sync();
+        clk.end(10, lane);
+        // one lane per child: everything it needs of its parent sits in LDS, the 64-byte record and the sort key go out
+        for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
+            const uint32_t li = l0 + (uint32_t)lane;
+            if (li < nwrite) {
+                const uint32_t d = s_cdesc[li];
+                const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (d >> 9) & 511u;
+                const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
+                const float last = s_plast[pl], subc = s_psubc[pl];
+                const uint64_t hist = s_phist[pl];
+                const uint32_t pk = pmt & META_KMER_MASK;
+                Row cs, ce;
+                uint32_t ck, mv;
+                if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
+                else {
+                    const uint64_t pr = s_res[ci];
+                    if constexpr (NARROW) { cs = (uint32_t)pr; ce = cs + (uint32_t)(pr >> 32) - 1u; }
+                    else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
+                    ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
+                }
+                SortKey key;
+                const uint32_t gi = nchild + li;
+                const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
+                const uint32_t co = chd_off + (gi << PATH_SHIFT);
+                if constexpr (NARROW) gst(sb, co, make_uint4(cs, ce, c.moves, c.meta));
+                else { const uint64_t r = (cs << KEY_LEN_BITS) | (ce - cs); gst(sb, co, make_uint4((uint32_t)r, (uint32_t)(r >> 32), c.moves, c.meta)); }
+                gst(sb, co + 16u, make_uint4(__float_as_uint(c.last), __float_as_uint(subc), (uint32_t)c.hist, (uint32_t)(c.hist >> 32)));
+                if constexpr (NARROW) {
+                    const uint32_t run = (d >> 18) ? 5u : type;
+                    gst(sb, str_off + run * run_bytes + ((uint32_t)s_ckpos[li] << 3), key.a);
+                    gst(sb, info_off + (gi << 3), key.b);
+                    // the k-mer's own range, for the boundary test (see the sort): a one-row child on its first / last row
+                    if (cs == ce) {
+                        const ulonglong2 kr = g_load(kmer_ranges + ck);
+                        if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
+                    }
+                } else {
+                    gst(sb, ukeys_off + (gi << 4), key);
+                }
+            }
+        }
+        nchild += nwrite;
+        wave_sync();
+        clk.end(11, lane);
+    }
+    clk.end(1, lane);
+    uint32_t tst = 0;
+    if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
+    const uint32_t anyb = __any(bchild) ? 1u : 0u;
+    if (lane == 0) {
+        s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.bchild = anyb; s_w.tstatus |= tst;
+        s_w.scnt[0] = scnt0; s_w.scnt[1] = scnt1; s_w.scnt[2] = scnt2; s_w.scnt[3] = scnt3; s_w.scnt[4] = scnt4; s_w.scnt[5] = scntx;
+    }
+    wave_sync();
+    return c_nbr;
+}
+
+// ---------------- S: the children's keys in the reference's order (mapper.cpp:531, 866-871) ----------------
+template <bool NARROW>
+static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    const uint32_t n = ctx_get(s_w.nchild);
+    const uint32_t max_paths = A->sc.max_paths;
+    const uint32_t ukeys_off = A->sc.off_keys, skeys_off = A->sc.off_keys + A->sc.keys_cap * (uint32_t)sizeof(SortKey);
+    UNC_AS_GLOBAL SortKey *const ukeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + ukeys_off);
+    UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + skeys_off);
+    uint32_t kl = NARROW ? A->ix.key_len_bits : 0u;     // key mode of THIS event
+    if constexpr (NARROW) {
+        const UNC_AS_GLOBAL uint64_t *const skeys64 = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(skeys);
+        const UNC_AS_GLOBAL uint64_t *const info = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);
+        const uint32_t str_off = A->sc.off_streams, sk_off = skeys_off, run_bytes = max_paths << 3;
+        uint32_t scnt0 = ctx_get(s_w.scnt[0]), scnt1 = ctx_get(s_w.scnt[1]), scnt2 = ctx_get(s_w.scnt[2]), scnt3 = ctx_get(s_w.scnt[3]),
+                 scnt4 = ctx_get(s_w.scnt[4]), nx = ctx_get(s_w.scnt[5]);
+        bool sorted_ok = false;
+        if (n > MERGE_MIN) {
+            // moves of one base: ascending but for the odd pair of nested parents (repair_run); then the unsorted
+            // run is sorted, merged with the moves, and the result with the stays
+            const uint32_t x_off = str_off + 5u * run_bytes;
+            if constexpr (MERGE_REPAIR) {
+                if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); scnt1 -= v; nx += v; }
+                if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); scnt2 -= v; nx += v; }
+                if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); scnt3 -= v; nx += v; }
+                if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); scnt4 -= v; nx += v; }
+            }
+            wave_sync();
+            if (nx > 1) {
+                KeyArr<6> KX;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
+                KX.n = nx;
+                sort_any64(sb, KX, x_off, lane);          // in place
+                wave_sync();
+            }
+            KeyArr<4> KM;       // the moves, base by base
+            KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
+            KM.n = KM.cum[3] + scnt4;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
+            KeyArr<4> KB = KM;  // what the stays are merged with
+            if (nx > 0) {
+                if (KM.n > 0) {
+                    merge_runs<4, 1>(sb, KM, ka_single(x_off, nx), A->sc.off_tmp, lane, 0u);
+                    wave_sync();
+                    KB.adj[0] = A->sc.off_tmp;
+                } else KB.adj[0] = x_off;
+                KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
+                KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
+            }
+            sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, lane, 1u) != 0u;
+            wave_sync();
+        }
+        if (!sorted_ok) {
+            // few children, or runs that were not ascending after all: the bitonic network over all of them
+            KeyArr<6> K6;
+            const uint32_t c[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
+            uint32_t cum = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 6; ++r) { K6.cum[r] = cum; K6.adj[r] = str_off + r * run_bytes - (cum << 3); cum += c[r]; }
+            K6.n = cum;
+            sort_any64(sb, K6, sk_off, lane);
+        }
+        // BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can
+        // share a boundary row and two children with the SAME one-row range may carry DIFFERENT k-mers.  The
+        // reference then walks them in seed_prob order (mapper.cpp:543-563 runs per position), which the narrow
+        // key cannot express: such an event (rare) is re-sorted with the full 128-bit keys.
+        if (ctx_get(s_w.bchild)) {
+            wave_sync();
+            bool mixed = false;
+            for (uint32_t base = 0; base + 1 < n; base += WAVE) {
+                const uint32_t i = base + (uint32_t)lane;
+                if (i + 1 < n) {
+                    const uint64_t ki = skeys64[i], kn = skeys64[i + 1];
+                    if ((ki >> 16) == (kn >> 16) && ((info[ki & 0xFFFFu] ^ info[kn & 0xFFFFu]) & META_KMER_MASK)) mixed = true;
+                }
+            }
+            if (__any(mixed)) {
+                for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+                    const uint64_t k = skeys64[i], ri = k >> 16;
+                    SortKey w;
+                    w.a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
+                    w.b = info[k & 0xFFFFu];
+                    g_store(ukeys + i, w);
+                }
+                kl = 0;
+                wave_sync();
+            }
+        }
+    }
+    if (!kl) {
+        if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
+        else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
+        else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
+        else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
+        else sort_hybrid(ukeys, skeys, n, lane);
+    }
+    CTX_SET(kl, kl);
+    wave_sync();
+}
+
+// ---------------- W: walk in sorted order (mapper.cpp:533-603) ----------------
+// duplicate-range pruning, per-k-mer gap sources from a segmented prefix-max (the sequential unchecked_range logic in closed
+// form), survivors -> next parent list, seed-valid survivors -> seed list
+template <bool NARROW>
+static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
+    const uint32_t n = ctx_get(s_w.nchild), cur = ctx_get(s_w.cur), event_i = ctx_get(s_w.event_i);
+    const uint32_t kl = ctx_get(s_w.kl);
+    uint32_t n_seedp = ctx_get(s_w.n_seedp);
+    const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
+    const float source_prob = A->ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
+    const UNC_AS_GLOBAL uint64_t *const kmer_ranges = (const UNC_AS_GLOBAL uint64_t *)A->ix.kmer_ranges;
+    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+    const uint32_t chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT), nord_off = A->sc.off_order + (cur ^ 1u) * (max_paths << 2);
+    const uint32_t seedp_off = A->sc.off_seedp;
+    const UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<const UNC_AS_GLOBAL SortKey *>(sb + A->sc.off_keys + A->sc.keys_cap * (uint32_t)sizeof(SortKey));
+    const UNC_AS_GLOBAL uint64_t *const skeys64 = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(skeys);
+    const UNC_AS_GLOBAL uint64_t *const infow = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);   // narrow keys: info words by creation index
+    const gptr_t chd = sb + chd_off;
+
+    uint32_t n_surv = 0, n_src = 0;
+    uint32_t carry_kmer = NKMER;
+    Row carry_U = 0;
+    uint64_t carry_range = ~0ull, carry_w = 0;
+    const uint32_t room = max_paths - n;   // sources that still fit
+    // narrow keys: the sorted keys of the pass after next and the info words (seed_prob, idx, flags, k-mer) they
+    // point to for the next pass are fetched while this pass is worked on; a lane's successor comes from
+    // its neighbour lane, the last lane's from the next pass
+    uint64_t kq0 = ~0ull, kq1 = ~0ull, bq0 = 0, bq1 = 0;
+    if (kl) {
+        if ((uint32_t)lane < n) kq0 = skeys64[lane];
+        if ((uint32_t)lane + WAVE < n) kq1 = skeys64[lane + WAVE];
+        if ((uint32_t)lane < n) bq0 = infow[kq0 & 0xFFFFu];
+        if ((uint32_t)lane + WAVE < n) bq1 = infow[kq1 & 0xFFFFu];
+    }
+    // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
+    ulonglong2 krq = make_ulonglong2(1ull, 0ull);
+    if (kl && (uint32_t)lane < n) {
+        const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
+        if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+    }
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool have = i < n;
+        const bool has_next = i + 1 < n;
+        Row start, end, nstart;
+        uint64_t sb_;                         // sb_: info word of the child that survives at this position
+        uint32_t kmer, nkmer;
+        bool dup;
+        ulonglong2 krc = make_ulonglong2(1ull, 0ull);
+        if (kl) {
+            const uint64_t ki = kq0, bi = bq0;
+            uint64_t kn = (uint64_t)__shfl((unsigned long long)ki, (lane + 1) & 63);
+            uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
+            const uint64_t kf = bcast64(kq1, 0), bf = bcast64(bq1, 0);
+            if (lane == WAVE - 1) { kn = kf; bn = bf; }
+            kq0 = kq1; bq0 = bq1;
+            kq1 = i + 2 * WAVE < n ? skeys64[i + 2 * WAVE] : ~0ull;
+            krc = krq;
+            krq = make_ulonglong2(1ull, 0ull);
+            if (i + WAVE < n) {
+                const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
+                if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+            }
+            const uint64_t ri = ki >> 16, rn = kn >> 16;
+            start = (Row)(ri >> kl); end = start + (Row)(ri & ((1ull << kl) - 1ull));
+            nstart = (Row)(rn >> kl);
+            kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
+            nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
+            dup = has_next && rn == ri;
+            // among equal ranges the reference keeps the highest (seed_prob, creation order): a running max of
+            // the info words over each run, read off at the run's last position
+            uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
+            if (lane == 0) pr = carry_range;
+            const bool rhead = !have || ri != pr;
+            sb_ = seg_incl_max64(bi, rhead);
+            const uint64_t rheads = __ballot(rhead);
+            if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb_) sb_ = carry_w;
+            const uint32_t nvv = n - base < WAVE ? n - base : WAVE;
+            carry_range = bcast64(ri, (int)nvv - 1);
+            carry_w = bcast64(sb_, (int)nvv - 1);
+        } else {
+            SortKey ki, kn;
+            ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
+            if (have) ki = g_load(skeys + i);
+            if (has_next) kn = g_load(skeys + i + 1);
+            start = (Row)(ki.a >> KEY_LEN_BITS); end = start + (Row)(ki.a & KEY_LEN_MASK);
+            nstart = (Row)(kn.a >> KEY_LEN_BITS);
+            kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
+            nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
+            dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
+            sb_ = ki.b;                              // sorted by seed_prob inside the run: the last one survives
+        }
+        const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
+        uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
+        if (lane == 0) pk = carry_kmer;
+        const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
+        const bool next_same = has_next && nkmer == kmer;
+        const bool psrc = have && s_probs[have ? kmer : 0] >= source_prob;
+        // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
+        Row U;
+        if constexpr (NARROW) U = seg_incl_max32(have ? end + 1u : 0u, first || !have);
+        else U = seg_incl_max64(have ? end + 1 : 0, first || !have);
+        const uint64_t heads = __ballot(first || !have);
+        const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
+        if (headless && carry_U > U) U = carry_U;
+        Row kr_s = 1, kr_e = 0;
+        if (kl) {
+            if (first && psrc) kr_s = (Row)krc.x;
+            if (have && !dup && psrc && !next_same) kr_e = (Row)krc.y;
+        } else {
+            if (first && psrc) kr_s = (Row)kmer_ranges[2 * kmer];
+            if (have && !dup && psrc && !next_same) kr_e = (Row)kmer_ranges[2 * kmer + 1];
+        }
+        const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
+        const Row c_s = U, c_e = next_same ? nstart - 1 : kr_e;                        // :579-589
+        const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
+        uint32_t stot;
+        const uint32_t soff = excl_sum_bits<2>((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
+        const uint32_t q0 = n_src + soff;                      // sources appended before this child
+        const bool not_full0 = q0 < room;                      // next_path != end at step A
+        if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
+        if (a_valid && not_full0) write_source<NARROW>(chd, n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
+        const uint32_t qc = q0 + (a_valid ? 1u : 0u);
+        if (c_valid && qc < room) write_source<NARROW>(chd, n + qc, c_s, c_e, kmer, s_probs[kmer]);
+        // survivors keep sorted order in the next parent list
+        const bool surv = have && !dup;
+        const uint64_t sm = __ballot(surv);
+        if (surv) gst(sb, nord_off + ((n_surv + (uint32_t)prefix_popc(sm)) << 2), idx);
+        n_surv += (uint32_t)__popcll(sm);
+        // update_seeds(child, false), :601 -- validity was decided at creation
+        const bool sv = surv && (sb_ & KEYB_SEED_FLAG);
+        const uint64_t svm = __ballot(sv);
+        if (sv) {
+            const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
+            // path.sa_checked_ = true (no value returned: no round trip)
+            __hip_atomic_fetch_or(reinterpret_cast<UNC_AS_GLOBAL uint32_t *>(chd + (idx << PATH_SHIFT) + 12u), META_SA_CHECKED, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (pos < max_seed_paths) {
+                SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
+                sp.ref_len = (uint32_t)(sb_ >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
+                gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
+            }
+        }
+        n_seedp += (uint32_t)__popcll(svm);
+        // carries into the next pass
+        const uint32_t nv = n - base < WAVE ? n - base : WAVE;
+        carry_kmer = bcast32(kmer, (int)nv - 1);
+        if constexpr (NARROW) carry_U = bcast32(U, (int)nv - 1); else carry_U = bcast64(U, (int)nv - 1);
+        n_src += stot;
+        if (n_src > room) n_src = room;
+        if (kl) bq1 = i + 2 * WAVE < n ? infow[kq1 & 0xFFFFu] : 0ull;
+    }
+    uint32_t tst = 0;
+    if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
+    if (lane == 0) { s_w.n_surv = n_surv; s_w.n_src = n_src; s_w.n_seedp = n_seedp; s_w.tstatus |= tst; }
+    wave_sync();
+}
+
+// ---------------- F: remaining full-range sources, :605-624; the next parent list is complete after it ----------------
+// sources_added_[k] for k = j*64 + lane lives in bit j of this lane's 16-bit field (two lanes per word).
+// Pass 1 decides, in k-mer order, which k-mers get a full-range source and where (pure ALU + LDS);
+// pass 2 fetches their ranges and writes the records, one lane per source, in one memory round trip.
+template <bool NARROW>
+static __device__ __noinline__ void phase_F(kargs_t A_, gptr_t sb_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_e);   // NKMER entries
+    const uint32_t n = ctx_get(s_w.nchild), cur = ctx_get(s_w.cur);
+    const uint32_t n_surv = n ? ctx_get(s_w.n_surv) : 0u, n_src = n ? ctx_get(s_w.n_src) : 0u;
+    const uint32_t max_paths = A->sc.max_paths;
+    const float source_prob = A->ix.thresholds[0];
+    const uint32_t kvalid = ((const UNC_AS_GLOBAL uint16_t *)A->ix.kmer_valid)[lane];     // bit j: k-mer j*64+lane occurs in the reference
+    const UNC_AS_GLOBAL uint64_t *const kmer_ranges = (const UNC_AS_GLOBAL uint64_t *)A->ix.kmer_ranges;
+    const uint32_t chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT), nord_off = A->sc.off_order + (cur ^ 1u) * (max_paths << 2);
+    uint32_t ent = n + n_src;
+    {
+        const uint32_t ent0 = ent;
+        const uint32_t myflags = (s_flags[lane >> 1] >> ((lane & 1) << 4)) & 0xFFFFu;
+        uint32_t newflags = 0;
+#pragma unroll 4
+        for (int j = 0; j < NKMER / WAVE; ++j) {
+            const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+            const uint32_t fl = (myflags >> j) & 1u;
+            const bool cond = !fl && s_probs[k] >= source_prob && ((kvalid >> j) & 1u);
+            const uint64_t m = __ballot(cond);
+            const uint32_t before = ent + (uint32_t)prefix_popc(m);
+            const bool exec = before < max_paths;           // loop header: next_path != end
+            const bool app = cond && exec;
+            if (app) s_list[before - ent0] = k;
+            if (!exec && fl) newflags |= 1u << j;           // flags survive only past the cut-off
+            ent += (uint32_t)__popcll(__ballot(app));
+        }
+        const uint32_t other = (uint32_t)__shfl_xor((int)newflags, 1);
+        wave_sync();
+        if (!(lane & 1)) s_flags[lane >> 1] = newflags | (other << 16);
+        for (uint32_t q = (uint32_t)lane; q < ent - ent0; q += WAVE) {
+            const uint32_t k = s_list[q];
+            write_source<NARROW>(sb + chd_off, ent0 + q, kmer_ranges[2 * k], kmer_ranges[2 * k + 1], k, s_probs[k]);
+        }
+    }
+    wave_sync();
+    const uint32_t nsrc_total = ent - n;
+    for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) gst(sb, nord_off + ((n_surv + q) << 2), n + q);
+    if (lane == 0) { s_w.n_parents = n_surv + nsrc_total; s_w.n_surv_par = n_surv; s_w.cur = cur ^ 1u; }
+    wave_sync();
+}
+
+// ---------------- T + G: seeds -> SeedTracker, then the confidence test ----------------
+// SA look-ups for all seeds in parallel, then SeedTracker::add_seed in the reference's order on the pooled B+-tree;
+// get_final / check_map_conf (seed_tracker.cpp:129-143,259-262).  Returns this lane's SA look-ups | LF steps << 32.
+template <bool PROF>
+static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    const FmView ix = fm_view(A);
+    const uint32_t n_seedp = ctx_get(s_w.n_seedp);
+    const uint32_t seedp_off = A->sc.off_seedp, tasks_off = A->sc.off_tasks;
+    const uint32_t p_min_map_len = A->P.min_map_len;
+    const float p_min_mean_conf = A->P.min_mean_conf, p_min_top_conf = A->P.min_top_conf;
+    PhaseClock<PROF> clk;
+    uint32_t c_sa = 0, c_lf = 0;
+    Tracker T;
+    {
+        const Tracker v = s_T;      // uniform values: back into scalar registers
+        T.n = uniform32(v.n); T.n_lens = uniform32(v.n_lens); T.max1 = uniform32(v.max1); T.max2 = uniform32(v.max2);
+        T.status = uniform32(v.status); T.n_leaves = uniform32(v.n_leaves); T.n_alloc = uniform32(v.n_alloc);
+        T.len_sum = __uint_as_float(uniform32(__float_as_uint(v.len_sum)));
+        T.mm.ref_st = uniform64(v.mm.ref_st); T.mm.rstart = uniform64(v.mm.rstart); T.mm.rend = uniform64(v.mm.rend);
+        T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
+    }
+    const TrackerMem TM = tracker_mem(A, sb);
+    uint32_t top_n = 0;
+    for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
+        const uint32_t si = sb0 + (uint32_t)lane;
+        SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
+        if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
+        uint32_t ttot;
+        const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
+        // one task per FM row of a seed path: the row (40 bits) with the seed's event (16 bits) and move count on top,
+        // so that the serial part below gets everything about 64 seeds from one coalesced load
+        {
+            const uint64_t tag = ((uint64_t)(sp.evt & 0xFFFFu) << 40) | ((uint64_t)sp.ref_len << 56);
+            for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), (sp.start + j) | tag);
+        }
+        wave_sync();
+        for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
+            const uint32_t ti = t0 + (uint32_t)lane;
+            if (ti < ttot) {
+                uint32_t lf;
+                const uint64_t v = gld<uint64_t>(sb, tasks_off + (ti << 3));
+                const uint64_t row = v & ((1ull << 40) - 1ull);
+                const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
+                gst(sb, tasks_off + (ti << 3), (ix.seq_len - sa) | (v & ~((1ull << 40) - 1ull)));    // sa_end, mapper.cpp:678
+                c_sa++;
+                c_lf += lf;
+            }
+        }
+        wave_sync();
+        clk.end(5, lane);
+        // SeedTracker::add_seed in the reference's order = task order (seed paths in list order, their rows ascending)
+        for (uint32_t t0 = 0; t0 < ttot && !T.status; t0 += WAVE) {
+            const uint32_t nt = ttot - t0 < WAVE ? ttot - t0 : WAVE;
+            const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
+            for (uint32_t j = 0; j < nt; ++j) {
+                const uint64_t v = uniform64(bcast64(mine, (int)j));     // scalar, as every argument of add_seed must be
+                add_seed(T, TM, p_min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane, top_n);
+            }
+        }
+        clk.end(6, lane);
+    }
+    // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
+    bool conf = false;
+    if (T.mm.total_len >= p_min_map_len && T.n_lens >= 2) {
+        const float mean_len = __fdiv_rn(T.len_sum, (float)T.n);
+        const float second_len = (float)T.max2;
+        const float ml = (float)T.mm.total_len;
+        conf = (p_min_mean_conf > 0 && __fdiv_rn(ml, mean_len) >= p_min_mean_conf) ||
+               (p_min_top_conf > 0 && __fdiv_rn(ml, second_len) >= p_min_top_conf);
+    }
+    wave_sync();
+    if (lane == 0) { s_T = T; s_w.tstatus |= T.status; s_w.conf = conf ? 1u : 0u; }
+    wave_sync();
+    return (uint64_t)c_sa | ((uint64_t)c_lf << 32);
+}
+
+// k_map: the per-read path-forest search, one WAVEFRONT per read, persistent over a read queue.
+// PROF: per-phase shader-clock counters (unc_mapper_last_phase_cycles); the plain instantiation carries none of it
+// NARROW: the index allows 64-bit sort keys and 32-bit rows (DevIndex::key_len_bits > 0: E. coli, chr20): the children's keys
+// leave phase E as sorted runs and are merged; the other instantiation (human-sized references) sorts 128-bit keys
+template <bool PROF, bool NARROW>
+__global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
+    const kargs_t A = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();     // the argument block itself: Aval is its only member
+    (void)Aval;
     const int lane = lane_id();
     const uint64_t wave_t0 = (uint64_t)wall_clock64();
-    const DevIndex &ix = A.ix;
-    const unc_params_t &P = A.P;
-    const uint32_t max_paths = A.sc.max_paths;
-    const bool sliced = A.sched.ctl != nullptr;      // batch mode with time slices (see DevSched)
-
-    const float thr_lane = ix.thresholds[lane];      // lane l keeps prob_threshes_[l]
-    const float source_prob = ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
-    const uint32_t klb = NARROW ? ix.key_len_bits : 0u;   // 0: 128-bit sort keys; else narrow 64-bit keys (see sort_regs64)
-    const uint32_t kvalid = ix.kmer_valid[lane];     // bit j: k-mer j*64+lane occurs in the reference
+    const bool sliced = A->sched.ctl != nullptr;      // batch mode with time slices (see DevSched)
+    const uint32_t resume = A->resume;
 
     for (;;) {
         // ---------------- fetch or resume a read ----------------
@@ -1064,26 +1841,27 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         uint32_t tstatus = 0;                        // UNC_READ_* bits (mirror of the tracker's status)
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
-        uint64_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t slot = (A.resume && A.slot_map) ? A.slot_map[blockIdx.x] : blockIdx.x;
+        uint32_t slot = (resume && A->slot_map) ? A->slot_map[blockIdx.x] : blockIdx.x;
         bool restore = false;
         if (sliced) {
             // task = a new read in a free slot while both exist, else the longest-parked read
             uint32_t kind = 0, tslot = 0, tread = 0;
             if (lane == 0) {
-                SchedCtl *const sc = A.sched.ctl;
+                SchedCtl *const sc = A->sched.ctl;
+                SchedCell *const free_cells = A->sched.free_cells, *const park_cells = A->sched.park_cells;
+                const uint32_t cap_mask = A->sched.cap_mask, n_reads = A->rd.n_reads;
                 for (int tries = 0; tries < 4096 && !kind; ++tries) {
-                    const bool more = ld_acq(&sc->next_read) < A.rd.n_reads;
+                    const bool more = ld_acq(&sc->next_read) < n_reads;
                     if (more) {
-                        const uint32_t fs = sched_pop(&sc->freeq, A.sched.free_cells, A.sched.cap_mask);
+                        const uint32_t fs = sched_pop(&sc->freeq, free_cells, cap_mask);
                         if (fs != SCHED_EMPTY) {
                             const uint32_t t = atomicAdd(&sc->next_read, 1u);
-                            if (t < A.rd.n_reads) { kind = 1; tslot = fs; tread = t; }
-                            else sched_push(&sc->freeq, A.sched.free_cells, A.sched.cap_mask, fs);
+                            if (t < n_reads) { kind = 1; tslot = fs; tread = t; }
+                            else sched_push(&sc->freeq, free_cells, cap_mask, fs);
                         }
                     }
                     if (!kind) {
-                        const uint32_t ps = sched_pop(&sc->parkq, A.sched.park_cells, A.sched.cap_mask);
+                        const uint32_t ps = sched_pop(&sc->parkq, park_cells, cap_mask);
                         if (ps != SCHED_EMPTY) { kind = 2; tslot = ps; }
                     }
                     // reads left but every slot is in another wavefront's hands right now: wait for one to come back
@@ -1097,34 +1875,29 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         }
 
         // everything this read owns hangs off ONE uniform pointer; regions are 32-bit byte offsets (DevScratch)
-        char *const sb = A.sc.base + (size_t)slot * A.sc.slot_bytes;
-        const uint32_t ukeys_off = A.sc.off_keys, skeys_off = A.sc.off_keys + A.sc.keys_cap * (uint32_t)sizeof(SortKey);
-        const uint32_t seedp_off = A.sc.off_seedp, tasks_off = A.sc.off_tasks;
-        SlotState *const st = reinterpret_cast<SlotState *>(sb + A.sc.off_state);
-        auto tracker_mem = [&]() {                   // built where it is used: its pointers need not live across the phases
-            TrackerMem M;
-            M.sb = sb; M.off_dir = A.sc.off_cl_dir; M.off_chunks = A.sc.off_cl_chunks; M.max_leaves = A.sc.max_clusters / 16;
-            M.pool = A.pool;
-            return M;
-        };
+        const gptr_t sb = (gptr_t)A->sc.base + (size_t)slot * A->sc.slot_bytes;
+        UNC_AS_GLOBAL SlotState *const st = reinterpret_cast<UNC_AS_GLOBAL SlotState *>(sb + A->sc.off_state);
+        if constexpr (PROF) { if (lane < 12) s_cyc[lane] = 0; }
 
-        const bool fresh = A.resume && A.rd.new_read && A.rd.new_read[blockIdx.x];   // first chunk of a read
-        if ((A.resume && !fresh) || restore) {
+        const bool fresh = resume && A->rd.new_read && A->rd.new_read[blockIdx.x];   // first chunk of a read
+        if ((resume && !fresh) || restore) {
             r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             n_surv_par = uniform32(st->n_surv);
             T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
-            T.status = st->status; T.len_sum = st->len_sum; T.mm = st->max_map; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
+            T.status = st->status; T.len_sum = st->len_sum; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
+            T.mm.ref_st = st->max_map.ref_st; T.mm.rstart = st->max_map.rstart; T.mm.rend = st->max_map.rend;
+            T.mm.evt_st = st->max_map.evt_st; T.mm.evt_en = st->max_map.evt_en; T.mm.total_len = st->max_map.total_len;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
             event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
-            if (restore) { if constexpr (PROF) { for (int i = 0; i < 12; ++i) cyc[i] = st->cyc[i]; } }
+            if (restore) { if constexpr (PROF) { if (lane < 12) s_cyc[lane] = st->cyc[lane]; } }
             else if (uniform32(st->done)) break;
-        } else if (A.resume) {
+        } else if (resume) {
             r = blockIdx.x;
             {   // a new read takes the channel over: what the previous one still holds goes back to the pool
                 Tracker old;
                 old.n_alloc = uniform32(st->n_alloc);
-                tracker_release(old, tracker_mem(), lane);
+                tracker_release(old, tracker_mem(A, sb), lane);
             }
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
@@ -1133,11 +1906,11 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         } else {
             if (!sliced) {
                 uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(A.next_read, 1u);
+                if (lane == 0) t = atomicAdd(A->next_read, 1u);
                 r = bcast32(t, 0);
-                if (r >= A.rd.n_reads) break;
+                if (r >= A->rd.n_reads) break;
             }
-            if (A.read_list) r = uniform32(A.read_list[r]);
+            if (A->read_list) r = uniform32(A->read_list[r]);
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
@@ -1145,668 +1918,61 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
         }
         tstatus = uniform32(T.status);
         wave_sync();
-        if (lane == 0) s_T = T;
+        if (lane == 0) {
+            s_T = T;
+            s_w.event_i = event_i; s_w.n_parents = n_parents; s_w.cur = cur; s_w.n_surv_par = n_surv_par; s_w.tstatus = tstatus;
+        }
         wave_sync();
-        const unc_evt_info_t inf = A.rd.info[r];
-        const uint32_t n_events = inf.n_events;
-        const float scale = inf.scale, shift = inf.shift;
-        const float *means = A.rd.means + A.rd.moff[r];
-        const uint32_t ring_mod = A.rd.ring_mod, ring_r0 = ring_mod ? A.rd.ring0[r] : 0u;
+        const uint32_t n_events = A->rd.info[r].n_events;
+        const float scale = A->rd.info[r].scale, shift = A->rd.info[r].shift;
+        const UNC_AS_GLOBAL float *const means = (const UNC_AS_GLOBAL float *)A->rd.means + A->rd.moff[r];
+        const uint32_t ring_mod = A->rd.ring_mod, ring_r0 = ring_mod ? A->rd.ring0[r] : 0u;
+        const uint32_t max_events = A->P.max_events, max_steps = A->max_steps;
 #define MEAN_AT(e) means[ring_mod ? (ring_r0 + (e)) % ring_mod : (e)]
 
         uint32_t done = 0, steps = 0;
         float next_mean = event_i < n_events ? MEAN_AT(event_i) : 0.0f;
-        while (!done && steps < A.max_steps) {
+        while (!done && steps < max_steps) {
             // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
-            if (ring_mod && event_i >= n_events && event_i < P.max_events && !tstatus) break;   // chunk mapped: park
-            if (event_i >= n_events || event_i >= P.max_events || tstatus) { done = 2; break; }
+            if (ring_mod && event_i >= n_events && event_i < max_events && !tstatus) break;   // chunk mapped: park
+            if (event_i >= n_events || event_i >= max_events || tstatus) { done = 2; break; }
             ++steps;
 
-            // ---------------- P: match log-probs ----------------
-            uint64_t tk = PROF ? (uint64_t)clock64() : 0ull, tn = 0;
-#ifdef UNC_V_SORTPROF
-#define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[(i) >= 8 ? 1 : (i)] += tn - tk; tk = tn; } else (void)tn
-#define SPHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
-#else
-#define PHASE_END(i) if constexpr (PROF) { tn = (uint64_t)clock64(); cyc[i] += tn - tk; tk = tn; } else (void)tn
-#define SPHASE_END(i) (void)tn
-#endif
+            PhaseClock<PROF> clk;
             const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);   // Normalizer::at
             if (event_i + 1 < n_events) next_mean = MEAN_AT(event_i + 1);
-#pragma unroll 4
-            for (int j = 0; j < NKMER / WAVE; ++j) {
-                const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
-                const float mu = ix.model[k], v2 = ix.model[NKMER + k], ld = ix.model[2 * NKMER + k];
-                const float d = __fsub_rn(level, mu);
-                const double q = -((double)d * (double)d) / (double)v2;
-                s_probs[k] = (float)(q - (double)ld);
+            if (lane == 0) gst(sb, A->sc.off_levels + ((event_i & (LEVEL_RING - 1u)) << 2), level);   // (read back 22 events on: PathRec)
+            phase_P(A, level, lane);
+            clk.end(0, lane);
+            c_nbr += phase_E<PROF, NARROW>(A, sb, lane);
+            clk.reset();       // (phase E keeps its own clock: parts 8..11, the rest in 1)
+            if (ctx_get(s_w.nchild) > 0) {
+                phase_S<NARROW>(A, sb, lane);
+                clk.end(2, lane);
+                phase_W<NARROW>(A, sb, lane);
+                clk.end(3, lane);
             }
-            wave_sync();
-
-            // byte offsets (inside the slot) of this event's parent / child records and parent-order lists
-            const uint32_t par_off = A.sc.off_paths + cur * (max_paths << 6), chd_off = A.sc.off_paths + (cur ^ 1u) * (max_paths << 6);
-            const uint32_t pord_off = A.sc.off_order + cur * (max_paths << 2), nord_off = A.sc.off_order + (cur ^ 1u) * (max_paths << 2);
-            const uint32_t g_sl = event_i & (MAT_PERIOD - 1u), p_sl = (event_i - 1u) & (MAT_PERIOD - 1u);   // recent[] / second[] slots
-
-            PHASE_END(0);
-            // ---------------- E: extend parents ----------------
-            uint32_t nchild = 0, n_seedp = 0;
-            bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort below)
-            // narrow keys: keys filed so far in each run (stays / moves by base of the sorted survivors; children of sources)
-            uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
-            const uint32_t run_bytes = max_paths << 3;
-            // parent index list and record headers are fetched one / two passes ahead of their use
-            uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
-            uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
-            uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
-            if ((uint32_t)lane < n_parents) {
-                q0c = gld<uint4>(sb, par_off + (phys_cur << 6)); q1c = gld<uint4>(sb, par_off + (phys_cur << 6) + 16u);
-            }
-            for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
-                const uint32_t pi = base + (uint32_t)lane;
-                const bool have = pi < n_parents;
-                const uint4 q0 = q0c, q1 = q1c;
-                // the sums this parent hands down: needed only when its children are written, after the FM round trip
-                float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f), q3 = q2;
-                if (have) { q2 = gld<float4>(sb, par_off + (phys_cur << 6) + 32u); q3 = gld<float4>(sb, par_off + (phys_cur << 6) + 48u); }
-                phys_cur = phys_nxt;
-                if (pi + WAVE < n_parents) {
-                    q0c = gld<uint4>(sb, par_off + (phys_nxt << 6)); q1c = gld<uint4>(sb, par_off + (phys_nxt << 6) + 16u);
-                }
-                if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * WAVE) << 2));
-                uint32_t pmoves = 0, pmeta = 0;
-                uint64_t pstart = 1, pend = 1;
-                float pprob = 0.0f;
-                if (have) {
-                    pstart = ((uint64_t)q0.y << 32) | q0.x;
-                    pend = ((uint64_t)q0.w << 32) | q0.z;
-                    pmoves = q1.x; pprob = __uint_as_float(q1.y); pmeta = q1.z;
-                }
-                const uint64_t plen_fm = pend - pstart + 1;
-                const float thr = __shfl(thr_lane, __clzll((long long)plen_fm));   // get_prob_thresh, :161-167
-                const uint32_t kmer = pmeta & META_KMER_MASK;
-                const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
-                const bool stay_ok = have && stays < P.max_consec_stay && s_probs[kmer] >= thr;
-                // kmer_neighbor (bp.hpp:105-108): the four successors ((kmer << 2) & KMASK) | b are neighbours in the table
-                const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
-                uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
-                if (!have) mask = 0;
-                s_pstart[lane] = pstart; s_pend[lane] = pend; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta; s_pring[lane] = q1.w;
-                const uint32_t ncand = (uint32_t)__popc(mask);
-                uint32_t ctot;
-                const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
-                {
-                    uint32_t w = coff;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b)
-                        if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
-                }
-                wave_sync();
-                PHASE_END(8);
-                // FM look-ups, every lane busy
-                for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
-                    const uint32_t ci = c0 + (uint32_t)lane;
-                    if (ci < ctot) {
-                        const uint32_t cd = s_cand[ci];
-                        uint64_t ns, ne;
-                        fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
-                        s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
-                    }
-                }
-                wave_sync();
-                PHASE_END(9);
-                // children per parent, in the reference's order: stay, then bases 0..3
-                // bit j: j-th candidate of this lane has a non-empty range (four unconditional reads; the staging buffer
-                // extends past the result slots, and whatever lies beyond this lane's candidates is masked off)
-                uint32_t vmask = (s_res[coff] != 0 ? 1u : 0u) | (s_res[coff + 1] != 0 ? 2u : 0u) | (s_res[coff + 2] != 0 ? 4u : 0u) |
-                                 (s_res[coff + 3] != 0 ? 8u : 0u);
-                vmask &= (1u << ncand) - 1u;
-                const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
-                uint32_t chtot;
-                const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
-                const uint32_t room = max_paths - nchild;                 // > 0 here
-                const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
-                const bool visited = have && choff < room;                // reached before the buffer filled
-                // work counter: the get_neighbor calls the reference makes (it stops at the cut-off)
-                if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += ncand;   // every call precedes the cut-off
-                else
-                    for (uint32_t j = 0; j < ncand; ++j)
-                        if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
-                if constexpr (NARROW) {
-                    // creation position (inside this pass) of this lane's child of each type: stay, bases 0..3
-                    const bool is_src = pi >= n_surv_par;          // children of sources: the unsorted run
-                    uint32_t cpos[5], cres[5];
-                    bool ex[5];
-                    ex[0] = stay_ok; cpos[0] = choff; cres[0] = 0;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        const uint32_t jj = (uint32_t)__popc(mask & ((1u << b) - 1u));
-                        ex[b + 1] = ((mask >> b) & 1u) && ((vmask >> jj) & 1u);
-                        cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << jj) - 1u));
-                        cres[b + 1] = coff + jj;
-                    }
-#pragma unroll
-                    for (uint32_t t = 0; t < 5; ++t) ex[t] = ex[t] && cpos[t] < nwrite;      // the max_paths cut-off
-                    const bool pass_has_surv = base < n_surv_par, pass_has_src = base + WAVE > n_surv_par;
-                    uint32_t kp[5] = {0, 0, 0, 0, 0};
-                    if (pass_has_surv) {
-                        // a run takes at most one child per parent: position = keys filed + fitting children of earlier lanes
-                        const uint64_t m0 = __ballot(ex[0] && !is_src), m1 = __ballot(ex[1] && !is_src), m2 = __ballot(ex[2] && !is_src),
-                                       m3 = __ballot(ex[3] && !is_src), m4 = __ballot(ex[4] && !is_src);
-                        kp[0] = scnt0 + (uint32_t)prefix_popc(m0); kp[1] = scnt1 + (uint32_t)prefix_popc(m1);
-                        kp[2] = scnt2 + (uint32_t)prefix_popc(m2); kp[3] = scnt3 + (uint32_t)prefix_popc(m3);
-                        kp[4] = scnt4 + (uint32_t)prefix_popc(m4);
-                        scnt0 += (uint32_t)__popcll(m0); scnt1 += (uint32_t)__popcll(m1); scnt2 += (uint32_t)__popcll(m2);
-                        scnt3 += (uint32_t)__popcll(m3); scnt4 += (uint32_t)__popcll(m4);
-                    }
-                    if (pass_has_src) {
-                        // the unsorted run keeps creation order
-                        const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
-                        uint32_t xtot;
-                        uint32_t xo = scntx + excl_sum_bits<3>(nfit, &xtot);
-                        if (is_src) {
-#pragma unroll
-                            for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
-                        }
-                        scntx += xtot;
-                    }
-#pragma unroll
-                    for (uint32_t t = 0; t < 5; ++t)
-                        if (ex[t]) {
-                            s_cdesc[cpos[t]] = (uint32_t)lane | (t << 6) | (cres[t] << 9) | (is_src ? 1u << 18 : 0u);
-                            s_ckpos[cpos[t]] = (uint16_t)kp[t];
-                        }
-                } else {
-                    uint32_t w = choff;
-                    if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
-                    uint32_t jj = 0;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        if (mask & (1u << b)) {
-                            if (vmask & (1u << jj)) {
-                                if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((coff + jj) << 9);
-                                ++w;
-                            }
-                            ++jj;
-                        }
-                    }
-                }
-                s_prec[lane] = q2; s_psec[lane] = q3;
-                // dead ends -> update_seeds(prev_path, true), :513-519 / is_seed_valid :842-863
-                bool ended_seed = false;
-                uint32_t e_count = 0, e_mc = 0;
-                if (visited && nch == 0 && !(pmeta & META_SA_CHECKED)) {
-                    const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
-                    const uint32_t mc = (uint32_t)__popc(pmoves);
-                    const bool base_ok = plen == P.seed_len && pprob >= P.min_seed_prob;
-                    const bool uniq = plen_fm == 1 && (pmoves & 1u) == 1u &&
-                                      (float)(plen - mc) <= __fmul_rn(P.max_stay_frac, (float)P.seed_len);
-                    const bool rep = plen_fm <= (uint64_t)P.max_rep_copy && mc >= P.min_rep_len;
-                    ended_seed = base_ok && (uniq || rep);
-                    e_count = (uint32_t)plen_fm;
-                    e_mc = mc;
-                }
-                {
-                    const uint64_t em = __ballot(ended_seed);
-                    const uint32_t pos = n_seedp + (uint32_t)prefix_popc(em);
-                    if (ended_seed) {
-                        if (pos < A.sc.max_seed_paths) {
-                            SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
-                            gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
-                        }
-                    }
-                    n_seedp += (uint32_t)__popcll(em);
-                }
-                wave_sync();
-                PHASE_END(10);
-                // one lane per child: everything it needs of its parent sits in LDS, the 64-byte record and the sort key go out
-                for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
-                    const uint32_t li = l0 + (uint32_t)lane;
-                    if (li < nwrite) {
-                        const uint32_t d = s_cdesc[li];
-                        const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (d >> 9) & 511u;
-                        const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
-                        float4 rec = s_prec[pl];
-                        const float4 sec = s_psec[pl];
-                        const float last = f4_get(rec, p_sl), second = f4_get(sec, g_sl);
-                        const uint32_t pk = pmt & META_KMER_MASK;
-                        uint64_t cs, ce;
-                        uint32_t ck, mv;
-                        if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
-                        else {
-                            const uint64_t pr = s_res[ci];
-                            cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull;
-                            ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
-                        }
-                        // the k-mer's own range, for the boundary test after the record is out: requested here, without a
-                        // condition, so that the record arithmetic below runs while it is on its way
-                        const ulonglong2 kr = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[ck];
-                        SortKey key;
-                        const uint32_t gi = nchild + li;
-                        const ChildHdr c = make_child(pmv, pmt, last, second, cs, ce, ck, s_probs[ck], mv, P, gi, klb, key);
-                        f4_set(rec, g_sl, c.appended);
-                        const uint32_t co = chd_off + (gi << 6);
-                        gst(sb, co, make_uint4((uint32_t)cs, (uint32_t)(cs >> 32), (uint32_t)ce, (uint32_t)(ce >> 32)));
-                        gst(sb, co + 16u, make_uint4(c.moves, __float_as_uint(c.seed_prob), c.meta, s_pring[pl]));
-                        gst(sb, co + 32u, rec);
-                        gst(sb, co + 48u, sec);
-                        if constexpr (NARROW) {
-                            const uint32_t run = (d >> 18) ? 5u : type;
-                            gst(sb, A.sc.off_streams + run * run_bytes + ((uint32_t)s_ckpos[li] << 3), key.a);
-                            gst(sb, A.sc.off_info + (gi << 3), key.b);
-                            if (cs == ce && (cs == kr.x || cs == kr.y)) bchild = true;
-                        } else {
-                            gst(sb, ukeys_off + (gi << 4), key);
-                        }
-                    }
-                }
-                nchild += nwrite;
-                wave_sync();
-                PHASE_END(11);
-            }
-            if (n_seedp > A.sc.max_seed_paths) { tstatus |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
-            wave_sync();
-
-            PHASE_END(1);
-            // ---------------- S + W: sort children, prune duplicates, gap sources ----------------
-            const uint32_t n = nchild;
-            uint32_t n_surv = 0, n_src = 0;
-            if (n > 0) {
-                SortKey *const ukeys = reinterpret_cast<SortKey *>(sb + ukeys_off), *const skeys = reinterpret_cast<SortKey *>(sb + skeys_off);
-                uint64_t *const skeys64 = reinterpret_cast<uint64_t *>(skeys);
-                const uint64_t *const infow = reinterpret_cast<const uint64_t *>(sb + A.sc.off_info);   // narrow keys: info words by creation index
-                uint32_t kl = klb;     // key mode of THIS event
-                if constexpr (NARROW) {
-                    const uint64_t *const info = reinterpret_cast<const uint64_t *>(sb + A.sc.off_info);
-                    const uint32_t str_off = A.sc.off_streams, sk_off = skeys_off;
-                    uint32_t nx = scntx;
-                    bool sorted_ok = false;
-                    if (n > MERGE_MIN) {
-                        // moves of one base: ascending but for the odd pair of nested parents (repair_run); then the unsorted
-                        // run is sorted, merged with the moves, and the result with the stays
-                        const uint32_t x_off = str_off + 5u * run_bytes;
-                        if constexpr (MERGE_REPAIR) {
-                        if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); scnt1 -= v; nx += v; }
-                        if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); scnt2 -= v; nx += v; }
-                        if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); scnt3 -= v; nx += v; }
-                        if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); scnt4 -= v; nx += v; }
-                        }
-                        wave_sync();
-                        SPHASE_END(8);
-                        if (nx > 1) {
-                            KeyArr<6> KX;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
-                            KX.n = nx;
-                            sort_any64(sb, KX, x_off, lane);          // in place
-                            wave_sync();
-                        }
-                        SPHASE_END(9);
-                        KeyArr<4> KM;       // the moves, base by base
-                        KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
-                        KM.n = KM.cum[3] + scnt4;
-#pragma unroll
-                        for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
-                        KeyArr<4> KB = KM;  // what the stays are merged with
-                        if (nx > 0) {
-                            if (KM.n > 0) {
-                                merge_runs<4, 1>(sb, KM, ka_single(x_off, nx), A.sc.off_tmp, s_e, lane, 0u);
-                                wave_sync();
-                                KB.adj[0] = A.sc.off_tmp;
-                            } else KB.adj[0] = x_off;
-                            KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
-                            KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
-                        }
-                        SPHASE_END(10);
-                        sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, s_e, lane, 1u) != 0u;
-                        wave_sync();
-                        SPHASE_END(11);
-                    }
-                    if (!sorted_ok) {
-                        // few children, or runs that were not ascending after all: the bitonic network over all of them
-                        KeyArr<6> K6;
-                        const uint32_t c[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
-                        uint32_t cum = 0;
-#pragma unroll
-                        for (uint32_t r = 0; r < 6; ++r) { K6.cum[r] = cum; K6.adj[r] = str_off + r * run_bytes - (cum << 3); cum += c[r]; }
-                        K6.n = cum;
-                        sort_any64(sb, K6, sk_off, lane);
-                    }
-                    // BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can
-                    // share a boundary row and two children with the SAME one-row range may carry DIFFERENT k-mers.  The
-                    // reference then walks them in seed_prob order (mapper.cpp:543-563 runs per position), which the narrow
-                    // key cannot express: such an event (rare) is re-sorted with the full 128-bit keys.
-                    if (__any(bchild)) {
-                        wave_sync();
-                        bool mixed = false;
-                        for (uint32_t base = 0; base + 1 < n; base += WAVE) {
-                            const uint32_t i = base + (uint32_t)lane;
-                            if (i + 1 < n) {
-                                const uint64_t ki = skeys64[i], kn = skeys64[i + 1];
-                                if ((ki >> 16) == (kn >> 16) && ((info[ki & 0xFFFFu] ^ info[kn & 0xFFFFu]) & META_KMER_MASK)) mixed = true;
-                            }
-                        }
-                        if (__any(mixed)) {
-                            for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
-                                const uint64_t k = skeys64[i], ri = k >> 16;
-                                SortKey w;
-                                w.a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
-                                w.b = info[k & 0xFFFFu];
-                                ukeys[i] = w;
-                            }
-                            kl = 0;
-                            wave_sync();
-                        }
-                    }
-                }
-                if (!kl) {
-                    if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
-                    else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
-                    else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
-                    else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
-                    else sort_hybrid(ukeys, skeys, n, lane);
-                }
-                wave_sync();
-                PHASE_END(2);
-
-                uint32_t carry_kmer = NKMER;
-                uint64_t carry_U = 0, carry_range = ~0ull, carry_w = 0;
-                const uint32_t room = max_paths - n;   // sources that still fit
-                // narrow keys: the sorted keys of the pass after next and the info words (seed_prob, idx, flags, k-mer) they
-                // point to for the next pass are fetched while this pass is worked on; a lane's successor comes from
-                // its neighbour lane, the last lane's from the next pass
-                uint64_t kq0 = ~0ull, kq1 = ~0ull, bq0 = 0, bq1 = 0;
-                if (kl) {
-                    if ((uint32_t)lane < n) kq0 = skeys64[lane];
-                    if ((uint32_t)lane + WAVE < n) kq1 = skeys64[lane + WAVE];
-                    if ((uint32_t)lane < n) bq0 = infow[kq0 & 0xFFFFu];
-                    if ((uint32_t)lane + WAVE < n) bq1 = infow[kq1 & 0xFFFFu];
-                }
-                // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
-                ulonglong2 krq = make_ulonglong2(1ull, 0ull);
-                if (kl && (uint32_t)lane < n) {
-                    const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
-                    if (s_probs[km0] >= source_prob) krq = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[km0];
-                }
-                for (uint32_t base = 0; base < n; base += WAVE) {
-                    const uint32_t i = base + (uint32_t)lane;
-                    const bool have = i < n;
-                    const bool has_next = i + 1 < n;
-                    uint64_t start, end, nstart, sb_;     // sb_: info word of the child that survives at this position
-                    uint32_t kmer, nkmer;
-                    bool dup;
-                    ulonglong2 krc = make_ulonglong2(1ull, 0ull);
-                    if (kl) {
-                        const uint64_t ki = kq0, bi = bq0;
-                        uint64_t kn = (uint64_t)__shfl((unsigned long long)ki, (lane + 1) & 63);
-                        uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
-                        const uint64_t kf = bcast64(kq1, 0), bf = bcast64(bq1, 0);
-                        if (lane == WAVE - 1) { kn = kf; bn = bf; }
-                        kq0 = kq1; bq0 = bq1;
-                        kq1 = i + 2 * WAVE < n ? skeys64[i + 2 * WAVE] : ~0ull;
-                        krc = krq;
-                        krq = make_ulonglong2(1ull, 0ull);
-                        if (i + WAVE < n) {
-                            const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
-                            if (s_probs[kmn] >= source_prob) krq = reinterpret_cast<const ulonglong2 *>(ix.kmer_ranges)[kmn];
-                        }
-                        const uint64_t ri = ki >> 16, rn = kn >> 16;
-                        start = ri >> kl; end = start + (ri & ((1ull << kl) - 1ull));
-                        nstart = rn >> kl;
-                        kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
-                        nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
-                        dup = has_next && rn == ri;
-                        // among equal ranges the reference keeps the highest (seed_prob, creation order): a running max of
-                        // the info words over each run, read off at the run's last position
-                        uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
-                        if (lane == 0) pr = carry_range;
-                        const bool rhead = !have || ri != pr;
-                        sb_ = seg_incl_max64(bi, rhead);
-                        const uint64_t rheads = __ballot(rhead);
-                        if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb_) sb_ = carry_w;
-                        const uint32_t nvv = n - base < WAVE ? n - base : WAVE;
-                        carry_range = bcast64(ri, (int)nvv - 1);
-                        carry_w = bcast64(sb_, (int)nvv - 1);
-                    } else {
-                        SortKey ki, kn;
-                        ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
-                        if (have) ki = skeys[i];
-                        if (has_next) kn = skeys[i + 1];
-                        start = ki.a >> KEY_LEN_BITS; end = start + (ki.a & KEY_LEN_MASK);
-                        nstart = kn.a >> KEY_LEN_BITS;
-                        kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
-                        nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
-                        dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
-                        sb_ = ki.b;                              // sorted by seed_prob inside the run: the last one survives
-                    }
-                    const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
-                    uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
-                    if (lane == 0) pk = carry_kmer;
-                    const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
-                    const bool next_same = has_next && nkmer == kmer;
-                    const bool psrc = have && s_probs[have ? kmer : 0] >= source_prob;
-                    // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
-                    uint64_t U = seg_incl_max64(have ? end + 1 : 0, first || !have);
-                    const uint64_t heads = __ballot(first || !have);
-                    const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
-                    if (headless && carry_U > U) U = carry_U;
-                    uint64_t kr_s = 1, kr_e = 0;
-                    if (kl) {
-                        if (first && psrc) kr_s = krc.x;
-                        if (have && !dup && psrc && !next_same) kr_e = krc.y;
-                    } else {
-                        if (first && psrc) kr_s = ix.kmer_ranges[2 * kmer];
-                        if (have && !dup && psrc && !next_same) kr_e = ix.kmer_ranges[2 * kmer + 1];
-                    }
-                    const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
-                    const uint64_t c_s = U, c_e = next_same ? nstart - 1 : kr_e;                   // :579-589
-                    const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
-                    uint32_t stot;
-                    const uint32_t soff = excl_sum_bits<2>((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
-                    const uint32_t q0 = n_src + soff;                      // sources appended before this child
-                    const bool not_full0 = q0 < room;                      // next_path != end at step A
-                    if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
-                    if (a_valid && not_full0) write_source(sb + chd_off, n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
-                    const uint32_t qc = q0 + (a_valid ? 1u : 0u);
-                    if (c_valid && qc < room) write_source(sb + chd_off, n + qc, c_s, c_e, kmer, s_probs[kmer]);
-                    // survivors keep sorted order in the next parent list
-                    const bool surv = have && !dup;
-                    const uint64_t sm = __ballot(surv);
-                    if (surv) gst(sb, nord_off + ((n_surv + (uint32_t)prefix_popc(sm)) << 2), idx);
-                    n_surv += (uint32_t)__popcll(sm);
-                    // update_seeds(child, false), :601 -- validity was decided at creation
-                    const bool sv = surv && (sb_ & KEYB_SEED_FLAG);
-                    const uint64_t svm = __ballot(sv);
-                    if (sv) {
-                        const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
-                        // path.sa_checked_ = true (no value returned: no round trip)
-                        atomicOr(reinterpret_cast<uint32_t *>(sb + chd_off + (idx << 6) + 24u), META_SA_CHECKED);
-                        if (pos < A.sc.max_seed_paths) {
-                            SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
-                            sp.ref_len = (uint32_t)(sb_ >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
-                            gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
-                        }
-                    }
-                    n_seedp += (uint32_t)__popcll(svm);
-                    // carries into the next pass
-                    const uint32_t nv = n - base < WAVE ? n - base : WAVE;
-                    carry_kmer = bcast32(kmer, (int)nv - 1);
-                    carry_U = bcast64(U, (int)nv - 1);
-                    n_src += stot;
-                    if (n_src > room) n_src = room;
-                    if (kl) bq1 = i + 2 * WAVE < n ? infow[kq1 & 0xFFFFu] : 0ull;
-                }
-                if (n_seedp > A.sc.max_seed_paths) { tstatus |= UNC_READ_SEED_OVERFLOW; n_seedp = A.sc.max_seed_paths; }
-            }
-            wave_sync();
-
-            PHASE_END(3);
-            // ---------------- F: remaining full-range sources, :605-624 ----------------
-            // sources_added_[k] for k = j*64 + lane lives in bit j of this lane's 16-bit field (two lanes per word).
-            // Pass 1 decides, in k-mer order, which k-mers get a full-range source and where (pure ALU + LDS);
-            // pass 2 fetches their ranges and writes the records, one lane per source, in one memory round trip.
-            uint32_t ent = n + n_src;
-            {
-                const uint32_t ent0 = ent;
-                const uint32_t myflags = (s_flags[lane >> 1] >> ((lane & 1) << 4)) & 0xFFFFu;
-                uint32_t newflags = 0;
-#pragma unroll 4
-                for (int j = 0; j < NKMER / WAVE; ++j) {
-                    const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
-                    const uint32_t fl = (myflags >> j) & 1u;
-                    const bool cond = !fl && s_probs[k] >= source_prob && ((kvalid >> j) & 1u);
-                    const uint64_t m = __ballot(cond);
-                    const uint32_t before = ent + (uint32_t)prefix_popc(m);
-                    const bool exec = before < max_paths;           // loop header: next_path != end
-                    const bool app = cond && exec;
-                    if (app) s_list[before - ent0] = k;
-                    if (!exec && fl) newflags |= 1u << j;           // flags survive only past the cut-off
-                    ent += (uint32_t)__popcll(__ballot(app));
-                }
-                const uint32_t other = (uint32_t)__shfl_xor((int)newflags, 1);
-                wave_sync();
-                if (!(lane & 1)) s_flags[lane >> 1] = newflags | (other << 16);
-                for (uint32_t q = (uint32_t)lane; q < ent - ent0; q += WAVE) {
-                    const uint32_t k = s_list[q];
-                    write_source(sb + chd_off, ent0 + q, ix.kmer_ranges[2 * k], ix.kmer_ranges[2 * k + 1], k, s_probs[k]);
-                }
-            }
-            wave_sync();
-            const uint32_t nsrc_total = ent - n;
-            for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) gst(sb, nord_off + ((n_surv + q) << 2), n + q);
-            n_parents = n_surv + nsrc_total;
-            n_surv_par = n_surv;
-            cur ^= 1u;
-            wave_sync();
-
-            PHASE_END(4);
-            // ---------------- T: seeds ----------------
-            // (nothing to add: the tracker, and with it the confidence test below, is where the last event left it)
+            phase_F<NARROW>(A, sb, lane);
+            clk.end(4, lane);
+            // T: (nothing to add: the tracker, and with it the confidence test, is where the last event left it)
             bool conf = false;
-            if (n_seedp > 0 && !tstatus) {
-                Tracker T;
-                {
-                    const Tracker v = s_T;      // uniform values: back into scalar registers
-                    T.n = uniform32(v.n); T.n_lens = uniform32(v.n_lens); T.max1 = uniform32(v.max1); T.max2 = uniform32(v.max2);
-                    T.status = uniform32(v.status); T.n_leaves = uniform32(v.n_leaves); T.n_alloc = uniform32(v.n_alloc);
-                    T.len_sum = __uint_as_float(uniform32(__float_as_uint(v.len_sum)));
-                    T.mm.ref_st = uniform64(v.mm.ref_st); T.mm.rstart = uniform64(v.mm.rstart); T.mm.rend = uniform64(v.mm.rend);
-                    T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
-                }
-                const TrackerMem TM = tracker_mem();
-                DirEnt *const s_top = reinterpret_cast<DirEnt *>(s_e);      // the staging buffer of phase E is idle here
-                uint32_t top_n = 0;
-                for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
-                    const uint32_t si = sb0 + (uint32_t)lane;
-                    SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
-                    if (si < n_seedp) sp = gld<SeedPath>(sb, seedp_off + si * (uint32_t)sizeof(SeedPath));
-                    uint32_t ttot;
-                    const uint32_t toff = excl_sum_bits<7>(sp.count, &ttot);
-                    // one task per FM row of a seed path: the row (40 bits) with the seed's event (16 bits) and move count on top,
-                    // so that the serial part below gets everything about 64 seeds from one coalesced load
-                    {
-                        const uint64_t tag = ((uint64_t)(sp.evt & 0xFFFFu) << 40) | ((uint64_t)sp.ref_len << 56);
-                        for (uint32_t j = 0; j < sp.count; ++j) gst(sb, tasks_off + ((toff + j) << 3), (sp.start + j) | tag);
-                    }
-                    wave_sync();
-                    for (uint32_t t0 = 0; t0 < ttot; t0 += WAVE) {
-                        const uint32_t ti = t0 + (uint32_t)lane;
-                        if (ti < ttot) {
-                            uint32_t lf;
-                            const uint64_t v = gld<uint64_t>(sb, tasks_off + (ti << 3));
-                            const uint64_t row = v & ((1ull << 40) - 1ull);
-                            const uint64_t sa = ix.sa_dense ? fm_sa_dense(ix, row, &lf) : fm_sa(ix, row, &lf);
-                            gst(sb, tasks_off + (ti << 3), (ix.seq_len - sa) | (v & ~((1ull << 40) - 1ull)));    // sa_end, mapper.cpp:678
-                            c_sa++;
-                            c_lf += lf;
-                        }
-                    }
-                    wave_sync();
-                    PHASE_END(5);
-                    // SeedTracker::add_seed in the reference's order = task order (seed paths in list order, their rows ascending)
-                    for (uint32_t t0 = 0; t0 < ttot && !T.status; t0 += WAVE) {
-                        const uint32_t nt = ttot - t0 < WAVE ? ttot - t0 : WAVE;
-                        const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
-                        for (uint32_t j = 0; j < nt; ++j) {
-                            const uint64_t v = uniform64(bcast64(mine, (int)j));     // scalar, as every argument of add_seed must be
-                            add_seed(T, TM, P.min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane, s_top, top_n);
-                        }
-                    }
-                    PHASE_END(6);
-                }
-
-                // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
-                if (T.mm.total_len >= P.min_map_len && T.n_lens >= 2) {
-                    const float mean_len = __fdiv_rn(T.len_sum, (float)T.n);
-                    const float second_len = (float)T.max2;
-                    const float ml = (float)T.mm.total_len;
-                    conf = (P.min_mean_conf > 0 && __fdiv_rn(ml, mean_len) >= P.min_mean_conf) ||
-                           (P.min_top_conf > 0 && __fdiv_rn(ml, second_len) >= P.min_top_conf);
-                }
-                tstatus |= T.status;
-                wave_sync();
-                if (lane == 0) s_T = T;
-                wave_sync();
+            if (ctx_get(s_w.n_seedp) > 0 && !ctx_get(s_w.tstatus)) {
+                const uint64_t c = phase_T<PROF>(A, sb, lane);
+                clk.reset();   // (5 and 6 inside)
+                c_sa += (uint32_t)c; c_lf += c >> 32;
+                conf = ctx_get(s_w.conf) != 0;
             }
+            tstatus = ctx_get(s_w.tstatus);
             if (tstatus) { done = 2; }
             else if (conf) { done = 1; }
             else {
-                // ---------------- M: every 4th event the rings of the live paths are brought up to date (PathRec) ----------------
-                // Events g-3 .. g have left their sums in recent[0..3]; they go into ring slots (g-3 .. g) % 23 of a copy of
-                // the lineage's previous ring (the other half of the ring pool), and second[0..3] for the children of events
-                // g+1 .. g+4 are the ring's entries of events g-21 .. g-18.  A path without a ring is younger than four
-                // events: only its recent sums exist, nothing older is ever read.
-                if (g_sl == MAT_PERIOD - 1u) {
-                    const uint32_t op = (event_i >> 2) & 1u;
-                    const uint32_t oring_off = A.sc.off_rings + op * max_paths * (RING_FLOATS * 4u);
-                    const uint32_t nring_off = A.sc.off_rings + (op ^ 1u) * max_paths * (RING_FLOATS * 4u);
-                    const uint32_t rec_off = A.sc.off_paths + cur * (max_paths << 6);        // the next event's parents
-                    const uint32_t lst_off = A.sc.off_order + cur * (max_paths << 2);
-                    const uint32_t w0 = ((event_i - 3u) % PS_RING) << 2, w1 = ((event_i - 2u) % PS_RING) << 2,
-                                   w2 = ((event_i - 1u) % PS_RING) << 2, w3 = (event_i % PS_RING) << 2;
-                    const uint32_t r0 = ((event_i + 2u) % PS_RING) << 2, r1 = ((event_i + 3u) % PS_RING) << 2,
-                                   r2 = ((event_i + 4u) % PS_RING) << 2, r3 = ((event_i + 5u) % PS_RING) << 2;
-                    // list entry two passes ahead, ring index and recent sums one pass ahead of their use (the records of a
-                    // pass are distinct from the next pass's: what this pass stores is not what the next one has loaded)
-                    uint32_t idx_c = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, lst_off + ((uint32_t)lane << 2)) : 0u;
-                    uint32_t idx_n = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, lst_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
-                    uint32_t oring_c = RING_NONE;
-                    float4 rc_c = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((uint32_t)lane < n_parents) {
-                        oring_c = gld<uint32_t>(sb, rec_off + (idx_c << 6) + 28u); rc_c = gld<float4>(sb, rec_off + (idx_c << 6) + 32u);
-                    }
-                    for (uint32_t k0 = 0; k0 < n_parents; k0 += WAVE) {
-                        const uint32_t k = k0 + (uint32_t)lane;
-                        const uint32_t idx = idx_c, oring = oring_c;
-                        const float4 rc = rc_c;
-                        idx_c = idx_n;
-                        if (k + WAVE < n_parents) {
-                            oring_c = gld<uint32_t>(sb, rec_off + (idx_c << 6) + 28u); rc_c = gld<float4>(sb, rec_off + (idx_c << 6) + 32u);
-                        }
-                        if (k + 2 * WAVE < n_parents) idx_n = gld<uint32_t>(sb, lst_off + ((k + 2 * WAVE) << 2));
-                        if (k < n_parents) {
-                            const uint32_t ro = rec_off + (idx << 6);
-                            const uint32_t no = nring_off + idx * (RING_FLOATS * 4u);
-                            if (oring != RING_NONE) {
-                                const uint32_t oo = oring_off + oring * (RING_FLOATS * 4u);
-                                const uint4 a0 = gld<uint4>(sb, oo), a1 = gld<uint4>(sb, oo + 16u), a2 = gld<uint4>(sb, oo + 32u),
-                                            a3 = gld<uint4>(sb, oo + 48u), a4 = gld<uint4>(sb, oo + 64u), a5 = gld<uint4>(sb, oo + 80u);
-                                float4 sc2;
-                                sc2.x = gld<float>(sb, oo + r0); sc2.y = gld<float>(sb, oo + r1); sc2.z = gld<float>(sb, oo + r2); sc2.w = gld<float>(sb, oo + r3);
-                                gst(sb, no, a0); gst(sb, no + 16u, a1); gst(sb, no + 32u, a2); gst(sb, no + 48u, a3); gst(sb, no + 64u, a4); gst(sb, no + 80u, a5);
-                                gst(sb, ro + 48u, sc2);
-                            }
-                            // same lane, after the copy: program order
-                            gst(sb, no + w0, rc.x); gst(sb, no + w1, rc.y); gst(sb, no + w2, rc.z); gst(sb, no + w3, rc.w);
-                            gst(sb, ro + 28u, idx);
-                        }
-                    }
-                    wave_sync();
-                }
                 event_i++;
+                CTX_SET(event_i, event_i);
+                wave_sync();
             }
-            PHASE_END(7);
+            clk.end(7, lane);
         }
+        n_parents = ctx_get(s_w.n_parents); cur = ctx_get(s_w.cur); n_surv_par = ctx_get(s_w.n_surv_par);
 
         // ---------------- publish / park ----------------
         const uint64_t t_nbr = wave_sum64(c_nbr), t_sa = wave_sum64(c_sa), t_lf = wave_sum64(c_lf);
@@ -1818,19 +1984,21 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
-            for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? cyc[i] : 0ull;
-            A.results[r] = res;
+            for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
+            g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
         }
-        if (done && !A.resume) tracker_release(T, tracker_mem(), lane);   // batch mode: the leaves go back to the pool at once
-        if (A.resume || !done) {
+        if (done && !resume) tracker_release(T, tracker_mem(A, sb), lane);   // batch mode: the leaves go back to the pool at once
+        if (resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
                 st->n_surv = n_surv_par;
                 st->status = T.status; st->n_clusters = T.n; st->n_lens = T.n_lens;
-                st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum; st->max_map = T.mm;
+                st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
+                st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
+                st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
-                if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = cyc[i]; } }
+                if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; } }
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
             if (!sliced) break;
@@ -1839,14 +2007,14 @@ __global__ __launch_bounds__(64, UNC_LB) void UNC_KMAP(UNC_MAPARGS A) {
             // hand the slot back: to the free ring when the read is finished, else to the end of the parked ring
             __threadfence();
             if (lane == 0) {
-                SchedCtl *const sc = A.sched.ctl;
-                if (done) sched_push(&sc->freeq, A.sched.free_cells, A.sched.cap_mask, slot);
-                else sched_push(&sc->parkq, A.sched.park_cells, A.sched.cap_mask, slot);
+                SchedCtl *const sc = A->sched.ctl;
+                if (done) sched_push(&sc->freeq, A->sched.free_cells, A->sched.cap_mask, slot);
+                else sched_push(&sc->parkq, A->sched.park_cells, A->sched.cap_mask, slot);
             }
         }
         wave_sync();
     }
-    if (A.wave_ticks && lane == 0) atomicAdd(A.wave_ticks, (unsigned long long)((uint64_t)wall_clock64() - wave_t0));
+    if (A->wave_ticks && lane == 0) atomicAdd(A->wave_ticks, (unsigned long long)((uint64_t)wall_clock64() - wave_t0));
 }
 
 }  // namespace unc
@@ -1856,16 +2024,16 @@ namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
                 const DevPool &pool, const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile) {
-    UNC_MAPARGS a;
+    MapArgs a;
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
     a.pool = pool;
     const bool narrow = ix.key_len_bits != 0;
-    if (profile && narrow) hipLaunchKernelGGL((UNC_KMAP<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
-    else if (profile) hipLaunchKernelGGL((UNC_KMAP<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
-    else if (narrow) hipLaunchKernelGGL((UNC_KMAP<false, true>), dim3(grid), dim3(WAVE), 0, st, a);
-    else hipLaunchKernelGGL((UNC_KMAP<false, false>), dim3(grid), dim3(WAVE), 0, st, a);
+    if (profile && narrow) hipLaunchKernelGGL((k_map<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (profile) hipLaunchKernelGGL((k_map<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((k_map<false, true>), dim3(grid), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL((k_map<false, false>), dim3(grid), dim3(WAVE), 0, st, a);
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {

@@ -25,7 +25,12 @@ __global__ void k_fm_neighbor(DevIndex ix, uint32_t n, const uint64_t *s, const 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t a, c;
-    fm_get_neighbor(ix, s[i], e[i], b[i], &a, &c);
+    if (ix.fm32 && s[i] >= 1 && s[i] <= e[i] && e[i] <= ix.seq_len) {      // what k_map does on a reference of fewer than 2^32 rows
+        uint32_t a32, c32;
+        fm32_get_neighbor(ix, (uint32_t)s[i], (uint32_t)e[i], b[i], &a32, &c32);
+        a = a32; c = c32;
+        if (a32 > c32) fm_get_neighbor(ix, s[i], e[i], b[i], &a, &c);      // an empty result: report the BWA-format pair
+    } else fm_get_neighbor(ix, s[i], e[i], b[i], &a, &c);
     os[i] = a;
     oe[i] = c;
 }
@@ -88,6 +93,60 @@ __global__ void k_dense_sa_check(DevIndex ix, const uint64_t *dense, uint32_t n,
     const uint64_t sa = fm_sa(ix, k, &steps);
     const uint64_t want = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);
     if (dense[k] != want) atomicAdd(bad, 1u);
+}
+
+
+// The 32-bit rank table (fm_dev.h, fm32_get_neighbor) from the BWA blocks: one thread per block of 64 symbols.
+__global__ void k_build_fm32(DevIndex ix, uint32_t *out, uint32_t n_blk) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blk) return;
+    const uint64_t base = (uint64_t)b << 6;
+    uint32_t cnt[4];
+    for (uint32_t c = 0; c < 4; ++c) {
+        uint64_t n = ix.L2[c];
+        if (base > 0 && base <= ix.seq_len) {       // occurrences among the symbols [0 .. base - 1] (symbol indices: no sentinel)
+            const FmBlock blk = fm_load_block(ix, base - 1);
+            n += fm_block_count(blk, c) + fm_block_rank(blk, base - 1, c);
+        } else if (base > ix.seq_len) n = ix.L2[c + 1];
+        cnt[c] = (uint32_t)n;
+    }
+    uint32_t h_lo = 0, h_hi = 0, l_lo = 0, l_hi = 0;
+    for (uint32_t j = 0; j < 64; ++j) {
+        const uint64_t p = base + j;
+        if (p >= ix.seq_len) break;
+        const uint32_t sym = (ix.bwt[((p >> 7) << 4) + 8 + ((p & 127) >> 4)] >> ((~p & 15) << 1)) & 3u;
+        if (j < 32) { h_lo |= (sym >> 1) << j; l_lo |= (sym & 1u) << j; }
+        else { h_hi |= (sym >> 1) << (j - 32); l_hi |= (sym & 1u) << (j - 32); }
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(out) + ((size_t)b << 1);
+    o[0] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+    o[1] = make_uint4(h_lo, h_hi, l_lo, l_hi);
+}
+// Load-time self-check of the table: `n` pseudo-random steps (rows spread over the whole index, short and long ranges, every
+// base) must give what the BWA-format arithmetic gives; *bad counts the ones that do not.
+__global__ void k_fm32_check(DevIndex ix, uint32_t n, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const uint64_t s = 1 + x % ix.seq_len;                       // 1 .. seq_len
+    uint64_t len = (i & 3u) == 0 ? (x >> 40) % ix.seq_len : (x >> 40) % 200;
+    uint64_t e = s + len;
+    if (e > ix.seq_len) e = ix.seq_len;
+    if (i == 0) e = ix.seq_len;
+    const uint32_t c = (uint32_t)(x >> 33) & 3u;
+    uint64_t ws, we;
+    fm_get_neighbor(ix, s, e, c, &ws, &we);
+    uint32_t gs, ge;
+    fm32_get_neighbor(ix, (uint32_t)s, (uint32_t)e, c, &gs, &ge);
+    const bool want_empty = ws > we, got_empty = gs > ge;
+    if (want_empty != got_empty || (!want_empty && (ws != gs || we != ge))) atomicAdd(bad, 1u);
+}
+void launch_build_fm32(const DevIndex &ix, uint32_t *out, uint32_t n_blk, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_fm32, dim3((n_blk + 255) / 256), dim3(256), 0, st, ix, out, n_blk);
+}
+void launch_fm32_check(const DevIndex &ix, uint32_t n, uint32_t *bad, hipStream_t st) {
+    hipLaunchKernelGGL(k_fm32_check, dim3((n + 255) / 256), dim3(256), 0, st, ix, n, bad);
 }
 
 // PoreModel::match_prob for all 1024 k-mers of each level (mapper.cpp:443-445)

@@ -12,36 +12,34 @@ constexpr int NKMER = UNC_NKMER;
 constexpr uint32_t KMASK = NKMER - 1;
 constexpr int MAX_REP_COPY_LIMIT = 64;
 
-// One path of the forest (Mapper::PathBuffer, mapper.hpp:139-196) = one 64-byte record.  The 23 float prefix sums
-// (prob_sums_) are NOT part of it: the reference only ever reads prob_sums_[length_] (the newest sum) and, once the
-// window is full, prob_sums_[1] (the sum that drops out next).  Sums are addressed by the event t that produced them:
-//   recent[t & 3]  the sums of this path's lineage for the events since the last materialisation (every 4th event),
-//                  recent[g & 3] of a path created by event g being its own newest sum;
-//   second[t & 3]  the sum of event t - 22, i.e. what a child created by event t subtracts (copied down the lineage);
-//   ring           index of the lineage's 23-entry ring (slot t % 23 = sum of event t) in the slot's ring pool.
-// After every 4th event the rings of the paths that are still alive are brought up to date (k_map phase M): old ring +
-// the four recent sums -> new ring, and the next four `second`s are read off it.  Children that the walk prunes (45 %)
-// never touch a ring, and extending a path writes 64 bytes instead of 128.
+// One path of the forest (Mapper::PathBuffer, mapper.hpp:139-196) = one 32-byte record.  The 23 float prefix sums
+// (prob_sums_) are NOT stored: the reference only ever reads prob_sums_[length_] (the newest sum) and, once the window is
+// full, prob_sums_[1] (the sum that drops out next), and prob_sums_[1] = prob_sums_[0] + (the match probability of the
+// window's oldest event) is recomputed from what that event's k-mer was.  A record carries
+//   last   prob_sums_[length_]
+//   sub    prob_sums_[0]: 0 until the window has slid for the first time
+//   hist   the lineage's k-mer at the OLDEST event of the window (10 bits) | the bases its moves have shifted in since
+//          (newest in the low bits; at most 21 of them, 2 bits each) << 10
+// so that a child of a full-window path gets  sub' = sub + match_prob(level of the oldest event, its k-mer)  -- the same
+// float addition, on the same operands, that made prob_sums_[1] in the reference -- and slides the k-mer one event on.
+// seed_prob_ is a function of (last, sub, length) and is recomputed where it is needed.  (Rounds 1-2 kept the sums: 128-byte
+// records, then 64-byte records + 96-byte rings copied for every live path every 4th event: most of the kernel's traffic.)
 struct alignas(16) PathRec {
-    uint64_t start, end;        // fm_range_
+    uint32_t r0, r1;            // fm_range_: start, end (fewer than 2^32 rows) or start << 30 | (end - start), low word first
     uint32_t moves;             // event_moves_ (22-bit shift register, LSB = newest event)
-    float seed_prob;            // seed_prob_
     uint32_t meta;              // kmer | length | consec_stays | sa_checked | first_full, see below
-    uint32_t ring;              // ring pool index (RING_NONE: the path is younger than the last materialisation)
-    float recent[4];
-    float second[4];
+    float last, sub;
+    uint32_t hist_lo, hist_hi;
 };
-static_assert(sizeof(PathRec) == 64, "PathRec must be half a cache line");
+static_assert(sizeof(PathRec) == 32, "PathRec is two 16-byte quads");
+constexpr int PATH_SHIFT = 5;            // log2(sizeof(PathRec))
+constexpr uint32_t LEVEL_RING = 32;      // normalised levels of the last events kept per read (the oldest window event is 22 back)
 
 constexpr uint32_t META_KMER_MASK = 0x3FFu;
 constexpr int META_LEN_SHIFT = 10;       // 5 bits
 constexpr int META_STAY_SHIFT = 16;      // 8 bits
 constexpr uint32_t META_SA_CHECKED = 1u << 24;
 constexpr uint32_t META_FIRST_FULL = 1u << 25;   // length_ reached seed_len with this event: prob_sums_[0] is still the initial 0
-constexpr uint32_t PS_RING = UNC_SEED_LEN + 1;   // entries per ring
-constexpr uint32_t RING_FLOATS = 24;             // floats per ring in the pool (96 bytes, 16-byte aligned)
-constexpr uint32_t RING_NONE = 0xFFFFFFFFu;
-constexpr uint32_t MAT_PERIOD = 4;               // events between materialisations (= entries of recent[] / second[])
 
 // Sort key of one child (operator< of mapper.cpp:866-871 made total by creation order):
 //   a = fm_range_.start << 30 | (fm_range_.length - 1)      (start asc, then end asc)
@@ -126,6 +124,7 @@ struct DevIndex {
     const uint64_t *kmer_ranges;  // [1024][2]
     const float *model;         // [3][1024]: lv_means, lv_vars_x2, lognorm_denoms
     const uint16_t *kmer_valid; // [64]: bit j of entry l = range of k-mer j*64+l is non-empty
+    const uint32_t *fm32;       // rank table of a reference with fewer than 2^32 rows (8 words per 64 symbols, fm_dev.h), else null
     uint64_t primary, seq_len;
     uint64_t L2[5];
     uint32_t key_len_bits;      // > 0: (start, length, child index) pack into one 64-bit sort key with this many length bits
@@ -141,7 +140,7 @@ struct DevScratch {
     uint32_t max_paths, keys_cap, max_seed_paths, max_clusters;
     // region offsets inside a slot
     uint32_t off_paths;    // PathRec [2][max_paths]
-    uint32_t off_rings;    // float   [2][max_paths][RING_FLOATS]
+    uint32_t off_levels;   // float   [LEVEL_RING]: normalised level of event e at [e % LEVEL_RING]
     uint32_t off_order;    // u32     [2][max_paths]
     uint32_t off_keys;     // SortKey [2][keys_cap]   (unsorted | sorted)
     uint32_t off_seedp;    // SeedPath[max_seed_paths]

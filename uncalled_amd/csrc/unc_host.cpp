@@ -78,6 +78,7 @@ struct unc_index {
     float *d_model = nullptr;
     uint16_t *d_kmer_valid = nullptr;
     uint64_t *d_sa_dense = nullptr;
+    uint32_t *d_fm32 = nullptr;
     uint64_t device_bytes = 0;
     DevIndex dev;
 };
@@ -176,6 +177,7 @@ extern "C" void unc_index_free(unc_index_t *ix) {
     if (ix->d_model) (void)hipFree(ix->d_model);
     if (ix->d_kmer_valid) (void)hipFree(ix->d_kmer_valid);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
+    if (ix->d_fm32) (void)hipFree(ix->d_fm32);
     delete ix;
 }
 
@@ -266,6 +268,27 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
             ix->device_bytes += need;
         }
     }
+    // References of fewer than 2^32 rows (the reference's own 32-bit regime, range.hpp:37) get the 32-bit rank table k_map
+    // works on there (fm_dev.h: 32 bytes per 64 symbols, counts with L2 folded in, symbols as bit planes), checked against the
+    // BWA-format arithmetic on 16 384 pseudo-random steps.
+    d.fm32 = nullptr;
+    if (n < 0xFFFFFF00ull) {
+        const uint32_t n_blk = (uint32_t)((n + 63) / 64 + 1);
+        HIPCHK(hipMalloc((void **)&ix->d_fm32, (size_t)n_blk * 32));
+        launch_build_fm32(d, ix->d_fm32, n_blk, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        d.fm32 = ix->d_fm32;
+        uint32_t *d_bad = nullptr, bad = 0;
+        HIPCHK(hipMalloc((void **)&d_bad, 4));
+        HIPCHK(hipMemset(d_bad, 0, 4));
+        launch_fm32_check(d, 16384, d_bad, nullptr);
+        const hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_bad);
+        HIPCHK(e1); HIPCHK(e2);
+        if (bad) return fail(UNC_ERR_HIP, "32-bit rank table self-check failed on %u of 16384 probe steps", bad);
+        ix->device_bytes += (size_t)n_blk * 32;
+    }
     // the 1024 k-mer ranges, derived on the device exactly as BwaIndex::load_index does (bwa_index.hpp:124-132)
     launch_kmer_ranges(d, ix->d_kmer_ranges, nullptr);
     HIPCHK(hipGetLastError());
@@ -287,7 +310,8 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         while ((n >> start_bits) != 0) ++start_bits;
         while ((max_len >> len_bits) != 0) ++len_bits;
         const char *wide = getenv("UNC_WIDE_KEYS");
-        ix->dev.key_len_bits = (start_bits + len_bits + 16 <= 64 && !(wide && wide[0] == '1')) ? len_bits : 0;
+        // (narrow keys also mean 32-bit rows in k_map: only with the 32-bit rank table)
+        ix->dev.key_len_bits = (start_bits + len_bits + 16 <= 64 && ix->dev.fm32 && !(wide && wide[0] == '1')) ? len_bits : 0;
         ix->dev.pad_ = 0;
     }
     {
@@ -452,7 +476,7 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     auto region = [&off](uint64_t bytes) { const uint64_t o = off; off += (bytes + 255) & ~255ull; return o; };
     const uint64_t leaves = max_clusters / 16;     // directory entries: leaves are at least half full after a split
     const uint64_t o_paths = region(2ull * sc.max_paths * sizeof(PathRec));
-    const uint64_t o_rings = region(2ull * sc.max_paths * RING_FLOATS * 4);
+    const uint64_t o_levels = region(LEVEL_RING * 4);
     const uint64_t o_order = region(2ull * sc.max_paths * 4);
     const uint64_t o_keys = region(2ull * sc.keys_cap * sizeof(SortKey));
     const uint64_t o_seedp = region((uint64_t)max_seed_paths * sizeof(SeedPath));
@@ -464,7 +488,7 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     const uint64_t o_info = region((uint64_t)sc.max_paths * 8);
     const uint64_t o_tmp = region((uint64_t)sc.max_paths * 8);
     if (off >= (1ull << 32)) return fail(UNC_ERR_ARG, "per-read scratch of %llu bytes does not fit 32-bit offsets (max_clusters %u)", (unsigned long long)off, max_clusters);
-    sc.off_paths = (uint32_t)o_paths; sc.off_rings = (uint32_t)o_rings; sc.off_order = (uint32_t)o_order; sc.off_keys = (uint32_t)o_keys;
+    sc.off_paths = (uint32_t)o_paths; sc.off_levels = (uint32_t)o_levels; sc.off_order = (uint32_t)o_order; sc.off_keys = (uint32_t)o_keys;
     sc.off_seedp = (uint32_t)o_seedp; sc.off_tasks = (uint32_t)o_tasks; sc.off_cl_dir = (uint32_t)o_cld; sc.off_cl_chunks = (uint32_t)o_clc;
     sc.off_state = (uint32_t)o_state;
     sc.off_streams = (uint32_t)o_streams; sc.off_info = (uint32_t)o_info; sc.off_tmp = (uint32_t)o_tmp;
@@ -926,38 +950,62 @@ extern "C" int unc_trace_paths(unc_mapper_t *m, unc_path_t *out, uint32_t cap, u
     const DevScratch &sc = m->sc;
     std::vector<uint32_t> ord(s.n_parents ? s.n_parents : 1);
     std::vector<PathRec> recs(sc.max_paths);
-    std::vector<float> rings((size_t)sc.max_paths * RING_FLOATS);
-    // The paths belong to event `gen`; materialisations (k_map phase M) ran after the events 3, 7, .. of a read that went
-    // on; prob_sums_ entry j of a path of length L is the sum of event gen - (L - j): in recent[] when that event came
-    // after the last materialisation, else in the lineage's ring.
+    // The paths belong to event `gen`.  prob_sums_ is not stored (PathRec): entry 0 is `sub`, entry j the sum after the j-th
+    // event of the window, rebuilt here exactly as the reference built it -- one float addition per event of the match
+    // probability of that event's level with the k-mer the lineage had then (the record's k-mer history); the last entry must
+    // come out as the record's `last`, which checks the history the kernel keeps.
     const int64_t gen = s.done == 1 ? (int64_t)s.event_i : (int64_t)s.event_i - 1;
-    const int64_t n_mat = (gen + 1) / 4 - ((s.done == 1 && gen % 4 == 3) ? 1 : 0);
-    const int64_t g0 = 4 * n_mat - 1;                       // event of the last materialisation (-1: none yet)
-    const uint32_t pool = (uint32_t)(n_mat & 1);
+    unc_evt_info_t inf;
+    uint64_t moff = 0;
+    HIPCHK(hipMemcpy(&inf, m->d_info, sizeof inf, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&moff, m->d_moff, 8, hipMemcpyDeviceToHost));
+    std::vector<float> means(gen >= 0 ? (size_t)gen + 1 : 1);
+    if (gen >= 0) HIPCHK(hipMemcpy(means.data(), m->d_means + moff, ((size_t)gen + 1) * 4, hipMemcpyDeviceToHost));
+    const bool narrow = m->ix->dev.key_len_bits != 0;
     HIPCHK(hipMemcpy(ord.data(), sc.base + sc.off_order + (size_t)s.cur * sc.max_paths * 4, (size_t)s.n_parents * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(recs.data(), sc.base + sc.off_paths + (size_t)s.cur * sc.max_paths * sizeof(PathRec),
                      (size_t)sc.max_paths * sizeof(PathRec), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rings.data(), sc.base + sc.off_rings + (size_t)pool * sc.max_paths * RING_FLOATS * 4,
-                     (size_t)sc.max_paths * RING_FLOATS * 4, hipMemcpyDeviceToHost));
+    const float *mu = m->ix->model.data(), *v2 = mu + NKMER, *ld = mu + 2 * NKMER;
     for (uint32_t i = 0; i < s.n_parents && i < cap; ++i) {
         const PathRec &r = recs[ord[i]];
         unc_path_t &o = out[i];
         memset(&o, 0, sizeof o);
-        o.fm_start = r.start; o.fm_end = r.end; o.event_moves = r.moves; o.seed_prob = r.seed_prob;
+        if (narrow) { o.fm_start = r.r0; o.fm_end = r.r1; }
+        else { const uint64_t v = ((uint64_t)r.r1 << 32) | r.r0; o.fm_start = v >> KEY_LEN_BITS; o.fm_end = o.fm_start + (v & KEY_LEN_MASK); }
+        o.event_moves = r.moves;
         o.kmer = (uint16_t)(r.meta & META_KMER_MASK);
         o.length = (uint8_t)((r.meta >> META_LEN_SHIFT) & 31u);
         o.consec_stays = (uint8_t)((r.meta >> META_STAY_SHIFT) & 255u);
         o.sa_checked = (r.meta & META_SA_CHECKED) ? 1 : 0;
         const int L = o.length;
-        for (int j = 0; j <= L && j <= UNC_SEED_LEN; ++j) {
-            const int64_t t = gen - (L - j);
-            float v;
-            if (j == 0 && (L < UNC_SEED_LEN || (r.meta & META_FIRST_FULL))) v = 0.0f;      // the initial prob_sums_[0]
-            else if (t > g0) v = r.recent[t & 3];
-            else if (r.ring != RING_NONE && r.ring < sc.max_paths) v = rings[(size_t)r.ring * RING_FLOATS + (size_t)(t % PS_RING)];
-            else return fail(UNC_ERR_HIP, "path %u: prob sum of event %lld has no ring", i, (long long)t);
-            o.prob_sums[j] = v;
+        // seed_prob_ as make_child / make_source left it (mapper.cpp:751-807)
+        const bool slid = L == UNC_SEED_LEN && !(r.meta & META_FIRST_FULL);
+        volatile float num = slid ? r.last - r.sub : r.last;
+        volatile float sp = num / (float)L;
+        o.seed_prob = sp;
+        const uint64_t hist = ((uint64_t)r.hist_hi << 32) | r.hist_lo;
+        uint32_t kmer = (uint32_t)hist & KMASK;
+        const uint64_t fifo = hist >> 10;
+        int queued = 0;
+        for (int j = 0; j + 1 < L; ++j) queued += (r.moves >> j) & 1u;      // moves after the window's oldest event
+        o.prob_sums[0] = slid ? r.sub : 0.0f;
+        for (int j = 1; j <= L; ++j) {
+            const int64_t t = gen - (L - j);                                 // the event behind entry j
+            if (t < 0) return fail(UNC_ERR_HIP, "path %u is longer than the read so far", i);
+            if (j > 1 && ((r.moves >> (L - j)) & 1u)) {                      // that event was a move: the next queued base joins the k-mer
+                if (queued <= 0) return fail(UNC_ERR_HIP, "path %u: k-mer history has fewer bases than moves", i);
+                --queued;
+                kmer = ((kmer << 2) & KMASK) | (uint32_t)((fifo >> (2 * queued)) & 3u);
+            }
+            volatile float level = inf.scale * means[(size_t)t];
+            level = level + inf.shift;
+            volatile float d = level - mu[kmer];
+            const double q = -((double)d * (double)d) / (double)v2[kmer];
+            const float pr = (float)(q - (double)ld[kmer]);
+            volatile float sum = o.prob_sums[j - 1] + pr;
+            o.prob_sums[j] = sum;
         }
+        if (L > 0 && kmer != o.kmer) return fail(UNC_ERR_HIP, "path %u: k-mer history ends in %u, the path's k-mer is %u", i, kmer, (unsigned)o.kmer);
     }
     *n_out = s.n_parents;
     return UNC_OK;

@@ -21,6 +21,8 @@ void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const
 void launch_self_align(const DevIndex &ix, const uint8_t *pac, uint32_t n, const uint64_t *pos, const uint64_t *remain, uint64_t *out,
                        uint32_t cap, uint32_t *out_len, hipStream_t st);
 void launch_dense_sa(const DevIndex &ix, uint64_t *out, hipStream_t st);
+void launch_build_fm32(const DevIndex &ix, uint32_t *out, uint32_t n_blk, hipStream_t st);
+void launch_fm32_check(const DevIndex &ix, uint32_t n, uint32_t *bad, hipStream_t st);
 void launch_dense_sa_check(const DevIndex &ix, const uint64_t *dense, uint32_t n, uint32_t *bad, hipStream_t st);
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st);
 void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStream_t st);

@@ -106,6 +106,31 @@ __device__ __forceinline__ uint64_t seg_incl_max64(uint64_t v, bool head) {
     return x;
 }
 
+
+// the same scan for 32-bit values: two DPP moves per step
+__device__ __forceinline__ uint32_t seg_incl_max32(uint32_t v, bool head) {
+    uint32_t x = v;
+    uint32_t f = head ? 1u : 0u;
+    const uint32_t l = (uint32_t)lane_id(), rl = l & 15u;
+#define UNC_SEG_STEP32(CTRL, GUARD)                                 \
+    {                                                               \
+        const uint32_t y = dpp_mov32<CTRL>(x);                      \
+        const uint32_t g = dpp_mov32<CTRL>(f);                      \
+        if (GUARD) {                                                \
+            if (!f) x = x > y ? x : y;                              \
+            f |= g;                                                 \
+        }                                                           \
+    }
+    UNC_SEG_STEP32(0x111, rl >= 1u)
+    UNC_SEG_STEP32(0x112, rl >= 2u)
+    UNC_SEG_STEP32(0x114, rl >= 4u)
+    UNC_SEG_STEP32(0x118, rl >= 8u)
+    UNC_SEG_STEP32(0x142, (l & 31u) >= 16u)
+    UNC_SEG_STEP32(0x143, l >= 32u)
+#undef UNC_SEG_STEP32
+    return x;
+}
+
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d);
@@ -118,14 +143,38 @@ __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
     return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
 }
 
+// Address spaces are spelled out wherever a pointer travels through a function call: a generic pointer that the compiler
+// cannot trace to its origin costs FLAT instructions (no scalar base, both memory counters), a kernel argument read through
+// a generic pointer costs vector loads.  (The CPU emulator of tests/ defines both markers empty.)
+#ifndef UNC_AS_GLOBAL
+#define UNC_AS_GLOBAL __attribute__((address_space(1)))
+#define UNC_AS_CONST __attribute__((address_space(4)))
+#endif
+typedef UNC_AS_GLOBAL char *gptr_t;            // global memory (a read's scratch slot, the leaf pool)
+typedef const UNC_AS_GLOBAL char *cgptr_t;
+
 // Global access as (uniform base, 32-bit byte offset): lets the compiler address with an SGPR base plus one VGPR
 // (global_load ... v_off, s[base]) instead of building a 64-bit address in a VGPR pair per access.  Every per-slot
 // array is far below 4 GB.
-template <class T> __device__ __forceinline__ T gld(const void *base, uint32_t off) {
-    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + off);
+// (structs are copied with the memcpy builtin, which takes pointers of any address space and becomes one load / store
+// of the struct's size and alignment; a class-type lvalue in a named address space has no copy constructor to bind to)
+template <class T> __device__ __forceinline__ T g_load(const UNC_AS_GLOBAL T *p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
 }
-template <class T> __device__ __forceinline__ void gst(void *base, uint32_t off, const T &v) {
-    *reinterpret_cast<T *>(static_cast<char *>(base) + off) = v;
+template <class T> __device__ __forceinline__ void g_store(UNC_AS_GLOBAL T *p, const T &v) { __builtin_memcpy(p, &v, sizeof(T)); }
+template <class T> __device__ __forceinline__ T gld(cgptr_t base, uint32_t off) { return g_load(reinterpret_cast<const UNC_AS_GLOBAL T *>(base + off)); }
+template <class T> __device__ __forceinline__ void gst(gptr_t base, uint32_t off, const T &v) { g_store(reinterpret_cast<UNC_AS_GLOBAL T *>(base + off), v); }
+// a pointer handed to an out-of-line function arrives in vector registers: back to a scalar pair
+template <class P> __device__ __forceinline__ P uniform_ptr(P p) {
+    return (P)uniform64((uint64_t)p);
+}
+// a struct of the kernel's argument block (constant address space) by value: only the fields that are used get loaded
+template <class T> __device__ __forceinline__ T ka_get(const UNC_AS_CONST T *p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
 }
 
 }  // namespace unc
