@@ -303,3 +303,24 @@ def case_big_forests(lib, oracle_lib, example, goldens, tmp_path, monkeypatch, w
         assert_hits_equal(hits, want, "big forests, wide keys" if wide else "big forests")
         assert (hits["n_nbr"] / np.maximum(hits["event_i"], 1)).min() > 1000        # ~600 parents, well over 512 children per event
     monkeypatch.delenv("UNC_WIDE_KEYS", raising=False)
+
+
+def case_mid_reference(lib, oracle_lib, tmp_path, n=3, genome=800000, cut=8000):
+    """A reference large enough that few children sit on a k-mer's boundary row (on the 10 kb example index nearly every
+    event has one and takes the sort through memory): events with many children then go through the merge that walks its
+    output tile in LDS.  Built here (synthetic genome, permissive thresholds), against the oracle."""
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
+    from tools.simulate_reads import simulate_reads
+    names, lens, codes = synthetic_genome(1, genome, seed=11)
+    prefix = tmp_path / "mid"
+    build_from_codes(prefix, names, [""], lens, codes)
+    (tmp_path / "mid.uncl").write_text("default\t-10.07,-5.5,-5.0,-4.6,-4.3,-4.1\t0.3\t115.000\n")     # permissive: hundreds of children per event
+    sim = simulate_reads(codes, lens, n, seed=5)
+    off = sim["offsets"]
+    raw = np.concatenate([sim["signal"][int(off[i]):int(off[i]) + cut] for i in range(n)])
+    o = (np.arange(n + 1) * cut).astype(np.uint64)
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    hits = capi.Mapper(capi.Index(prefix, lib=lib), n_slots=n).map_batch(raw, o, cal)
+    want = oracle_hits(oracle_lib.Index(prefix), raw, o, cal)
+    assert_hits_equal(hits, want, "mid reference")
+    assert (hits["n_nbr"] / np.maximum(hits["event_i"], 1)).max() > 300      # events well past the merge threshold

@@ -95,3 +95,7 @@ def sim_lib_norepair():
 
 def test_merge_check_and_fallback(sim_lib_norepair, oracle_lib, example, goldens, tmp_path, monkeypatch):
     pc.case_big_forests(sim_lib_norepair, oracle_lib, example, goldens, tmp_path, monkeypatch, wide_too=False)
+
+
+def test_merge_walk_mid_reference(sim_lib, oracle_lib, tmp_path):
+    pc.case_mid_reference(sim_lib, oracle_lib, tmp_path)

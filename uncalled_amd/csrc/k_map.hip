@@ -374,7 +374,6 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
         id0 = d - 1 >= lo ? bcast32(dk.leaf, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).leaf);   // window starts after it
         const cgptr_t lp0 = tm_leaf_ptr(M, id0);
         lk = lf_hot(lp0, lane);           // slots past the count hold stale keys: masked by c0
-        lc = lf_cold(lp0, lane);
         c0 = tm_cnt(M, id0);
         const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
         const uint32_t sn = (uint32_t)__popcll(__ballot(less));
@@ -490,6 +489,10 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             if (d > 0 && c0 < LEAF && (lb_in_leaf0 || lbL == T.n_leaves)) {
                 // into the leaf loaded above (the lower bound lies in it, or the seed sorts after everything and is appended
                 // to the last leaf = directory position d - 1): nothing to reload
+                // (the cold parts of the leaf are fetched only now, when they have to move: the kernel is bound by the bytes it
+                // moves, and most seeds extend a cluster and never get here)
+                lc = lf_cold(tm_leaf_ptr(M, id0), lane);
+                wave_sync();        // every lane has its cold part before any lane stores into its neighbour's slot
                 tracker_insert_held(M, d - 1, lb_in_leaf0 ? lbS : c0, id0, c0, lk, lc, nk, nc, lane, top_n);
             } else if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane, top_n)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             T.n++;
@@ -853,15 +856,17 @@ __device__ __forceinline__ uint32_t mslot(uint32_t i) { return i + (i >> 3); }
 constexpr uint32_t MERGE_LDS_KEYS = MERGE_TILE + MERGE_TILE / 8 + 1;
 
 // how many of the first d keys of merge(A, B) come from A (keys distinct): the first mid with !(A[mid] < B[d - 1 - mid]),
-// 64 probes per memory round trip
+// 16 probes per memory round trip (a scattered access costs the memory pipeline per LANE: four rounds of 16 are cheaper
+// than three of 64)
+constexpr uint32_t SPLIT_PROBES = 16;
 template <int RA, int RB>
 __device__ __forceinline__ uint32_t merge_split(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
     uint32_t lo = d > B.n ? d - B.n : 0u, hi = d < A.n ? d : A.n;
     while (lo < hi) {
-        const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint32_t span = hi - lo, step = (span + SPLIT_PROBES - 1u) / SPLIT_PROBES;
         const uint32_t p = lo + (uint32_t)lane * step;
         bool less = false;
-        if (p < hi) less = ka_load(sb, A, p) < ka_load(sb, B, d - 1u - p);
+        if ((uint32_t)lane < SPLIT_PROBES && p < hi) less = ka_load(sb, A, p) < ka_load(sb, B, d - 1u - p);
         const uint32_t c = (uint32_t)__popcll(__ballot(less));       // the predicate is monotone: the first c probes hold
         const uint32_t nlo = c ? lo + (c - 1u) * step + 1u : lo;
         const uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
@@ -989,6 +994,7 @@ static __device__ __noinline__ uint32_t repair_run(gptr_t sb_, uint32_t run_off_
         } else carry = bcast64(k, (int)nvalid - 1);
         const uint64_t vm = __ballot(viol);
         if (vm == 0 && shift == 0) continue;
+        if constexpr (!MERGE_REPAIR) { shift += (uint32_t)__popcll(vm); continue; }      // (test build: count, leave in place)
         wave_sync();
         const uint32_t before = (uint32_t)prefix_popc(vm);
         if (have) {
@@ -1074,6 +1080,8 @@ struct WaveCtx {
     uint32_t scnt[6];                                // narrow keys: keys filed in each run
     uint32_t n_surv, n_src;                          // the walk: survivors, gap sources
     uint32_t conf;                                   // the confidence test passed
+    uint32_t par_unsorted;                           // narrow keys: the surviving parents were not in ascending range order (never expected)
+    uint32_t walked;                                 // phase S walked the keys as it merged them: no separate walk
 };
 __shared__ WaveCtx s_w;
 __shared__ Tracker s_T;       // SeedTracker's scalars between the events that touch them
@@ -1106,11 +1114,12 @@ __device__ __forceinline__ TrackerMem tracker_mem(kargs_t A, gptr_t sb) {
 // ---------------- P: match log-probs of the normalised event (pore_model.hpp:163-165) -> s_probs ----------------
 static __device__ __noinline__ void phase_P(kargs_t A_, float level, int lane) {
     const kargs_t A = uniform_ptr(A_);
-    const UNC_AS_GLOBAL float *const model = (const UNC_AS_GLOBAL float *)A->ix.model;
+    const UNC_AS_GLOBAL float4 *const model4 = (const UNC_AS_GLOBAL float4 *)A->ix.model4;
 #pragma unroll 4
     for (int j = 0; j < NKMER / WAVE; ++j) {
         const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
-        const float mu = model[k], v2 = model[NKMER + k], ld = model[2 * NKMER + k];
+        const float4 row = g_load(model4 + k);          // one 16-byte row per k-mer: a third of the load instructions
+        const float mu = row.x, v2 = row.y, ld = row.z;
         const float d = __fsub_rn(level, mu);
         const double q = -((double)d * (double)d) / (double)v2;
         s_probs[k] = (float)(q - (double)ld);
@@ -1170,7 +1179,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     const uint32_t run_bytes = max_paths << 3;
     // a full-window parent's oldest event is 22 back from this one: its level, for the sum that drops out of the window
     const float level_old = event_i >= (uint32_t)SEED_LEN ? gld<float>(sb, A->sc.off_levels + (((event_i - (uint32_t)SEED_LEN) & (LEVEL_RING - 1u)) << 2)) : 0.0f;
-    const UNC_AS_GLOBAL float *const model = (const UNC_AS_GLOBAL float *)A->ix.model;
+    const UNC_AS_GLOBAL float4 *const model4 = (const UNC_AS_GLOBAL float4 *)A->ix.model4;
 
     PhaseClock<PROF> clk;
     uint32_t c_nbr = 0;
@@ -1178,6 +1187,8 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort)
     // narrow keys: keys filed so far in each run (stays / moves by base of the sorted survivors; children of sources)
     uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
+    uint64_t par_carry = 0;
+    bool par_bad = false;
     // parent index list and record headers are fetched one / two passes ahead of their use
     uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
     uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
@@ -1210,8 +1221,16 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         const bool pfull = plen == (uint32_t)SEED_LEN;
         const uint32_t okmer = (uint32_t)phist & KMASK;
         float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
-        if (pfull) { o_mu = model[okmer]; o_v2 = model[NKMER + okmer]; o_ld = model[2 * NKMER + okmer]; }
+        if (pfull) { const float4 row = g_load(model4 + okmer); o_mu = row.x; o_v2 = row.y; o_ld = row.z; }
         const Row plen_fm = pend - pstart + 1;
+        if constexpr (NARROW) {
+            // the merge of the children's keys relies on the survivors being in ascending (start, length) order: checked here
+            const uint64_t pk = pi < n_surv_par ? ((uint64_t)pstart << 32) | (uint32_t)(pend - pstart) : ~0ull;
+            uint64_t pp = (uint64_t)__shfl_up((unsigned long long)pk, 1);
+            if (lane == 0) pp = par_carry;
+            if (__any(pi < n_surv_par && !(pk > pp))) par_bad = true;
+            par_carry = bcast64(pk, WAVE - 1);
+        }
         int thr_bin;                                                         // get_fm_bin = clzll(length), :161-163
         if constexpr (NARROW) thr_bin = 32 + __clz((int)plen_fm); else thr_bin = __clzll((long long)plen_fm);
         const float thr = __shfl(thr_lane, thr_bin);                          // get_prob_thresh, :165-167
@@ -1423,12 +1442,14 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
     const uint32_t anyb = __any(bchild) ? 1u : 0u;
     if (lane == 0) {
-        s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.bchild = anyb; s_w.tstatus |= tst;
+        s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.bchild = anyb; s_w.tstatus |= tst; s_w.par_unsorted = par_bad ? 1u : 0u;
         s_w.scnt[0] = scnt0; s_w.scnt[1] = scnt1; s_w.scnt[2] = scnt2; s_w.scnt[3] = scnt3; s_w.scnt[4] = scnt4; s_w.scnt[5] = scntx;
     }
     wave_sync();
     return c_nbr;
 }
+
+static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1> KA_, KeyArr<4> KB_, int lane);
 
 // ---------------- S: the children's keys in the reference's order (mapper.cpp:531, 866-871) ----------------
 template <bool NARROW>
@@ -1441,6 +1462,7 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
     UNC_AS_GLOBAL SortKey *const ukeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + ukeys_off);
     UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + skeys_off);
     uint32_t kl = NARROW ? A->ix.key_len_bits : 0u;     // key mode of THIS event
+    CTX_SET(walked, 0u);
     if constexpr (NARROW) {
         const UNC_AS_GLOBAL uint64_t *const skeys64 = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(skeys);
         const UNC_AS_GLOBAL uint64_t *const info = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);
@@ -1448,42 +1470,52 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
         uint32_t scnt0 = ctx_get(s_w.scnt[0]), scnt1 = ctx_get(s_w.scnt[1]), scnt2 = ctx_get(s_w.scnt[2]), scnt3 = ctx_get(s_w.scnt[3]),
                  scnt4 = ctx_get(s_w.scnt[4]), nx = ctx_get(s_w.scnt[5]);
         bool sorted_ok = false;
-        if (n > MERGE_MIN) {
-            // moves of one base: ascending but for the odd pair of nested parents (repair_run); then the unsorted
-            // run is sorted, merged with the moves, and the result with the stays
+        if (n > MERGE_MIN && !ctx_get(s_w.par_unsorted)) {
+            // moves of one base: ascending but for the odd pair of nested parents (repair_run moves those to the unsorted run);
+            // then the unsorted run is sorted and merged with the moves, and the result with the stays while it is walked
             const uint32_t x_off = str_off + 5u * run_bytes;
-            if constexpr (MERGE_REPAIR) {
-                if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); scnt1 -= v; nx += v; }
-                if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); scnt2 -= v; nx += v; }
-                if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); scnt3 -= v; nx += v; }
-                if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); scnt4 -= v; nx += v; }
-            }
+            uint32_t nviol = 0;
+            if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt1 -= v; nx += v; } }
+            if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt2 -= v; nx += v; } }
+            if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt3 -= v; nx += v; } }
+            if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt4 -= v; nx += v; } }
             wave_sync();
-            if (nx > 1) {
-                KeyArr<6> KX;
+            if (MERGE_REPAIR || nviol == 0) {       // (test build without the repair: an event with such a pair takes the network below)
+                if (nx > 1) {
+                    KeyArr<6> KX;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
-                KX.n = nx;
-                sort_any64(sb, KX, x_off, lane);          // in place
+                    for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
+                    KX.n = nx;
+                    sort_any64(sb, KX, x_off, lane);          // in place
+                    wave_sync();
+                }
+                KeyArr<4> KM;       // the moves, base by base
+                KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
+                KM.n = KM.cum[3] + scnt4;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
+                KeyArr<4> KB = KM;  // what the stays are merged with
+                if (nx > 0) {
+                    if (KM.n > 0) {
+                        merge_runs<4, 1>(sb, KM, ka_single(x_off, nx), A->sc.off_tmp, lane, 0u);
+                        wave_sync();
+                        KB.adj[0] = A->sc.off_tmp;
+                    } else KB.adj[0] = x_off;
+                    KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
+                    KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
+                }
+                if (!ctx_get(s_w.bchild)) {
+                    merge_walk(A, sb, ka_single(str_off, scnt0), KB, lane);
+                    CTX_SET(kl, kl);
+                    CTX_SET(walked, 1u);
+                    wave_sync();
+                    return;
+                }
+                // (an event with a single-row child on a k-mer's boundary row may need the 128-bit keys, which is decided on the
+                // sorted keys below: its keys go through memory)
+                sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, lane, 1u) != 0u;
                 wave_sync();
             }
-            KeyArr<4> KM;       // the moves, base by base
-            KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
-            KM.n = KM.cum[3] + scnt4;
-#pragma unroll
-            for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
-            KeyArr<4> KB = KM;  // what the stays are merged with
-            if (nx > 0) {
-                if (KM.n > 0) {
-                    merge_runs<4, 1>(sb, KM, ka_single(x_off, nx), A->sc.off_tmp, lane, 0u);
-                    wave_sync();
-                    KB.adj[0] = A->sc.off_tmp;
-                } else KB.adj[0] = x_off;
-                KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
-                KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
-            }
-            sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, lane, 1u) != 0u;
-            wave_sync();
         }
         if (!sorted_ok) {
             // few children, or runs that were not ascending after all: the bitonic network over all of them
@@ -1535,31 +1567,147 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
 
 // ---------------- W: walk in sorted order (mapper.cpp:533-603) ----------------
 // duplicate-range pruning, per-k-mer gap sources from a segmented prefix-max (the sequential unchecked_range logic in closed
-// form), survivors -> next parent list, seed-valid survivors -> seed list
+// form), survivors -> next parent list, seed-valid survivors -> seed list.  One pass = 64 consecutive sorted positions.
+template <bool NARROW> struct WalkConst {
+    gptr_t sb, chd;                                   // the slot; its child buffer
+    const UNC_AS_GLOBAL uint64_t *kmer_ranges;
+    uint32_t n, room, nord_off, seedp_off, max_seed_paths, event_i;
+    float source_prob;
+};
+template <bool NARROW> struct WalkState {
+    using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
+    uint32_t n_surv = 0, n_src = 0, n_seedp = 0;
+    uint32_t carry_kmer = NKMER;
+    Row carry_U = 0;
+    uint64_t carry_range = ~0ull, carry_w = 0;         // narrow keys: range / running info maximum of the run that is open at a pass boundary
+};
+template <bool NARROW> __device__ __forceinline__ WalkConst<NARROW> walk_const(kargs_t A, gptr_t sb) {
+    WalkConst<NARROW> C;
+    const uint32_t cur = ctx_get(s_w.cur), max_paths = A->sc.max_paths;
+    C.sb = sb; C.chd = sb + A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT);
+    C.kmer_ranges = (const UNC_AS_GLOBAL uint64_t *)A->ix.kmer_ranges;
+    C.n = ctx_get(s_w.nchild); C.room = max_paths - C.n;      // room: sources that still fit
+    C.nord_off = A->sc.off_order + (cur ^ 1u) * (max_paths << 2); C.seedp_off = A->sc.off_seedp; C.max_seed_paths = A->sc.max_seed_paths;
+    C.event_i = ctx_get(s_w.event_i);
+    C.source_prob = A->ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
+    return C;
+}
+template <bool NARROW> __device__ __forceinline__ void walk_finish(const WalkConst<NARROW> &C, WalkState<NARROW> &S, int lane) {
+    uint32_t tst = 0;
+    if (S.n_seedp > C.max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; S.n_seedp = C.max_seed_paths; }
+    if (lane == 0) { s_w.n_surv = S.n_surv; s_w.n_src = S.n_src; s_w.n_seedp = S.n_seedp; s_w.tstatus |= tst; }
+    wave_sync();
+}
+
+// narrow keys: this lane's sorted key ki and info word bi and its successor's kn, bn -> range, k-mers, duplicate flag and the
+// info word that survives at this position.  Among equal ranges the reference keeps the highest (seed_prob, creation
+// order): a running max of the info words over each run, read off at the run's last position.  nv = valid lanes of the pass.
+template <bool NARROW>
+__device__ __forceinline__ void walk_decode_narrow(WalkState<NARROW> &S, uint32_t kl, uint64_t ki, uint64_t kn, uint64_t bi, uint64_t bn, bool have,
+                                                   bool has_next, uint32_t nv, int lane, typename WalkState<NARROW>::Row &start,
+                                                   typename WalkState<NARROW>::Row &end, typename WalkState<NARROW>::Row &nstart, uint32_t &kmer,
+                                                   uint32_t &nkmer, bool &dup, uint64_t &sb_) {
+    using Row = typename WalkState<NARROW>::Row;
+    const uint64_t ri = ki >> 16, rn = kn >> 16;
+    start = (Row)(ri >> kl); end = start + (Row)(ri & ((1ull << kl) - 1ull));
+    nstart = (Row)(rn >> kl);
+    kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
+    nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
+    dup = has_next && rn == ri;
+    uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
+    if (lane == 0) pr = S.carry_range;
+    const bool rhead = !have || ri != pr;
+    sb_ = seg_incl_max64(bi, rhead);
+    const uint64_t rheads = __ballot(rhead);
+    if ((rheads & ((2ull << lane) - 1ull)) == 0 && S.carry_w > sb_) sb_ = S.carry_w;
+    S.carry_range = bcast64(ri, (int)nv - 1);
+    S.carry_w = bcast64(sb_, (int)nv - 1);
+}
+
+// the walk proper for one pass.  krc: the full range of this lane's k-mer when the driver has fetched it (narrow keys), else
+// it is read here.
+template <bool NARROW>
+__device__ __forceinline__ void walk_core(const WalkConst<NARROW> &C, WalkState<NARROW> &S, bool have, bool has_next,
+                                          typename WalkState<NARROW>::Row start, typename WalkState<NARROW>::Row end,
+                                          typename WalkState<NARROW>::Row nstart, uint32_t kmer, uint32_t nkmer, bool dup, uint64_t sb_,
+                                          bool have_krc, const ulonglong2 &krc, uint32_t nv, int lane) {
+    using Row = typename WalkState<NARROW>::Row;
+    const uint32_t n = C.n, room = C.room;
+    const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
+    uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
+    if (lane == 0) pk = S.carry_kmer;
+    const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
+    const bool next_same = has_next && nkmer == kmer;
+    const bool psrc = have && s_probs[have ? kmer : 0] >= C.source_prob;
+    // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
+    Row U;
+    if constexpr (NARROW) U = seg_incl_max32(have ? end + 1u : 0u, first || !have);
+    else U = seg_incl_max64(have ? end + 1 : 0, first || !have);
+    const uint64_t heads = __ballot(first || !have);
+    const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
+    if (headless && S.carry_U > U) U = S.carry_U;
+    Row kr_s = 1, kr_e = 0;
+    if (have_krc) {
+        if (first && psrc) kr_s = (Row)krc.x;
+        if (have && !dup && psrc && !next_same) kr_e = (Row)krc.y;
+    } else {
+        if (first && psrc) kr_s = (Row)C.kmer_ranges[2 * kmer];
+        if (have && !dup && psrc && !next_same) kr_e = (Row)C.kmer_ranges[2 * kmer + 1];
+    }
+    const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
+    const Row c_s = U, c_e = next_same ? nstart - 1 : kr_e;                        // :579-589
+    const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
+    uint32_t stot;
+    const uint32_t soff = excl_sum_bits<2>((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
+    const uint32_t q0 = S.n_src + soff;                    // sources appended before this child
+    const bool not_full0 = q0 < room;                      // next_path != end at step A
+    if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
+    if (a_valid && not_full0) write_source<NARROW>(C.chd, n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
+    const uint32_t qc = q0 + (a_valid ? 1u : 0u);
+    if (c_valid && qc < room) write_source<NARROW>(C.chd, n + qc, c_s, c_e, kmer, s_probs[kmer]);
+    // survivors keep sorted order in the next parent list
+    const bool surv = have && !dup;
+    const uint64_t sm = __ballot(surv);
+    if (surv) gst(C.sb, C.nord_off + ((S.n_surv + (uint32_t)prefix_popc(sm)) << 2), idx);
+    S.n_surv += (uint32_t)__popcll(sm);
+    // update_seeds(child, false), :601 -- validity was decided at creation
+    const bool sv = surv && (sb_ & KEYB_SEED_FLAG);
+    const uint64_t svm = __ballot(sv);
+    if (sv) {
+        const uint32_t pos = S.n_seedp + (uint32_t)prefix_popc(svm);
+        // path.sa_checked_ = true (no value returned: no round trip)
+        __hip_atomic_fetch_or(reinterpret_cast<UNC_AS_GLOBAL uint32_t *>(C.chd + (idx << PATH_SHIFT) + 12u), META_SA_CHECKED, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (pos < C.max_seed_paths) {
+            SeedPath sp; sp.start = start; sp.count = 1; sp.evt = C.event_i;
+            sp.ref_len = (uint32_t)(sb_ >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
+            gst(C.sb, C.seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
+        }
+    }
+    S.n_seedp += (uint32_t)__popcll(svm);
+    // carries into the next pass
+    S.carry_kmer = bcast32(kmer, (int)nv - 1);
+    if constexpr (NARROW) S.carry_U = bcast32(U, (int)nv - 1); else S.carry_U = bcast64(U, (int)nv - 1);
+    S.n_src += stot;
+    if (S.n_src > room) S.n_src = room;
+}
+
+// the walk over sorted keys that lie in global memory (few children: the bitonic network's output; 128-bit keys)
 template <bool NARROW>
 static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
     const kargs_t A = uniform_ptr(A_);
     const gptr_t sb = uniform_ptr(sb_);
     using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
-    const uint32_t n = ctx_get(s_w.nchild), cur = ctx_get(s_w.cur), event_i = ctx_get(s_w.event_i);
-    const uint32_t kl = ctx_get(s_w.kl);
-    uint32_t n_seedp = ctx_get(s_w.n_seedp);
-    const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
-    const float source_prob = A->ix.thresholds[0];      // Mapper::get_source_prob, mapper.cpp:169-171
-    const UNC_AS_GLOBAL uint64_t *const kmer_ranges = (const UNC_AS_GLOBAL uint64_t *)A->ix.kmer_ranges;
+    const WalkConst<NARROW> C = walk_const<NARROW>(A, sb);
+    WalkState<NARROW> S;
+    S.n_seedp = ctx_get(s_w.n_seedp);
+    const uint32_t n = C.n, kl = ctx_get(s_w.kl);
+    const float source_prob = C.source_prob;
     const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
-    const uint32_t chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT), nord_off = A->sc.off_order + (cur ^ 1u) * (max_paths << 2);
-    const uint32_t seedp_off = A->sc.off_seedp;
     const UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<const UNC_AS_GLOBAL SortKey *>(sb + A->sc.off_keys + A->sc.keys_cap * (uint32_t)sizeof(SortKey));
     const UNC_AS_GLOBAL uint64_t *const skeys64 = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(skeys);
     const UNC_AS_GLOBAL uint64_t *const infow = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);   // narrow keys: info words by creation index
-    const gptr_t chd = sb + chd_off;
 
-    uint32_t n_surv = 0, n_src = 0;
-    uint32_t carry_kmer = NKMER;
-    Row carry_U = 0;
-    uint64_t carry_range = ~0ull, carry_w = 0;
-    const uint32_t room = max_paths - n;   // sources that still fit
     // narrow keys: the sorted keys of the pass after next and the info words (seed_prob, idx, flags, k-mer) they
     // point to for the next pass are fetched while this pass is worked on; a lane's successor comes from
     // its neighbour lane, the last lane's from the next pass
@@ -1580,8 +1728,9 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
         const uint32_t i = base + (uint32_t)lane;
         const bool have = i < n;
         const bool has_next = i + 1 < n;
+        const uint32_t nv = n - base < WAVE ? n - base : WAVE;
         Row start, end, nstart;
-        uint64_t sb_;                         // sb_: info word of the child that survives at this position
+        uint64_t sbw;                         // info word of the child that survives at this position
         uint32_t kmer, nkmer;
         bool dup;
         ulonglong2 krc = make_ulonglong2(1ull, 0ull);
@@ -1599,23 +1748,7 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
                 const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
                 if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
             }
-            const uint64_t ri = ki >> 16, rn = kn >> 16;
-            start = (Row)(ri >> kl); end = start + (Row)(ri & ((1ull << kl) - 1ull));
-            nstart = (Row)(rn >> kl);
-            kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
-            nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
-            dup = has_next && rn == ri;
-            // among equal ranges the reference keeps the highest (seed_prob, creation order): a running max of
-            // the info words over each run, read off at the run's last position
-            uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
-            if (lane == 0) pr = carry_range;
-            const bool rhead = !have || ri != pr;
-            sb_ = seg_incl_max64(bi, rhead);
-            const uint64_t rheads = __ballot(rhead);
-            if ((rheads & ((2ull << lane) - 1ull)) == 0 && carry_w > sb_) sb_ = carry_w;
-            const uint32_t nvv = n - base < WAVE ? n - base : WAVE;
-            carry_range = bcast64(ri, (int)nvv - 1);
-            carry_w = bcast64(sb_, (int)nvv - 1);
+            walk_decode_narrow<NARROW>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
         } else {
             SortKey ki, kn;
             ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
@@ -1626,72 +1759,143 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
             kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
             nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
             dup = has_next && kn.a == ki.a;          // equal fm_range_, :569
-            sb_ = ki.b;                              // sorted by seed_prob inside the run: the last one survives
+            sbw = ki.b;                              // sorted by seed_prob inside the run: the last one survives
         }
-        const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
-        uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
-        if (lane == 0) pk = carry_kmer;
-        const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
-        const bool next_same = has_next && nkmer == kmer;
-        const bool psrc = have && s_probs[have ? kmer : 0] >= source_prob;
-        // unchecked_range.start_ when step C runs for i = running max of (end + 1) in the k-mer group
-        Row U;
-        if constexpr (NARROW) U = seg_incl_max32(have ? end + 1u : 0u, first || !have);
-        else U = seg_incl_max64(have ? end + 1 : 0, first || !have);
-        const uint64_t heads = __ballot(first || !have);
-        const bool headless = (heads & ((2ull << lane) - 1ull)) == 0;   // group began in an earlier pass
-        if (headless && carry_U > U) U = carry_U;
-        Row kr_s = 1, kr_e = 0;
-        if (kl) {
-            if (first && psrc) kr_s = (Row)krc.x;
-            if (have && !dup && psrc && !next_same) kr_e = (Row)krc.y;
-        } else {
-            if (first && psrc) kr_s = (Row)kmer_ranges[2 * kmer];
-            if (have && !dup && psrc && !next_same) kr_e = (Row)kmer_ranges[2 * kmer + 1];
-        }
-        const bool a_valid = first && psrc && kr_s <= start - 1;                       // :549-557
-        const Row c_s = U, c_e = next_same ? nstart - 1 : kr_e;                        // :579-589
-        const bool c_valid = have && !dup && psrc && c_s <= c_e;                       // :592
-        uint32_t stot;
-        const uint32_t soff = excl_sum_bits<2>((a_valid ? 1u : 0u) + (c_valid ? 1u : 0u), &stot);
-        const uint32_t q0 = n_src + soff;                      // sources appended before this child
-        const bool not_full0 = q0 < room;                      // next_path != end at step A
-        if (first && psrc && not_full0) atomicOr(&s_flags[(kmer & 63u) >> 1], 1u << (((kmer & 1u) << 4) + (kmer >> 6)));   // :547
-        if (a_valid && not_full0) write_source<NARROW>(chd, n + q0, kr_s, start - 1, kmer, s_probs[kmer]);
-        const uint32_t qc = q0 + (a_valid ? 1u : 0u);
-        if (c_valid && qc < room) write_source<NARROW>(chd, n + qc, c_s, c_e, kmer, s_probs[kmer]);
-        // survivors keep sorted order in the next parent list
-        const bool surv = have && !dup;
-        const uint64_t sm = __ballot(surv);
-        if (surv) gst(sb, nord_off + ((n_surv + (uint32_t)prefix_popc(sm)) << 2), idx);
-        n_surv += (uint32_t)__popcll(sm);
-        // update_seeds(child, false), :601 -- validity was decided at creation
-        const bool sv = surv && (sb_ & KEYB_SEED_FLAG);
-        const uint64_t svm = __ballot(sv);
-        if (sv) {
-            const uint32_t pos = n_seedp + (uint32_t)prefix_popc(svm);
-            // path.sa_checked_ = true (no value returned: no round trip)
-            __hip_atomic_fetch_or(reinterpret_cast<UNC_AS_GLOBAL uint32_t *>(chd + (idx << PATH_SHIFT) + 12u), META_SA_CHECKED, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (pos < max_seed_paths) {
-                SeedPath sp; sp.start = start; sp.count = 1; sp.evt = event_i;
-                sp.ref_len = (uint32_t)(sb_ >> KEYB_MOVES_SHIFT) & 31u; sp.pad = 0;
-                gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
-            }
-        }
-        n_seedp += (uint32_t)__popcll(svm);
-        // carries into the next pass
-        const uint32_t nv = n - base < WAVE ? n - base : WAVE;
-        carry_kmer = bcast32(kmer, (int)nv - 1);
-        if constexpr (NARROW) carry_U = bcast32(U, (int)nv - 1); else carry_U = bcast64(U, (int)nv - 1);
-        n_src += stot;
-        if (n_src > room) n_src = room;
+        walk_core<NARROW>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, kl != 0, krc, nv, lane);
         if (kl) bq1 = i + 2 * WAVE < n ? infow[kq1 & 0xFFFFu] : 0ull;
     }
-    uint32_t tst = 0;
-    if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
-    if (lane == 0) { s_w.n_surv = n_surv; s_w.n_src = n_src; s_w.n_seedp = n_seedp; s_w.tstatus |= tst; }
-    wave_sync();
+    walk_finish<NARROW>(C, S, lane);
+}
+
+// narrow keys, many children: the LAST merge -- the stays with everything else -- and the walk in one.  A tile of sorted keys
+// is left in LDS and walked there; the sorted keys never go to memory (the kernel is bound by the bytes it moves).  The
+// walk looks one key ahead, so a tile's last key waits for the next tile.  Both inputs are ascending by construction
+// (phase E checks the parents' order, repair_run the moves, the unsorted run went through the network); should the output
+// not be, the read is marked UNC_READ_SORT_FAULT.
+static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1> KA_, KeyArr<4> KB_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    uint64_t *const s_tile = s_e;
+    const KeyArr<1> KA = ka_uniform(KA_);
+    const KeyArr<4> KB = ka_uniform(KB_);
+    const uint32_t n = KA.n + KB.n;
+    const WalkConst<true> C = walk_const<true>(A, sb);
+    WalkState<true> S;
+    S.n_seedp = ctx_get(s_w.n_seedp);
+    const uint32_t kl = A->ix.key_len_bits;
+    const float source_prob = C.source_prob;
+    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+    const UNC_AS_GLOBAL uint64_t *const infow = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);
+    uint32_t a0 = 0, b0 = 0;
+    uint64_t pend_key = 0;           // the previous tile's last key: walked first in this tile
+    bool have_pend = false, bad = false;
+    for (uint32_t o0 = 0; o0 < n; o0 += MERGE_TILE) {
+        const uint32_t d1 = o0 + MERGE_TILE < n ? o0 + MERGE_TILE : n;
+        const bool last_tile = d1 == n;
+        const uint32_t a1 = last_tile ? KA.n : merge_split(sb, KA, KB, d1, lane);
+        const uint32_t b1 = d1 - a1;
+        const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
+        {
+            uint64_t v[MERGE_C];
+#pragma unroll
+            for (uint32_t c = 0; c < MERGE_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                v[c] = 0;
+                if (i < na) v[c] = ka_load(sb, KA, a0 + i);
+                else if (i < tn) v[c] = ka_load(sb, KB, b0 + (i - na));
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < MERGE_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                if (i < tn) s_tile[mslot(i)] = v[c];
+            }
+        }
+        wave_sync();
+        const uint32_t d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
+        const uint32_t cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
+        uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+        while (__any(lo < hi)) {
+            if (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_tile[mslot(mid)] < s_tile[mslot(na + d - 1u - mid)]) lo = mid + 1u; else hi = mid;
+            }
+        }
+        uint32_t ia = lo, ib = d - lo;
+        uint64_t va = ia < na ? s_tile[mslot(ia)] : ~0ull, vb = ib < nb ? s_tile[mslot(na + ib)] : ~0ull;
+        uint64_t o[MERGE_C];
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c) {
+            const bool ta = va < vb;
+            o[c] = ta ? va : vb;
+            if (ta) ++ia; else ++ib;
+            const uint32_t idx = ta ? ia : na + ib;
+            const bool ok = ta ? ia < na : ib < nb;
+            uint64_t x = ~0ull;
+            if (ok && c + 1u < cnt) x = s_tile[mslot(idx)];
+            if (ta) va = x; else vb = x;
+        }
+        {   // the tile must come out ascending, and after the previous tile's last key
+            uint64_t last = o[0];
+            bool w = false;
+#pragma unroll
+            for (uint32_t c = 1; c < MERGE_C; ++c)
+                if (c < cnt) { w = w || !(o[c] > last); last = o[c]; }
+            uint64_t pl = (uint64_t)__shfl_up((unsigned long long)last, 1);
+            if (lane == 0) pl = pend_key;
+            if (cnt > 0 && !(o[0] > pl)) w = true;
+            if (__any(w)) bad = true;
+        }
+        // sorted tile at logical positions 1 .. tn, the waiting key at 0
+        wave_sync();
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c)
+            if (c < cnt) s_tile[mslot(1u + d + c)] = o[c];
+        if (lane == 0 && have_pend) s_tile[mslot(0)] = pend_key;
+        wave_sync();
+        // ---- the walk over logical positions [p0, p1): a key's successor sits one position on (none after the last key of all)
+        const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
+        uint64_t bq0 = 0, bq1 = 0;
+        {
+            const uint32_t pa = p0 + (uint32_t)lane, pb = pa + WAVE;
+            if (pa <= tn) bq0 = infow[s_tile[mslot(pa)] & 0xFFFFu];
+            if (pb <= tn) bq1 = infow[s_tile[mslot(pb)] & 0xFFFFu];
+        }
+        ulonglong2 krq = make_ulonglong2(1ull, 0ull);
+        if (p0 + (uint32_t)lane < p1) {
+            const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
+            if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+        }
+        for (uint32_t base = p0; base < p1; base += WAVE) {
+            const uint32_t p = base + (uint32_t)lane;
+            const bool have = p < p1;
+            const bool has_next = have && p < tn;
+            const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+            const uint64_t ki = have ? s_tile[mslot(p)] : ~0ull, kn = has_next ? s_tile[mslot(p + 1u)] : ~0ull;
+            const uint64_t bi = bq0;
+            uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
+            const uint64_t bf = bcast64(bq1, 0);
+            if (lane == WAVE - 1) bn = bf;
+            bq0 = bq1;
+            const ulonglong2 krc = krq;
+            krq = make_ulonglong2(1ull, 0ull);
+            if (p + WAVE < p1) {
+                const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
+                if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+            }
+            uint32_t start, end, nstart, kmer, nkmer;
+            uint64_t sbw;
+            bool dup;
+            walk_decode_narrow<true>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
+            walk_core<true>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, true, krc, nv, lane);
+            bq1 = p + 2 * WAVE <= tn ? infow[s_tile[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
+        }
+        pend_key = uniform64(s_tile[mslot(tn)]);
+        have_pend = true;
+        a0 = a1; b0 = b1;
+        wave_sync();
+    }
+    if (bad && lane == 0) s_w.tstatus |= UNC_READ_SORT_FAULT;
+    walk_finish<true>(C, S, lane);
 }
 
 // ---------------- F: remaining full-range sources, :605-624; the next parent list is complete after it ----------------
@@ -1949,7 +2153,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             if (ctx_get(s_w.nchild) > 0) {
                 phase_S<NARROW>(A, sb, lane);
                 clk.end(2, lane);
-                phase_W<NARROW>(A, sb, lane);
+                if (!ctx_get(s_w.walked)) phase_W<NARROW>(A, sb, lane);
                 clk.end(3, lane);
             }
             phase_F<NARROW>(A, sb, lane);

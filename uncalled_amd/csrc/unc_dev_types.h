@@ -123,6 +123,7 @@ struct DevIndex {
     const uint64_t *sa_dense;   // [seq_len + 1] full SA | LF-steps << 56, or null (then the sampled walk is used)
     const uint64_t *kmer_ranges;  // [1024][2]
     const float *model;         // [3][1024]: lv_means, lv_vars_x2, lognorm_denoms
+    const float *model4;        // [1024][4]: the same, one 16-byte row per k-mer (a lane that needs ONE k-mer's row: one access)
     const uint16_t *kmer_valid; // [64]: bit j of entry l = range of k-mer j*64+l is non-empty
     const uint32_t *fm32;       // rank table of a reference with fewer than 2^32 rows (8 words per 64 symbols, fm_dev.h), else null
     uint64_t primary, seq_len;

@@ -79,6 +79,7 @@ struct unc_index {
     uint16_t *d_kmer_valid = nullptr;
     uint64_t *d_sa_dense = nullptr;
     uint32_t *d_fm32 = nullptr;
+    float *d_model4 = nullptr;
     uint64_t device_bytes = 0;
     DevIndex dev;
 };
@@ -178,6 +179,7 @@ extern "C" void unc_index_free(unc_index_t *ix) {
     if (ix->d_kmer_valid) (void)hipFree(ix->d_kmer_valid);
     if (ix->d_sa_dense) (void)hipFree(ix->d_sa_dense);
     if (ix->d_fm32) (void)hipFree(ix->d_fm32);
+    if (ix->d_model4) (void)hipFree(ix->d_model4);
     delete ix;
 }
 
@@ -233,10 +235,16 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     HIPCHK(hipMalloc((void **)&ix->d_kmer_ranges, 2 * NKMER * 8));
     HIPCHK(hipMalloc((void **)&ix->d_model, 3 * NKMER * 4));
     HIPCHK(hipMemcpy(ix->d_model, ix->model.data(), 3 * NKMER * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<float> m4(4 * NKMER, 0.0f);
+        for (int k = 0; k < NKMER; ++k) { m4[4 * k] = ix->model[k]; m4[4 * k + 1] = ix->model[NKMER + k]; m4[4 * k + 2] = ix->model[2 * NKMER + k]; }
+        HIPCHK(hipMalloc((void **)&ix->d_model4, 4 * NKMER * 4));
+        HIPCHK(hipMemcpy(ix->d_model4, m4.data(), 4 * NKMER * 4, hipMemcpyHostToDevice));
+    }
     ix->device_bytes = bwt_bytes + n_sa * 8 + 2 * NKMER * 8 + 3 * NKMER * 4;
 
     DevIndex &d = ix->dev;
-    d.bwt = ix->d_bwt; d.sa = ix->d_sa; d.kmer_ranges = ix->d_kmer_ranges; d.model = ix->d_model;
+    d.bwt = ix->d_bwt; d.sa = ix->d_sa; d.kmer_ranges = ix->d_kmer_ranges; d.model = ix->d_model; d.model4 = ix->d_model4;
     d.primary = ix->primary; d.seq_len = n;
     for (int i = 0; i < 5; ++i) d.L2[i] = ix->L2[i];
     memcpy(d.thresholds, ix->thresholds, sizeof d.thresholds);
