@@ -38,11 +38,12 @@ constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
 constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
 __shared__ __attribute__((aligned(16))) float s_probs[NKMER];      // match log-probs of the current event
 __shared__ uint32_t s_flags[NKMER / 32];                            // sources_added_
-// one carved buffer for the per-pass staging of phase E (7.5 KB), reused as the merge tile of the sort, the source list of
-// phase F and the sampled directory of add_seed: with the probs table the wavefront stays under 13 KB of LDS (12 per CU)
-constexpr uint32_t S_E_WORDS = CAND_MAX + 2 * WAVE + 4 * WAVE + (3 * WAVE + CHILD_MAX) / 2 + CAND_MAX / 4;
+// one carved buffer for the per-pass staging of phase E, reused as the merge tile of the sort, the source list of phase F and
+// the sampled directory of add_seed: with the probs table a wavefront stays under 10 KB of LDS, so that 16 fit a CU
+// (phase E, 32-bit rows: FM results 2 KB | parents' rows 512 B | history 512 | last / sub / moves / meta 4 x 256 | child
+// descriptors 640 | the children's run positions 640; the candidate list shares the last two, which are written after it is dead)
+constexpr uint32_t S_E_WORDS = (CAND_MAX * 8 + 2 * WAVE * 4 + WAVE * 8 + 4 * WAVE * 4 + 2 * CHILD_MAX * 2) / 8;
 __shared__ __attribute__((aligned(16))) uint64_t s_e[S_E_WORDS];
-__shared__ uint16_t s_ckpos[CHILD_MAX];                             // narrow keys: a child's position in its run
 
 struct MapArgs {
     DevIndex ix;
@@ -848,12 +849,13 @@ constexpr uint32_t MERGE_MIN = 256;     // fewer children than this go straight 
 #define UNC_MERGE_REPAIR 1              // (tests build the emulator library with 0: the runs then reach the merge unrepaired, its check
 #endif                                  //  must notice and the event must take the bitonic network instead, with the same result)
 constexpr bool MERGE_REPAIR = UNC_MERGE_REPAIR != 0;
-constexpr uint32_t MERGE_C = 12;
+constexpr uint32_t MERGE_C = 9;
 constexpr uint32_t MERGE_TILE = MERGE_C * WAVE;
 // LDS slot of tile element i: one pad slot per 8 keys, so that lanes whose reading positions are a multiple of 8 keys
 // apart (the typical distance) do not all fall on the same banks
 __device__ __forceinline__ uint32_t mslot(uint32_t i) { return i + (i >> 3); }
 constexpr uint32_t MERGE_LDS_KEYS = MERGE_TILE + MERGE_TILE / 8 + 1;
+static_assert(MERGE_LDS_KEYS <= S_E_WORDS && NKMER * 4 <= S_E_WORDS * 8, "merge tile / source list must fit the staging buffer");
 
 // how many of the first d keys of merge(A, B) come from A (keys distinct): the first mid with !(A[mid] < B[d - 1 - mid]),
 // 16 probes per memory round trip (a scattered access costs the memory pipeline per LANE: four rounds of 16 are cheaper
@@ -1060,7 +1062,7 @@ __device__ __forceinline__ void write_source(gptr_t buf, uint32_t idx, uint64_t 
 
 
 #ifndef UNC_LB
-#define UNC_LB 3
+#define UNC_LB 4     // wavefronts per SIMD: 128 VGPRs and under 10 KB of LDS each -> 16 per CU (12 -> 16: -12.6 % on 50 k E. coli reads)
 #endif
 
 // ---- One event = a sequence of PHASES, each an out-of-line function.  Inlined into one kernel body, the phases kept every
@@ -1156,13 +1158,17 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     // the 32-bit rank table (fm32_get_neighbor)
     using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
     constexpr int RES_BITS = 30;                       // wide rows: packed FM result start << 30 | row count (0 = empty range)
-    uint64_t *const s_res = s_e;
-    Row *const s_pstart = reinterpret_cast<Row *>(s_e + CAND_MAX), *const s_pend = reinterpret_cast<Row *>(s_e + CAND_MAX + WAVE);
-    uint64_t *const s_phist = s_e + CAND_MAX + 2 * WAVE;          // the parents' k-mer history, slid for their children
+    uint64_t *const s_res = s_e;                      // [parent lane << 2 | base]
+    Row *const s_pstart = reinterpret_cast<Row *>(s_e + CAND_MAX), *const s_pend = s_pstart + WAVE;
+    uint64_t *const s_phist = reinterpret_cast<uint64_t *>(s_pend + WAVE);          // the parents' k-mer history, slid for their children
     float *const s_plast = reinterpret_cast<float *>(s_phist + WAVE), *const s_psubc = s_plast + WAVE;   // prob_sums_[length_] / the children's prob_sums_[0]
     uint32_t *const s_pmoves = reinterpret_cast<uint32_t *>(s_psubc + WAVE), *const s_pmeta = s_pmoves + WAVE;
-    uint32_t *const s_cdesc = s_pmeta + WAVE;
-    uint16_t *const s_cand = reinterpret_cast<uint16_t *>(s_cdesc + CHILD_MAX);
+    uint16_t *const s_cdesc = reinterpret_cast<uint16_t *>(s_pmeta + WAVE);         // per child: parent lane | type << 6 | child of a source << 9
+    uint16_t *const s_ckpos = s_cdesc + CHILD_MAX;                                   // narrow keys: a child's position in its run
+    uint16_t *const s_cand = s_cdesc;                                                // (dead before the descriptors are written)
+    static_assert(NARROW ? (CAND_MAX * 8 + 2 * WAVE * 4 + WAVE * 8 + 4 * WAVE * 4 + 2 * CHILD_MAX * 2 <= sizeof(s_e))
+                         : (CAND_MAX * 8 + 2 * WAVE * 8 + WAVE * 8 + 4 * WAVE * 4 + CHILD_MAX * 2 <= sizeof(s_e)), "phase E staging");
+    static_assert(CAND_MAX * 2 <= CHILD_MAX * 2 * 2, "candidate list inside the descriptor area");
 
     const FmView ix = fm_view(A);
     const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
@@ -1261,22 +1267,22 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                 if constexpr (NARROW) {
                     uint32_t ns, ne;
                     fm32_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
-                    s_res[ci] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull;      // row count | first row
+                    s_res[cd] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull;      // row count | first row
                 } else {
                     uint64_t ns, ne;
                     fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
-                    s_res[ci] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
+                    s_res[cd] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
                 }
             }
         }
         wave_sync();
         clk.end(9, lane);
         // children per parent, in the reference's order: stay, then bases 0..3
-        // bit j: j-th candidate of this lane has a non-empty range (four unconditional reads; the staging buffer
-        // extends past the result slots, and whatever lies beyond this lane's candidates is masked off)
-        uint32_t vmask = (s_res[coff] != 0 ? 1u : 0u) | (s_res[coff + 1] != 0 ? 2u : 0u) | (s_res[coff + 2] != 0 ? 4u : 0u) |
-                         (s_res[coff + 3] != 0 ? 8u : 0u);
-        vmask &= (1u << ncand) - 1u;
+        // bit b: the step with base b was asked for and left a non-empty range (a lane's four result slots; the slots of
+        // bases that were not asked for hold stale words and are masked off)
+        const uint32_t rb = (uint32_t)lane << 2;
+        uint32_t vmask = (s_res[rb] != 0 ? 1u : 0u) | (s_res[rb + 1] != 0 ? 2u : 0u) | (s_res[rb + 2] != 0 ? 4u : 0u) | (s_res[rb + 3] != 0 ? 8u : 0u);
+        vmask &= mask;
         const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
         uint32_t chtot;
         const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
@@ -1284,22 +1290,21 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         const uint32_t nwrite = chtot < room ? chtot : room;      // children that fit (:480,507,521)
         const bool visited = have && choff < room;                // reached before the buffer filled
         // work counter: the get_neighbor calls the reference makes (it stops at the cut-off)
-        if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask) < room) c_nbr += ncand;   // every call precedes the cut-off
+        if (choff + nch < room) c_nbr += ncand;                   // every call precedes the cut-off
         else
-            for (uint32_t j = 0; j < ncand; ++j)
-                if (choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << j) - 1u)) < room) c_nbr++;
+            for (uint32_t b = 0; b < 4; ++b)
+                if (((mask >> b) & 1u) && choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u)) < room) c_nbr++;
+        wave_sync();             // (the candidate list is dead: its space takes the descriptors)
         if constexpr (NARROW) {
             // creation position (inside this pass) of this lane's child of each type: stay, bases 0..3
             const bool is_src = pi >= n_surv_par;          // children of sources: the unsorted run
-            uint32_t cpos[5], cres[5];
+            uint32_t cpos[5];
             bool ex[5];
-            ex[0] = stay_ok; cpos[0] = choff; cres[0] = 0;
+            ex[0] = stay_ok; cpos[0] = choff;
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
-                const uint32_t jj = (uint32_t)__popc(mask & ((1u << b) - 1u));
-                ex[b + 1] = ((mask >> b) & 1u) && ((vmask >> jj) & 1u);
-                cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << jj) - 1u));
-                cres[b + 1] = coff + jj;
+                ex[b + 1] = (vmask >> b) & 1u;
+                cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u));
             }
 #pragma unroll
             for (uint32_t t = 0; t < 5; ++t) ex[t] = ex[t] && cpos[t] < nwrite;      // the max_paths cut-off
@@ -1329,21 +1334,17 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
 #pragma unroll
             for (uint32_t t = 0; t < 5; ++t)
                 if (ex[t]) {
-                    s_cdesc[cpos[t]] = (uint32_t)lane | (t << 6) | (cres[t] << 9) | (is_src ? 1u << 18 : 0u);
+                    s_cdesc[cpos[t]] = (uint16_t)((uint32_t)lane | (t << 6) | (is_src ? 1u << 9 : 0u));
                     s_ckpos[cpos[t]] = (uint16_t)kp[t];
                 }
         } else {
             uint32_t w = choff;
-            if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint32_t)lane; ++w; }
-            uint32_t jj = 0;
+            if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint16_t)lane; ++w; }
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
-                if (mask & (1u << b)) {
-                    if (vmask & (1u << jj)) {
-                        if (w < nwrite) s_cdesc[w] = (uint32_t)lane | ((b + 1u) << 6) | ((coff + jj) << 9);
-                        ++w;
-                    }
-                    ++jj;
+                if (vmask & (1u << b)) {
+                    if (w < nwrite) s_cdesc[w] = (uint16_t)((uint32_t)lane | ((b + 1u) << 6));
+                    ++w;
                 }
             }
         }
@@ -1398,7 +1399,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
             const uint32_t li = l0 + (uint32_t)lane;
             if (li < nwrite) {
                 const uint32_t d = s_cdesc[li];
-                const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (d >> 9) & 511u;
+                const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (pl << 2) | ((type - 1u) & 3u);
                 const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
                 const float last = s_plast[pl], subc = s_psubc[pl];
                 const uint64_t hist = s_phist[pl];
@@ -1420,7 +1421,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                 else { const uint64_t r = (cs << KEY_LEN_BITS) | (ce - cs); gst(sb, co, make_uint4((uint32_t)r, (uint32_t)(r >> 32), c.moves, c.meta)); }
                 gst(sb, co + 16u, make_uint4(__float_as_uint(c.last), __float_as_uint(subc), (uint32_t)c.hist, (uint32_t)(c.hist >> 32)));
                 if constexpr (NARROW) {
-                    const uint32_t run = (d >> 18) ? 5u : type;
+                    const uint32_t run = (d >> 9) ? 5u : type;
                     gst(sb, str_off + run * run_bytes + ((uint32_t)s_ckpos[li] << 3), key.a);
                     gst(sb, info_off + (gi << 3), key.b);
                     // the k-mer's own range, for the boundary test (see the sort): a one-row child on its first / last row
@@ -2278,6 +2279,6 @@ void launch_pool_init(const DevPool &B, hipStream_t st) {
     hipLaunchKernelGGL(k_pool_init, dim3((cap + 255) / 256), dim3(256), 0, st, B);
 }
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
-// register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits up to 16.
+// register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits 16.
 uint32_t map_kernel_waves_per_cu() { return 4 * UNC_LB; }
 }  // namespace unc
