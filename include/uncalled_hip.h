@@ -78,7 +78,10 @@ typedef struct {
     uint64_t n_nbr, n_sa, n_lf;         /* get_neighbor calls, SA lookups, LF steps inside them */
     /* winning SeedCluster (seed_tracker.hpp:40-66), zero when unmapped */
     uint64_t cl_ref_st, cl_ref_en_start, cl_ref_en_end;
-    uint32_t cl_evt_st, cl_evt_en, cl_total_len, pad;
+    uint32_t cl_evt_st, cl_evt_en, cl_total_len;
+    float map_ms;                       /* batch path: time the read spent on the device, first event taken up -> result written
+                                         * (device wall clock; the PAF `mt` tag, mapper.cpp:197).  Reads share wavefronts in time
+                                         * slices, so this is residence, not service time.  0 on the chunked / trace paths */
 } unc_hit_t;
 
 /* stage tap: per-read result of the event/normalisation kernel */

@@ -249,7 +249,7 @@ def case_sliced_scheduler(lib, oracle_lib, example, goldens, max_paths=10000, sl
     m = capi.Mapper(dev_index, params=p, n_slots=n_slots, n_waves=n_waves, slice_events=slice_events)
     hits = m.map_batch(raw, off, cal)
     again = m.map_batch(raw, off, cal)          # the rings are re-initialised per batch
-    for name in hits.dtype.names:
+    for name in capi.RESULT_FIELDS:
         assert np.array_equal(again[name], hits[name]), name
     oix = oracle_lib.Index(example["prefix"])
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True), "sliced")
@@ -277,7 +277,7 @@ def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2,
     m3 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=64)
     hits3 = m3.map_batch(raw, off, cal)
     assert m3.last_remap()[0] == 0
-    for name in hits.dtype.names:
+    for name in capi.RESULT_FIELDS:
         assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]), name
 
 

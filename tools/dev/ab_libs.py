@@ -71,7 +71,7 @@ for spec in sys.argv[2:]:
         if first is None:
             first = hits.copy()
         else:
-            bad = [f for f in hits.dtype.names if not np.array_equal(hits[f], first[f])]
+            bad = [f for f in capi.RESULT_FIELDS if not np.array_equal(hits[f], first[f])]
             same = "IDENTICAL" if not bad else "MISMATCH in %s (%d reads)" % (bad, int(sum((hits[f] != first[f]).sum() for f in bad)))
         print({k: round(v / tot, 3) for k, v in pc.items() if v})
         print(spec.split("/")[-1], "k_events ms:", [round(x, 2) for x in te], "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", same, flush=True)

@@ -43,7 +43,19 @@ HIT = np.dtype([("mapped", "<i4"), ("fwd", "<i4"), ("rid", "<i4"), ("status", "<
                 ("matches", "<u4"), ("n_events", "<u4"), ("event_i", "<u4"), ("mean_event_len", "<f4"),
                 ("n_nbr", "<u8"), ("n_sa", "<u8"), ("n_lf", "<u8"),
                 ("cl_ref_st", "<u8"), ("cl_ref_en_start", "<u8"), ("cl_ref_en_end", "<u8"),
-                ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("pad", "<u4")])
+                ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("map_ms", "<f4")])
+# every field of a hit but the timing one: what two runs over the same reads must agree on
+RESULT_FIELDS = tuple(n for n in HIT.names if n != "map_ms")
+
+
+def hits_digest(hits):
+    """sha256 over the result fields of a hit array (map_ms, a wall-clock measurement, zeroed)."""
+    import hashlib
+    h = hits.copy()
+    h["map_ms"] = 0
+    return hashlib.sha256(h.tobytes()).hexdigest()
+
+
 EVT_INFO = np.dtype([("n_events", "<u4"), ("total_events", "<u4"), ("len_sum", "<f4"), ("scale", "<f4"),
                      ("shift", "<f4"), ("pad", "<u4")])
 PATH = np.dtype([("fm_start", "<u8"), ("fm_end", "<u8"), ("event_moves", "<u4"), ("seed_prob", "<f4"),

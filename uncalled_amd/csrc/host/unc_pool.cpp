@@ -386,9 +386,6 @@ void MapPool::mapper_main() {
         if (b.used == 0) { grow(b, 1); b.raw[0] = 0; }
         const int rc = unc_map_batch(mapper_, (uint32_t)n, b.raw, b.off.data(), b.cal.data(), 0, nullptr, hits.data());
         if (rc != UNC_OK && rc != UNC_ERR_OVERFLOW) { std::cerr << "Error: " << unc_last_error() << "\n"; abort(); }
-        float ms_e = 0, ms_m = 0;
-        unc_mapper_last_timing(mapper_, &ms_e, &ms_m);
-        const float ms_per_read = (ms_e + ms_m) / (float)n;
         std::vector<Paf> out;
         out.reserve(n);
         for (size_t i = 0; i < n; ++i) {
@@ -396,9 +393,9 @@ void MapPool::mapper_main() {
             Paf p(b.meta[i].id, (uint16_t)(b.meta[i].channel_idx + 1), b.meta[i].start_sample);
             p.set_read_len(h.rd_len);
             if (h.mapped) p.set_mapped(h.rd_st, h.rd_en, unc_index_seq_name(ix_, h.rid), h.rf_st, h.rf_en, h.rf_len, h.fwd != 0, (uint16_t)h.matches);
-            // GPU time of the batch / reads in it: reads share the wavefronts, there is no per-read wall clock (the
-            // reference times Mapper::map_read on the read's own thread)
-            p.set_float(Paf::MAP_TIME, ms_per_read);
+            // the read's residence on the device, first event taken up -> result written (the reference times
+            // Mapper::map_read on the read's own thread, mapper.cpp:197; here reads share wavefronts in time slices)
+            p.set_float(Paf::MAP_TIME, h.map_ms);
             if (h.status)   // the reference's SeedTracker is unbounded: say so instead of printing a silent unmapped line
                 std::cerr << "Warning: read " << b.meta[i].id << ": device scratch overflow (status " << h.status
                           << ") even after re-mapping with more room; reported unmapped\n";

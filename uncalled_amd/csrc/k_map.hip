@@ -2046,6 +2046,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         uint32_t tstatus = 0;                        // UNC_READ_* bits (mirror of the tracker's status)
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
+        uint64_t t_start = (uint64_t)wall_clock64();  // when the read was taken up (a parked read brings its own)
         uint32_t slot = (resume && A->slot_map) ? A->slot_map[blockIdx.x] : blockIdx.x;
         bool restore = false;
         if (sliced) {
@@ -2093,6 +2094,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             T.mm.ref_st = st->max_map.ref_st; T.mm.rstart = st->max_map.rstart; T.mm.rend = st->max_map.rend;
             T.mm.evt_st = st->max_map.evt_st; T.mm.evt_en = st->max_map.evt_en; T.mm.total_len = st->max_map.total_len;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
+            if (restore) t_start = st->t_start;
             if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
             event_i = uniform32(event_i); n_parents = uniform32(n_parents); cur = uniform32(cur);
             if (restore) { if constexpr (PROF) { if (lane < 12) s_cyc[lane] = st->cyc[lane]; } }
@@ -2189,6 +2191,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
+            res.ticks = resume ? 0ull : (uint64_t)wall_clock64() - t_start; res.pad2 = 0;
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
             g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
         }
@@ -2202,7 +2205,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
                 st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
-                st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf;
+                st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; } }
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];

@@ -86,6 +86,7 @@ struct alignas(16) SlotState {
     float len_sum;
     ClusterVal max_map;
     uint64_t n_nbr, n_sa, n_lf;
+    uint64_t t_start;        // device wall clock when the read's first event was taken up
     uint32_t sources_added[NKMER / 32];
     uint64_t cyc[12];        // phase cycle counters of the read so far (sliced batch mode)
 };
@@ -211,6 +212,8 @@ struct alignas(16) DevResult {
     uint32_t done, status, event_i, pad;
     ClusterVal cluster;
     uint64_t n_nbr, n_sa, n_lf;
+    uint64_t ticks;    // device wall clock ticks from the read's first event to this result
+    uint64_t pad2;
     uint64_t cyc[12];  // shader-clock cycles per phase: P, E(rest), S, W, F, T(sa), T(add_seed), G, E1, E2, E3, E4
 };
 

@@ -443,6 +443,7 @@ struct unc_mapper {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
+    float wall_khz = 0;            // device wall clock rate (ticks per ms)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
     DevPool pool{};                // leaves of the seed-cluster sets, shared by every read in flight
     DevScratch big{};              // scratch with a longer leaf directory for the reads that outgrew a slot's (kept between batches)
@@ -634,6 +635,11 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         bytes += sizeof(SchedCtl) + 2 * (size_t)cap * sizeof(SchedCell);
     }
     m->device_bytes = bytes;
+    {
+        int khz = 0;
+        HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ix->device));
+        m->wall_khz = (float)khz;
+    }
     HIPCHK(hipStreamCreate(&m->stream));
     for (auto &e : m->ev) HIPCHK(hipEventCreate(&e));
     guard.p = nullptr;
@@ -711,8 +717,9 @@ static uint32_t event_to_bp(const unc_params_t &P, uint32_t evt_i, float mean_ev
 
 // Mapper::set_ref_loc (mapper.cpp:708-728) + Paf::set_mapped / set_read_len (read_buffer.cpp:133-155,264-267)
 static void fill_hit(const unc_index *ix, const unc_params_t &P, const DevResult &res, const unc_evt_info_t &inf, uint64_t raw_len,
-                     unc_hit_t *h) {
+                     unc_hit_t *h, float ticks_per_ms = 0.0f) {
     memset(h, 0, sizeof *h);
+    h->map_ms = ticks_per_ms > 0.0f ? (float)((double)res.ticks / (double)ticks_per_ms) : 0.0f;
     h->rid = -1;
     h->status = res.status;
     h->n_events = inf.n_events;
@@ -836,7 +843,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     }
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
-        fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i]);
+        fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i], m->wall_khz);
         if (hits[i].status) worst = UNC_ERR_OVERFLOW;
     }
     if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise pool_chunks / max_clusters / max_seed_paths");
