@@ -202,6 +202,10 @@ void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms);
 /* mean lifetime of the persistent wavefronts of the last batch's k_map launch / the launch duration (both from the
  * device wall clock): 1.0 = every wavefront worked until the end, lower = idle tail behind the longest reads */
 double unc_mapper_last_wave_busy(const unc_mapper_t *m);
+/* what the code object says about the k_map instantiation this mapper launches (hipFuncGetAttributes): [0] VGPRs, [1] scratch
+ * bytes per lane (spills), [2] static LDS bytes per wavefront, [3] max threads per block, [4] wavefronts per CU the launch
+ * bounds are set for, [5] 1 = the 32-bit-row / merged-run instantiation (references below 2^32 rows) */
+int unc_mapper_kernel_info(const unc_mapper_t *m, uint32_t *out6);
 
 /* ---- chunked (realtime) path: replaces RealtimePool + per-channel Mapper::new_read(Chunk&) / add_chunk /
  * process_chunk / map_chunk (realtime_pool.cpp:74-142,349-358; mapper.cpp:210-431) with the deterministic

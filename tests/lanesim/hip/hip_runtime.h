@@ -281,6 +281,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 1ull << 33; *t = 1ull << 34; return 0; }
 enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
 static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 100000; return 0; }
+struct hipFuncAttributes { int numRegs; size_t localSizeBytes, sharedSizeBytes; int maxThreadsPerBlock; };
+static inline hipError_t hipFuncGetAttributes(hipFuncAttributes *a, const void *) { a->numRegs = 0; a->localSizeBytes = a->sharedSizeBytes = 0; a->maxThreadsPerBlock = 64; return 0; }
 struct hipPointerAttribute_t { int type; };
 constexpr int hipMemoryTypeHost = 0, hipMemoryTypeDevice = 1;
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeDevice; return 0; }

@@ -118,6 +118,8 @@ def load(path=None):
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.unc_mapper_last_remap.restype = None
+    L.unc_mapper_kernel_info.argtypes = [vp, vp]
+    L.unc_mapper_kernel_info.restype = i32
     L.unc_mapper_geometry.argtypes = [vp, vp]
     L.unc_mapper_geometry.restype = None
     L.unc_mapper_set_profile.argtypes = [vp, C.c_int]
@@ -301,6 +303,14 @@ class Mapper:
         out = np.zeros(5, dtype=np.uint32)
         self.L.unc_mapper_geometry(self.h, out.ctypes.data)
         return dict(zip(("n_waves", "n_slots", "slice_events", "pool_chunks", "max_clusters"), (int(x) for x in out)))
+
+    def kernel_info(self):
+        """Register / scratch / LDS figures of the k_map instantiation this mapper launches, read off the code object."""
+        out = np.zeros(6, dtype=np.uint32)
+        _check(self.L, self.L.unc_mapper_kernel_info(self.h, out.ctypes.data))
+        d = dict(zip(("vgprs", "scratch_bytes_per_lane", "lds_bytes", "max_threads", "waves_per_cu", "rows32"), (int(x) for x in out)))
+        d["rows32"] = bool(d["rows32"])
+        return d
 
     def set_profile(self, on=True):
         self.L.unc_mapper_set_profile(self.h, 1 if on else 0)

@@ -2284,4 +2284,13 @@ void launch_pool_init(const DevPool &B, hipStream_t st) {
 // resident single-wave workgroups per CU for the persistent grid: UNC_LB waves on each of the 4 SIMDs (launch bounds =
 // register budget); the LDS footprint (under 10 KB of the CU's 160 KB) admits 16.
 uint32_t map_kernel_waves_per_cu() { return 4 * UNC_LB; }
+int map_kernel_attributes(bool narrow, bool profile, uint32_t *out4) {
+    hipFuncAttributes a;
+    const void *f = narrow ? (profile ? (const void *)k_map<true, true> : (const void *)k_map<false, true>)
+                           : (profile ? (const void *)k_map<true, false> : (const void *)k_map<false, false>);
+    const hipError_t e = hipFuncGetAttributes(&a, f);
+    if (e != hipSuccess) return (int)e;
+    out4[0] = (uint32_t)a.numRegs; out4[1] = (uint32_t)a.localSizeBytes; out4[2] = (uint32_t)a.sharedSizeBytes; out4[3] = (uint32_t)a.maxThreadsPerBlock;
+    return 0;
+}
 }  // namespace unc

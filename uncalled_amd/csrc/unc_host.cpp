@@ -859,6 +859,13 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
 
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
+extern "C" int unc_mapper_kernel_info(const unc_mapper_t *m, uint32_t *out6) {
+    if (!m || !out6) return fail(UNC_ERR_ARG, "null argument");
+    const bool narrow = m->ix->dev.key_len_bits != 0;
+    if (map_kernel_attributes(narrow, false, out6)) return fail(UNC_ERR_HIP, "hipFuncGetAttributes failed");
+    out6[4] = map_kernel_waves_per_cu(); out6[5] = narrow ? 1u : 0u;
+    return UNC_OK;
+}
 extern "C" void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5) {
     out5[0] = m->n_waves; out5[1] = m->n_slots; out5[2] = m->sched.ctl ? m->slice_events : 0u;
     out5[3] = m->pool.n_chunks; out5[4] = m->sc.max_clusters;

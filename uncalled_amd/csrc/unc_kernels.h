@@ -15,6 +15,7 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
 void launch_sched_init(const DevSched &S, hipStream_t st);
 void launch_pool_init(const DevPool &B, hipStream_t st);
 uint32_t map_kernel_waves_per_cu();
+int map_kernel_attributes(bool narrow, bool profile, uint32_t *out4);   // VGPRs, scratch bytes / lane, LDS bytes, max threads
 void launch_kmer_ranges(const DevIndex &ix, uint64_t *out2048, hipStream_t st);
 void launch_fm_neighbor(const DevIndex &ix, uint32_t n, const uint64_t *s, const uint64_t *e, const uint8_t *b, uint64_t *os,
                         uint64_t *oe, hipStream_t st);
