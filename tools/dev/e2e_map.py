@@ -37,12 +37,50 @@ for f0 in range(0, n, per_file):
 t_write = time.time() - t0
 del sim
 torch.cuda.empty_cache()
+# ---- how fast the files can be read at all (Fast5Reader alone, one thread, page cache warm from the write): the loader's ceiling
 t0 = time.time()
-r = subprocess.run([sys.executable, "-m", "uncalled_amd", "map", str(prefix), str(d)], cwd=str(ROOT), capture_output=True, text=True)
+conf = unc.Conf()
+rd = unc.Fast5Reader(conf)
+for f in files:
+    rd.add_fast5(str(f))
+n_read = 0
+while True:
+    rd.fill_buffer()
+    if rd.buffer_size() == 0:
+        break
+    while rd.buffer_size():
+        rd.pop_read()
+        n_read += 1
+t_reader = time.time() - t0
+
+# ---- the CLI: PAF lines are time-stamped as they arrive, so that start-up (interpreter, index load, dense SA, first batch) and the
+# steady state can be told apart
+import select
+t0 = time.time()
+p = subprocess.Popen([sys.executable, "-u", "-m", "uncalled_amd", "map", str(prefix), str(d)], cwd=str(ROOT), stdout=subprocess.PIPE,
+                     stderr=subprocess.PIPE, text=True, bufsize=1)
+stamps, mapped, n_lines = [], 0, 0
+for line in p.stdout:
+    if not line or line.startswith("#"):
+        continue
+    n_lines += 1
+    if line.split("\t")[2] != "*":
+        mapped += 1
+    if n_lines % 1000 == 1:
+        stamps.append((time.time() - t0, n_lines))
+err = p.stderr.read()
+p.wait()
 dt = time.time() - t0
-lines = [l for l in r.stdout.splitlines() if l and not l.startswith("#")]
-mapped = sum(1 for l in lines if l.split("\t")[2] != "*")
+stamps.append((dt, n_lines))
+t_first = stamps[0][0]
+# steady state: from the first line of the SECOND half of the output to the last line
+half = [x for x in stamps if x[1] >= n_lines // 2]
+steady = (n_lines - half[0][1]) / (dt - half[0][0]) if len(half) > 1 and dt > half[0][0] else None
 print(json.dumps({"workload": "python -m uncalled_amd map <ecoli_syn> <dir of multi-fast5 files>", "reads": n, "fast5_files": len(files),
                   "fast5_bytes": sum(f.stat().st_size for f in files), "wall_s_incl_process_start_and_index_load": dt,
-                  "reads_per_sec_end_to_end": len(lines) / dt, "paf_lines": len(lines), "mapped": mapped, "rc": r.returncode,
-                  "fast5_write_s": t_write, "stderr_tail": r.stderr[-300:]}))
+                  "reads_per_sec_end_to_end": n_lines / dt, "first_paf_line_after_s": t_first,
+                  "reads_per_sec_steady_state": steady, "steady_state_note": "second half of the PAF lines, by arrival time in the parent process",
+                  "fast5_reader_alone_reads_per_sec": n_read / t_reader if t_reader > 0 else None,
+                  "fast5_reader_note": "Fast5Reader.pop_read over the same files on one thread, nothing else running: the ceiling of MapPool's loader thread",
+                  "paf_lines": n_lines, "mapped": mapped, "rc": p.returncode,
+                  "fast5_write_s": t_write, "stderr_tail": err[-300:]}))

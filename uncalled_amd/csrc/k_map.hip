@@ -91,78 +91,80 @@ __device__ __forceinline__ uint32_t sched_pop(SchedQueue *q, SchedCell *cells, u
 }
 
 struct Tracker {
-    uint32_t n, n_lens, max1, max2, status, n_leaves, n_alloc;
+    uint32_t n, n_lens, max1, max2, status, n_alloc;      // n_alloc: nodes taken from the read's own chunks so far
     float len_sum;
     ClusterVal mm;
 };
 
-// SeedTracker's std::set<SeedCluster> as a two-level B+-tree (layout: unc_dev_types.h, ClusterKey): a per-read directory
-// of leaves (first key + pool index, kept sorted) over leaves of up to 64 clusters each (one lane per cluster), values
-// inline.  Insert / erase touch one leaf (a lane-parallel shift inside 64 entries) plus, once every ~32 inserts, a leaf
-// split; nothing is ever O(#clusters) but the directory shift of a split (256 entries per memory round trip).
-constexpr uint32_t LEAF = LEAF_KEYS;
-constexpr uint32_t LEAF_NONE = 0xFFFFFFFFu;
+// SeedTracker's std::set<SeedCluster> (ordered by ref_en_.start descending, evt_en_ descending) as a GRID OF BUCKETS over
+// ref_en_.start.  add_seed only ever looks at the clusters whose start lies in [seed start - seed event, seed start]: from
+// lower_bound(seed) the reference scans towards smaller starts, takes the best-supported cluster the seed can extend, and stops
+// at the first cluster that lies more than `event` rows back (seed_tracker.cpp:169-191: in_range needs r2 - r1 <= e2 - e1 <=
+// e2, a cluster further back is never a candidate and ends the scan).  Inside that window the scan's outcome does not depend
+// on any order but the set's own tie-break (among equally long candidates the first in set order), so a bucket is an UNORDERED
+// array: nodes of NODE_K clusters (hot key 16 B + cold part 32 B each) chained from a per-read table of bucket heads.  A seed
+// costs the heads of its window's buckets (one coalesced load), their nodes (one load, one lane per cluster) and a store;
+// insert = append, erase = move the node's last cluster into the hole.  No directory, nothing to shift, nothing to split.
+// The bucket width (DevIndex::bucket_shift) is set per index so that a window of max_events rows spans at most 9 buckets
+// (9 x 7 = 63 lanes) and a read has at most 2^16 buckets.  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
+// directory search, leaf load and leaf shift were three to five dependent memory round trips per seed.)
+constexpr uint32_t NODE_K = 7;
+constexpr uint32_t NODE_BYTES = 384;                   // header 16 + 7 hot keys + 7 cold parts = 352, padded to 3 x 128
+constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;
+constexpr uint32_t CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;      // nodes per pool chunk (512)
+constexpr uint32_t WIN_BUCKETS = 9;
+constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
+struct alignas(16) NodeHdr { uint32_t count, next, pad0, pad1; };            // next: node id + 1 (0: end of the chain)
+static_assert(CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES && NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES, "node layout");
+static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32, "seed-cluster record layout");
 struct PoolView {          // DevPool with its arrays typed as global memory
-    gptr_t leaves;
-    UNC_AS_GLOBAL uint32_t *cnt;
+    gptr_t nodes;
     SchedQueue *q;
     SchedCell *cells;
     uint32_t cap_mask;
 };
 struct TrackerMem {
-    gptr_t sb;             // the read's slot: directory and chunk list live there
-    uint32_t off_dir;      // DirEnt [max_leaves]
-    uint32_t off_chunks;   // u32 [max_leaves / 64 + 1]
-    uint32_t max_leaves;
-    PoolView pool;         // leaves
+    gptr_t sb;             // the read's slot: bucket heads and chunk list live there
+    uint32_t off_heads;    // u32 [n_buckets]: first node of the bucket + 1 (0: empty)
+    uint32_t off_chunks;   // u32 [max_nodes / CHUNK_NODES + 1]
+    uint32_t max_nodes;
+    uint32_t n_buckets, shift;
+    PoolView pool;         // nodes
 };
-__device__ __forceinline__ gptr_t tm_leaf_ptr(const TrackerMem &M, uint32_t leaf) { return M.pool.leaves + (size_t)leaf * LEAF_BYTES; }
-__device__ __forceinline__ ClusterKey lf_hot(cgptr_t lp, uint32_t slot) { return gld<ClusterKey>(lp, slot << 4); }
-__device__ __forceinline__ ClusterCold lf_cold(cgptr_t lp, uint32_t slot) { return gld<ClusterCold>(lp, LEAF_COLD_OFF + (slot << 5)); }
-__device__ __forceinline__ void lf_hot_st(gptr_t lp, uint32_t slot, const ClusterKey &k) { gst(lp, slot << 4, k); }
-__device__ __forceinline__ void lf_cold_st(gptr_t lp, uint32_t slot, const ClusterCold &c) { gst(lp, LEAF_COLD_OFF + (slot << 5), c); }
-__device__ __forceinline__ DirEnt tm_dir(const TrackerMem &M, uint32_t i) { return gld<DirEnt>(M.sb, M.off_dir + (i << 4)); }
-__device__ __forceinline__ void tm_dir_st(const TrackerMem &M, uint32_t i, const DirEnt &k) { gst(M.sb, M.off_dir + (i << 4), k); }
-__device__ __forceinline__ void tm_dir_first(const TrackerMem &M, uint32_t i, const ClusterKey &k, uint32_t leaf) {
-    DirEnt f; f.rstart = k.rstart; f.evt_en = k.evt_en; f.leaf = leaf;
-    tm_dir_st(M, i, f);
-}
-__device__ __forceinline__ uint32_t tm_cnt(const TrackerMem &M, uint32_t leaf) { return M.pool.cnt[leaf]; }
-__device__ __forceinline__ void tm_cnt_st(const TrackerMem &M, uint32_t leaf, uint32_t c) { M.pool.cnt[leaf] = c; }
-static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32 && sizeof(DirEnt) == 16, "seed-cluster record layout");
 
-template <class K> __device__ __forceinline__ bool key_less(const K &k, uint64_t r2, uint32_t e2) {
-    // operator< of seed_tracker.cpp:97-102: ref_en_.start descending, then evt_en_ descending
-    return k.rstart > r2 || (k.rstart == r2 && k.evt_en > e2);
-}
-
-// A fresh leaf for this read: the next one of its newest chunk, or the first of a chunk popped off the pool's ring.
-// LEAF_NONE when the directory is full or the pool has run dry (the read then overflows and is mapped again later).
-__device__ __forceinline__ uint32_t tracker_new_leaf(Tracker &T, const TrackerMem &M, int lane) {
+// A fresh node for this read: the next one of its newest chunk, or the first of a chunk popped off the pool's ring.
+// NODE_NONE when the read has used up its allowance or the pool has run dry (the read then overflows and is mapped again later).
+__device__ __forceinline__ uint32_t tracker_new_node(Tracker &T, const TrackerMem &M, int lane) {
     const uint32_t a = T.n_alloc;
-    if (a >= M.max_leaves) return LEAF_NONE;
+    if (a >= M.max_nodes) return NODE_NONE;
     uint32_t chunk;
-    if ((a & (CHUNK_LEAVES - 1)) == 0) {
+    if ((a & (CHUNK_NODES - 1)) == 0) {
         uint32_t c = SCHED_EMPTY;
         if (lane == 0) {
             c = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
-            if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_LEAVES) << 2), c);
+            if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2), c);
         }
         chunk = bcast32(c, 0);
-        if (chunk == SCHED_EMPTY) return LEAF_NONE;
+        if (chunk == SCHED_EMPTY) return NODE_NONE;
     } else {
-        chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_LEAVES) << 2)));
+        chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2)));
     }
     T.n_alloc = a + 1;
-    return chunk * CHUNK_LEAVES + (a & (CHUNK_LEAVES - 1));
+    return chunk * CHUNK_NODES + (a & (CHUNK_NODES - 1));
 }
 
 // the read is over: its chunks go back to the pool
 __device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
-    const uint32_t n_chunks = (T.n_alloc + CHUNK_LEAVES - 1) / CHUNK_LEAVES;
+    const uint32_t n_chunks = (T.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
     for (uint32_t i = (uint32_t)lane; i < n_chunks; i += WAVE)
         sched_push(M.pool.q, M.pool.cells, M.pool.cap_mask, gld<uint32_t>(M.sb, M.off_chunks + (i << 2)));
-    T.n_alloc = 0; T.n_leaves = 0; T.n = 0;
+    T.n_alloc = 0; T.n = 0;
+    wave_sync();
+}
+// a read starts with every bucket empty
+__device__ __forceinline__ void tracker_clear_heads(const TrackerMem &M, int lane) {
+    const uint32_t n16 = (M.n_buckets + 3) / 4;
+    for (uint32_t i = (uint32_t)lane; i < n16; i += WAVE) gst(M.sb, M.off_heads + (i << 4), make_uint4(0u, 0u, 0u, 0u));
     wave_sync();
 }
 
@@ -179,266 +181,153 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
     else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
 }
 
-// move directory entries [a,b) one slot up / down, 256 entries (four per lane) per memory round trip: a leaf split on a
-// large set (thousands of leaves on a human-sized reference) is a few trips, not one per 64 entries
-__device__ __forceinline__ void dir_shift_up(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
-    for (uint32_t hi = b; hi > a;) {
-        const uint32_t lo = hi - a > 256 ? hi - 256 : a;
-        DirEnt k[4];
-        bool have[4];
+__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t idx = lo + (uint32_t)lane + 64u * j;
-            have[j] = idx < hi;
-            if (have[j]) k[j] = tm_dir(M, idx);
-        }
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (have[j]) tm_dir_st(M, lo + (uint32_t)lane + 64u * j + 1, k[j]);
-        wave_sync();
-        hi = lo;
-    }
+    for (int d = 32; d > 0; d >>= 1) { const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, d); v = o > v ? o : v; }
+    return v;
 }
-__device__ __forceinline__ void dir_shift_down(const TrackerMem &M, uint32_t a, uint32_t b, int lane) {
-    for (uint32_t lo = a; lo < b; lo += 256) {
-        DirEnt k[4];
-        bool have[4];
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t idx = lo + (uint32_t)lane + 64u * j;
-            have[j] = idx < b;
-            if (have[j]) k[j] = tm_dir(M, idx);
-        }
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (have[j]) tm_dir_st(M, lo + (uint32_t)lane + 64u * j - 1, k[j]);
-        wave_sync();
-    }
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
+    return v;
 }
 
-// remove entry `slot` of directory position L, whose leaf has pool index `id` and `c` clusters; keeps the directory's first keys right
-// (the structural paths -- directory shifts, erase, the insert that may split -- stay inline: out of line, with the tracker
-// passed through the stack, the gfx950 build returned wrong results on the device while the emulator build of the same sources did not)
-__device__ __forceinline__ void tracker_erase(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, int lane,
-                                              uint32_t &top_n) {
-    if (c == 1 || slot == 0) top_n = 0;      // the directory changes: its LDS sample is stale
-    const gptr_t lp = tm_leaf_ptr(M, id);
-    ClusterKey k;
-    ClusterCold cc;
-    const bool mv = (uint32_t)lane > slot && (uint32_t)lane < c;
-    if (mv) { k = lf_hot(lp, lane); cc = lf_cold(lp, lane); }
-    wave_sync();
-    if (mv) { lf_hot_st(lp, lane - 1, k); lf_cold_st(lp, lane - 1, cc); }
-    wave_sync();
-    if (c == 1) {
-        dir_shift_down(M, L + 1, T.n_leaves, lane);
-        T.n_leaves--;
-        if (lane == 0) tm_cnt_st(M, id, 0);
-    } else {
-        if (lane == 0) {
-            tm_cnt_st(M, id, c - 1);
-            if (slot == 0) tm_dir_first(M, L, lf_hot(lp, 0), id);
-        }
-    }
-    wave_sync();
+// one cluster as add_seed carries it between the gather and the commit (all fields uniform)
+struct ClusterRef { uint32_t found, node, slot, cnt, next, tl, e; uint64_t r; };
+// the lane `src` holds the cluster: its fields to every lane
+__device__ __forceinline__ ClusterRef cluster_ref(uint32_t node, uint32_t slot, const NodeHdr &h, const ClusterKey &k, int src) {
+    ClusterRef c;
+    c.found = 1; c.node = bcast32(node, src); c.slot = bcast32(slot, src); c.cnt = bcast32(h.count, src); c.next = bcast32(h.next, src);
+    c.tl = bcast32(k.total_len, src); c.e = bcast32(k.evt_en, src); c.r = bcast64(k.rstart, src);
+    return c;
+}
+__device__ __forceinline__ gptr_t node_ptr(const TrackerMem &M, uint32_t node) { return M.pool.nodes + (size_t)node * NODE_BYTES; }
+__device__ __forceinline__ void node_store(const TrackerMem &M, uint32_t node, uint32_t slot, const ClusterKey &k, const ClusterCold &c) {
+    const gptr_t p = node_ptr(M, node);
+    gst(p, NODE_HOT_OFF + (slot << 4), k);
+    gst(p, NODE_COLD_OFF + (slot << 5), c);
+}
+__device__ __forceinline__ void node_hdr_store(const TrackerMem &M, uint32_t node, uint32_t count, uint32_t next) {
+    NodeHdr h; h.count = count; h.next = next; h.pad0 = 0; h.pad1 = 0;
+    gst(node_ptr(M, node), 0u, h);
 }
 
-// insert a cluster at (L, slot); L == n_leaves means "after everything".  Returns false when no leaf can be had.
-__device__ __forceinline__ bool tracker_insert(Tracker &T, const TrackerMem &M, uint32_t L, uint32_t slot, const ClusterKey &nk,
-                                                   const ClusterCold &nc, int lane, uint32_t &top_n) {
-    top_n = 0;
-    if (T.n_leaves == 0) {
-        const uint32_t id = tracker_new_leaf(T, M, lane);
-        if (id == LEAF_NONE) return false;
-        if (lane == 0) {
-            const gptr_t lp = tm_leaf_ptr(M, id);
-            lf_hot_st(lp, 0, nk); lf_cold_st(lp, 0, nc);
-            tm_cnt_st(M, id, 1);
-            tm_dir_first(M, 0, nk, id);
-        }
-        T.n_leaves = 1;
-        wave_sync();
-        return true;
-    }
-    if (L == T.n_leaves) { L = T.n_leaves - 1; slot = tm_cnt(M, uniform32(tm_dir(M, L).leaf)); }   // append to the last leaf
-    uint32_t id = uniform32(tm_dir(M, L).leaf), c = tm_cnt(M, id);
-    if (c == LEAF) {
-        // split: the upper half moves to a fresh leaf that follows this one in the directory
-        const uint32_t nid = tracker_new_leaf(T, M, lane);
-        if (nid == LEAF_NONE) return false;
-        const gptr_t src = tm_leaf_ptr(M, id), dst = tm_leaf_ptr(M, nid);
-        if (lane >= (int)(LEAF / 2)) { lf_hot_st(dst, lane - LEAF / 2, lf_hot(src, lane)); lf_cold_st(dst, lane - LEAF / 2, lf_cold(src, lane)); }
-        wave_sync();
-        dir_shift_up(M, L + 1, T.n_leaves, lane);
-        if (lane == 0) {
-            tm_dir_first(M, L + 1, lf_hot(dst, 0), nid);
-            tm_cnt_st(M, id, LEAF / 2); tm_cnt_st(M, nid, LEAF / 2);
-        }
-        T.n_leaves++;
-        wave_sync();
-        if (slot > LEAF / 2) { L = L + 1; slot -= LEAF / 2; id = nid; }
-        c = LEAF / 2;
-    }
-    const gptr_t lp = tm_leaf_ptr(M, id);
-    ClusterKey k;
-    ClusterCold cc;
-    const bool mv = (uint32_t)lane >= slot && (uint32_t)lane < c;
-    if (mv) { k = lf_hot(lp, lane); cc = lf_cold(lp, lane); }
-    wave_sync();
-    if (mv) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
-    if (lane == 0) {
-        lf_hot_st(lp, slot, nk); lf_cold_st(lp, slot, nc);
-        tm_cnt_st(M, id, c + 1);
-        if (slot == 0) tm_dir_first(M, L, nk, id);
-    }
-    wave_sync();
-    return true;
-}
-
-// The same insert when the caller already holds the target leaf (directory position L, pool index id, count c < LEAF, lane
-// l's hot key k and cold part cc): no load at all, what sits at and behind `slot` moves up one and the new cluster goes in.
-__device__ __forceinline__ void tracker_insert_held(const TrackerMem &M, uint32_t L, uint32_t slot, uint32_t id, uint32_t c, const ClusterKey &k,
-                                                    const ClusterCold &cc, const ClusterKey &nk, const ClusterCold &nc, int lane, uint32_t &top_n) {
-    if (slot == 0) top_n = 0;
-    const gptr_t lp = tm_leaf_ptr(M, id);
-    if ((uint32_t)lane >= slot && (uint32_t)lane < c) { lf_hot_st(lp, lane + 1, k); lf_cold_st(lp, lane + 1, cc); }
-    if (lane == 0) {
-        lf_hot_st(lp, slot, nk); lf_cold_st(lp, slot, nc);
-        tm_cnt_st(M, id, c + 1);
-        if (slot == 0) tm_dir_first(M, L, nk, id);
-    }
-    wave_sync();
-}
-
-// SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform)
-#ifndef UNC_TOP_MIN
-#define UNC_TOP_MIN 64      // (tests build the emulator library with 1: the small test sets then take the sampled path too)
-#endif
-constexpr uint32_t TOP_MIN = UNC_TOP_MIN;
-// s_top / top_n: 64 evenly spaced directory entries kept in LDS (valid for a directory of top_n leaves, 0 = stale): the
-// first level of the search costs no memory round trip on the large sets of a human-sized reference.
-static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt,
-                                int lane, uint32_t &top_n) {
-    DirEnt *const s_top = reinterpret_cast<DirEnt *>(s_e);      // the staging buffer of phase E is idle while seeds are added
+// SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform; stores by lane 0)
+static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt, int lane) {
     if (T.status) return;
     const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
     const uint32_t e2 = evt;
 
-    // ---- lower_bound(new_seed): leaves whose first key sorts before the seed (64-ary search), then inside one leaf
-    uint32_t lo = 0, hi = T.n_leaves;
-    if (hi > TOP_MIN) {
-        const uint32_t step = (hi + 63) / 64;
-        const uint32_t idx = (uint32_t)lane * step;
-        if (top_n != hi) {
-            DirEnt e; e.rstart = 0; e.evt_en = 0; e.leaf = 0;     // past the end: never sorts before a seed
-            if (idx < hi) e = tm_dir(M, idx);
-            wave_sync();
-            s_top[lane] = e;
-            top_n = hi;
-            wave_sync();
-        }
-        const DirEnt te = s_top[lane];
-        const bool less = idx < hi && key_less(te, r2, e2);
-        const uint32_t c = (uint32_t)__popcll(__ballot(less));
-        lo = c ? (c - 1) * step + 1 : 0;
-        hi = c * step < hi ? c * step : hi;
-    }
-    while (hi - lo > 64) {
-        uint32_t step = (hi - lo + 63) / 64;
-        uint32_t idx = lo + (uint32_t)lane * step;
-        bool less = false;
-        if (idx < hi) less = key_less(tm_dir(M, idx), r2, e2);
-        uint32_t c = (uint32_t)__popcll(__ballot(less));
-        uint32_t nlo = c ? lo + (c - 1) * step + 1 : lo;
-        uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
-        lo = nlo;
-        hi = nhi;
-    }
-    // the last directory window stays in registers (lane l: entry lo + l): leaf ids and first keys are read off it below
-    uint32_t d;
-    DirEnt dk; dk.rstart = 0; dk.evt_en = 0; dk.leaf = 0;
-    {
-        uint32_t idx = lo + (uint32_t)lane;
-        bool less = false;
-        if (idx < hi) { dk = tm_dir(M, idx); less = key_less(dk, r2, e2); }
-        d = lo + (uint32_t)__popcll(__ballot(less));
-    }
-    // leaf d - 1 (the last one whose first key sorts before the seed): its count, hot keys and cold parts in one round trip
-    // (the cold parts are what an insert into this leaf has to move; most seeds on a large reference end up as one)
-    uint32_t lbL = 0, lbS = 0;   // position of the first key that does not sort before the seed; lbL == n_leaves: none
-    uint32_t id0 = 0, c0 = 0;    // pool index / count of the leaf at directory position d - 1
-    ClusterKey lk; lk.rstart = 0; lk.evt_en = 0; lk.total_len = 0;
-    ClusterCold lc; lc.ref_st = 0; lc.rend = 0; lc.evt_st = 0; lc.pad[0] = lc.pad[1] = lc.pad[2] = 0;
-    if (d > 0) {
-        id0 = d - 1 >= lo ? bcast32(dk.leaf, (int)(d - 1 - lo)) : uniform32(tm_dir(M, d - 1).leaf);   // window starts after it
-        const cgptr_t lp0 = tm_leaf_ptr(M, id0);
-        lk = lf_hot(lp0, lane);           // slots past the count hold stale keys: masked by c0
-        c0 = tm_cnt(M, id0);
-        const bool less = (uint32_t)lane < c0 && key_less(lk, r2, e2);
-        const uint32_t sn = (uint32_t)__popcll(__ballot(less));
-        if (sn < c0) { lbL = d - 1; lbS = sn; } else { lbL = d; lbS = 0; }
-    }
-    const bool lb_in_leaf0 = d > 0 && lbL == d - 1;
+    // ---- gather: the buckets that hold starts in [r2 - e2, r2], highest first; lane = (bucket j, slot s) of the bucket's current node
+    const uint64_t r_lo = r2 > (uint64_t)e2 ? r2 - (uint64_t)e2 : 0ull;
+    const uint32_t b_hi = (uint32_t)(r2 >> M.shift), b_lo = (uint32_t)(r_lo >> M.shift);
+    const uint32_t nb = b_hi - b_lo + 1u;                         // <= WIN_BUCKETS for max_events < 2^15 (the default is 30 000)
+    const uint32_t j = (uint32_t)lane / NODE_K, s = (uint32_t)lane % NODE_K;
+    uint32_t head0 = 0;                                           // head of the seed's own bucket
 
-    // ---- forward scan for the best-supported cluster this seed can extend (:169-191), one leaf per pass
-    uint32_t best_len = 0, mL = 0xFFFFFFFFu, mS = 0, m_id = 0, m_c = 0;
-    ClusterKey mk; mk.rstart = 0; mk.evt_en = 0; mk.total_len = 0;
-    bool exists_at_lb = false;   // an equivalent key (r2, e2) already sits at the lower bound
-    bool stop = false;
-    {
-        uint32_t curL = lbL;
-        bool first = true;
-        while (curL < T.n_leaves && !stop) {
-            uint32_t id, c, from = 0;
-            ClusterKey k;
-            if (first && lb_in_leaf0) { id = id0; c = c0; k = lk; from = lbS; }
-            else {
-                id = (curL >= lo && curL < hi) ? bcast32(dk.leaf, (int)(curL - lo)) : uniform32(tm_dir(M, curL).leaf);
-                k = lf_hot(tm_leaf_ptr(M, id), lane);
-                c = tm_cnt(M, id);
-            }
-            if (first) {   // the key at the lower bound is the first one this scan looks at
-                const uint64_t kr = bcast64(k.rstart, (int)from);
-                const uint32_t ke = bcast32(k.evt_en, (int)from);
-                exists_at_lb = kr == r2 && ke == e2;
-            }
-            const bool have = (uint32_t)lane >= from && (uint32_t)lane < c;
-            uint64_t r1 = 0;
-            uint32_t e1 = 0, tl = 0;
-            if (have) { r1 = k.rstart; e1 = k.evt_en; tl = k.total_len; }
-            const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
-            const bool in_range = have && e1 <= e2 && dr <= de && dr >= de / 12;
-            const bool far = have && dr >= (uint64_t)e2;
-            uint32_t tot;
-            uint32_t pm = excl_max32(in_range ? tl : 0u, &tot);
-            if (pm < best_len) pm = best_len;
-            const bool taken = in_range && tl > pm;
-            const bool brk = have && !taken && far;
-            uint64_t bm = __ballot(brk), tm = __ballot(taken);
-            if (bm) {
-                int firstb = __ffsll((unsigned long long)bm) - 1;
-                tm &= (1ull << firstb) - 1ull;
-                stop = true;
-            }
-            const int last = tm ? 63 - __clzll((long long)tm) : 0;
-            const uint32_t tl_last = bcast32(tl, last);
-            if (tm) {
-                mL = curL; mS = (uint32_t)last; best_len = tl_last; m_id = id; m_c = c;
-                mk.rstart = bcast64(k.rstart, last); mk.evt_en = bcast32(k.evt_en, last); mk.total_len = tl_last;
-            }
-            curL++;
-            first = false;
+    ClusterRef best; best.found = 0; best.node = best.slot = best.cnt = best.next = best.tl = best.e = 0; best.r = 0;   // best-supported candidate among the near ones
+    ClusterRef f0 = best;                                         // the cluster exactly e2 rows back with evt_en 0, if there is one
+    bool f_other = false;                                         // ... and whether another cluster sits exactly e2 rows back (it ends the scan first)
+    bool exists = false;                                          // an equivalent key (r2, e2) is in the set
+    uint64_t lb_r = 0; uint32_t lb_e = 0; bool lb_have = false;   // key at lower_bound(seed): the first in set order not before the seed
+    uint32_t ins_node = 0, ins_cnt = 0, ins_next = 0;             // a node of the seed's own bucket with room (id + 1)
+    for (uint32_t jb = 0; jb < nb; jb += WIN_BUCKETS) {
+    const bool active = j < WIN_BUCKETS && jb + j < nb;
+    uint32_t node1 = active ? gld<uint32_t>(M.sb, M.off_heads + ((b_hi - jb - j) << 2)) : 0u;      // node id + 1
+    if (jb == 0) head0 = bcast32(node1, 0);
+    while (__any(node1 != 0u)) {
+        NodeHdr h; h.count = 0; h.next = 0; h.pad0 = h.pad1 = 0;
+        ClusterKey k; k.rstart = 0; k.evt_en = 0; k.total_len = 0;
+        if (node1) {
+            const cgptr_t p = node_ptr(M, node1 - 1u);
+            h = gld<NodeHdr>(p, 0u);
+            k = gld<ClusterKey>(p, NODE_HOT_OFF + (s << 4));
         }
+        const bool valid = node1 != 0u && s < h.count;
+        const uint64_t r1 = k.rstart;
+        const uint32_t e1 = k.evt_en, tl = k.total_len;
+        // not before the seed in set order, and not further back than e2 rows
+        const bool in_win = valid && r1 <= r2 && !(r1 == r2 && e1 > e2) && (r2 - r1) <= (uint64_t)e2;
+        const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
+        const bool in_range = in_win && e1 <= e2 && dr <= de && dr >= de / 12;       // :178-181
+        const bool farE = in_win && dr == (uint64_t)e2;                              // r2 - r1 >= e2: a non-candidate here ends the scan
+        if (__any(valid && r1 == r2 && e1 == e2)) exists = true;
+        // a node of the seed's own bucket with a free slot
+        if (!ins_node) {
+            const uint64_t m = __ballot(jb == 0 && j == 0 && s == 0 && node1 != 0u && h.count < NODE_K);
+            if (m) { ins_node = bcast32(node1, 0); ins_cnt = bcast32(h.count, 0); ins_next = bcast32(h.next, 0); }
+        }
+        // lower bound: the largest (r1, e1) in the window
+        {
+            const uint64_t mr = wave_max64(in_win ? r1 + 1ull : 0ull);               // (+1: a start of 0 still counts)
+            if (mr) {
+                const uint32_t me = wave_max32(in_win && r1 + 1ull == mr ? e1 + 1u : 0u);
+                if (!lb_have || mr - 1ull > lb_r || (mr - 1ull == lb_r && me - 1u > lb_e)) { lb_r = mr - 1ull; lb_e = me - 1u; }
+                lb_have = true;
+            }
+        }
+        // near candidates: the longest wins, among equally long ones the first in set order = the largest (r1, e1)
+        {
+            const bool cand = in_range && !farE;
+            const uint64_t cm = __ballot(cand);
+            if (cm) {
+                const uint32_t m_tl = wave_max32(cand ? tl + 1u : 0u) - 1u;
+                const bool s1 = cand && tl == m_tl;
+                const uint64_t m_r = wave_max64(s1 ? r1 + 1ull : 0ull) - 1ull;
+                const bool s2 = s1 && r1 == m_r;
+                const uint32_t m_e = wave_max32(s2 ? e1 + 1u : 0u) - 1u;
+                const uint64_t wm = __ballot(s2 && e1 == m_e);
+                const int src = __ffsll((unsigned long long)wm) - 1;
+                const bool better = !best.found || m_tl > best.tl || (m_tl == best.tl && (m_r > best.r || (m_r == best.r && m_e > best.e)));
+                if (better) best = cluster_ref(node1 - 1u, s, h, k, src);
+            }
+        }
+        // clusters exactly e2 rows back
+        {
+            if (__any(farE && e1 > 0u)) f_other = true;
+            const uint64_t fm = __ballot(farE && e1 == 0u);
+            if (fm) f0 = cluster_ref(node1 - 1u, s, h, k, __ffsll((unsigned long long)fm) - 1);
+        }
+        node1 = node1 ? h.next : 0u;          // on along the chains
     }
+    }
+    // the scan reaches the clusters e2 rows back after all nearer ones, in order of descending evt_en: any of them with evt_en > 0
+    // is out of range and ends it; the one with evt_en 0 is in range (r2 - r1 = e2 - e1) and is taken when it is longer
+    ClusterRef mt = best;
+    if (f0.found && !f_other && (!best.found || f0.tl > best.tl)) mt = f0;
 
-    if (mL != 0xFFFFFFFFu) {
-        const gptr_t mlp = tm_leaf_ptr(M, m_id);
-        const ClusterCold mp = lf_cold(mlp, mS);
+    // where a new key goes: a free slot of the seed's own bucket, or a fresh node at its head
+    auto insert_key = [&](const ClusterKey &nk, const ClusterCold &nc) -> bool {
+        if (ins_node) {
+            if (lane == 0) { node_store(M, ins_node - 1u, ins_cnt, nk, nc); node_hdr_store(M, ins_node - 1u, ins_cnt + 1u, ins_next); }
+        } else {
+            const uint32_t id = tracker_new_node(T, M, lane);
+            if (id == NODE_NONE) return false;
+            if (lane == 0) {
+                node_store(M, id, 0u, nk, nc); node_hdr_store(M, id, 1u, head0);
+                gst(M.sb, M.off_heads + (b_hi << 2), id + 1u);
+            }
+        }
+        return true;
+    };
+    // take the cluster c out of its node: the node's last cluster moves into the hole
+    auto erase_ref = [&](const ClusterRef &c) {
+        const uint32_t last = c.cnt - 1u;
+        if (c.slot != last) {
+            const cgptr_t p = node_ptr(M, c.node);
+            const ClusterKey lk = gld<ClusterKey>(p, NODE_HOT_OFF + (last << 4));
+            const ClusterCold lc = gld<ClusterCold>(p, NODE_COLD_OFF + (last << 5));
+            wave_sync();
+            if (lane == 0) node_store(M, c.node, c.slot, lk, lc);
+        }
+        if (lane == 0) node_hdr_store(M, c.node, last, c.next);
+    };
+
+    if (mt.found) {
+        const ClusterCold mp = gld<ClusterCold>(node_ptr(M, mt.node), NODE_COLD_OFF + (mt.slot << 5));
         ClusterVal a;
-        a.ref_st = mp.ref_st; a.rstart = mk.rstart; a.rend = mp.rend;
-        a.evt_st = mp.evt_st; a.evt_en = mk.evt_en; a.total_len = mk.total_len;
+        a.ref_st = mp.ref_st; a.rstart = mt.r; a.rend = mp.rend;
+        a.evt_st = mp.evt_st; a.evt_en = mt.e; a.total_len = mt.tl;
         const uint32_t prev_len = a.total_len;
         // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
         uint8_t growth = 0;
@@ -457,24 +346,24 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             lens_replace(T, prev_len, a.total_len);
             if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
         }
-        // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2)
+        // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2).  The insert collides -- and the cluster is
+        // dropped -- when that key is already in the set and is not the matched cluster itself (which then sits at the lower bound)
         ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = a.total_len;
         ClusterCold nc; nc.ref_st = a.ref_st; nc.rend = a.rend; nc.evt_st = a.evt_st; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
+        const bool is_lb = lb_have && mt.r == lb_r && mt.e == lb_e;
         wave_sync();
-        if (lbL == mL && lbS == mS) {
-            if (lane == 0) {
-                lf_hot_st(mlp, mS, nk); lf_cold_st(mlp, mS, nc);
-                if (mS == 0) tm_dir_first(M, mL, nk, m_id);
-            }
-            if (mS == 0) top_n = 0;
-            wave_sync();
-        } else if (exists_at_lb) {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane, top_n);     // the re-insert collides: the cluster is dropped
+        if (!is_lb && exists) {
+            erase_ref(mt);
             T.n--;
+        } else if ((uint32_t)(mt.r >> M.shift) == b_hi) {
+            if (lane == 0) node_store(M, mt.node, mt.slot, nk, nc);      // same bucket: the cluster stays where it is
         } else {
-            tracker_erase(T, M, mL, mS, m_id, m_c, lane, top_n);     // lb sorts before the match: its position is unaffected
-            if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane, top_n)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            erase_ref(mt);                                               // its start moved into the seed's bucket
+            wave_sync();
+            // (the node found for inserting is not the one just shrunk: that one belongs to another bucket)
+            if (!insert_key(nk, nc)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
         }
+        wave_sync();
     } else {
         // new cluster (:218-228): the bookkeeping happens even when the set insert collides
         lens_insert(T, ref_len);
@@ -483,20 +372,13 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             T.mm.ref_st = r2; T.mm.rstart = r2; T.mm.rend = ref_en;
             T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
         }
-        if (!exists_at_lb) {
+        if (!exists) {
             ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
             ClusterCold nc; nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
             wave_sync();
-            if (d > 0 && c0 < LEAF && (lb_in_leaf0 || lbL == T.n_leaves)) {
-                // into the leaf loaded above (the lower bound lies in it, or the seed sorts after everything and is appended
-                // to the last leaf = directory position d - 1): nothing to reload
-                // (the cold parts of the leaf are fetched only now, when they have to move: the kernel is bound by the bytes it
-                // moves, and most seeds extend a cluster and never get here)
-                lc = lf_cold(tm_leaf_ptr(M, id0), lane);
-                wave_sync();        // every lane has its cold part before any lane stores into its neighbour's slot
-                tracker_insert_held(M, d - 1, lb_in_leaf0 ? lbS : c0, id0, c0, lk, lc, nk, nc, lane, top_n);
-            } else if (!tracker_insert(T, M, lbL, lbS, nk, nc, lane, top_n)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (!insert_key(nk, nc)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             T.n++;
+            wave_sync();
         }
     }
 }
@@ -1107,8 +989,10 @@ template <bool PROF> struct PhaseClock {
 
 __device__ __forceinline__ TrackerMem tracker_mem(kargs_t A, gptr_t sb) {
     TrackerMem M;
-    M.sb = sb; M.off_dir = A->sc.off_cl_dir; M.off_chunks = A->sc.off_cl_chunks; M.max_leaves = A->sc.max_clusters / 16;
-    M.pool.leaves = (gptr_t)A->pool.leaves; M.pool.cnt = (UNC_AS_GLOBAL uint32_t *)A->pool.cnt;
+    M.sb = sb; M.off_heads = A->sc.off_cl_dir; M.off_chunks = A->sc.off_cl_chunks;
+    M.max_nodes = A->sc.max_clusters / 4 ? A->sc.max_clusters / 4 : 1u;
+    M.n_buckets = A->ix.n_buckets; M.shift = A->ix.bucket_shift;
+    M.pool.nodes = (gptr_t)A->pool.leaves;
     M.pool.q = A->pool.q; M.pool.cells = A->pool.cells; M.pool.cap_mask = A->pool.cap_mask;
     return M;
 }
@@ -1966,13 +1850,12 @@ static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane
     {
         const Tracker v = s_T;      // uniform values: back into scalar registers
         T.n = uniform32(v.n); T.n_lens = uniform32(v.n_lens); T.max1 = uniform32(v.max1); T.max2 = uniform32(v.max2);
-        T.status = uniform32(v.status); T.n_leaves = uniform32(v.n_leaves); T.n_alloc = uniform32(v.n_alloc);
+        T.status = uniform32(v.status); T.n_alloc = uniform32(v.n_alloc);
         T.len_sum = __uint_as_float(uniform32(__float_as_uint(v.len_sum)));
         T.mm.ref_st = uniform64(v.mm.ref_st); T.mm.rstart = uniform64(v.mm.rstart); T.mm.rend = uniform64(v.mm.rend);
         T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
     }
     const TrackerMem TM = tracker_mem(A, sb);
-    uint32_t top_n = 0;
     for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
         const uint32_t si = sb0 + (uint32_t)lane;
         SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
@@ -2006,7 +1889,7 @@ static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane
             const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
             for (uint32_t j = 0; j < nt; ++j) {
                 const uint64_t v = uniform64(bcast64(mine, (int)j));     // scalar, as every argument of add_seed must be
-                add_seed(T, TM, p_min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane, top_n);
+                add_seed(T, TM, p_min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane);
             }
         }
         clk.end(6, lane);
@@ -2090,7 +1973,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             n_surv_par = uniform32(st->n_surv);
             T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
-            T.status = st->status; T.len_sum = st->len_sum; T.n_leaves = st->n_leaves; T.n_alloc = st->n_alloc;
+            T.status = st->status; T.len_sum = st->len_sum; T.n_alloc = st->n_alloc;
             T.mm.ref_st = st->max_map.ref_st; T.mm.rstart = st->max_map.rstart; T.mm.rend = st->max_map.rend;
             T.mm.evt_st = st->max_map.evt_st; T.mm.evt_en = st->max_map.evt_en; T.mm.total_len = st->max_map.total_len;
             if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
@@ -2106,8 +1989,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 old.n_alloc = uniform32(st->n_alloc);
                 tracker_release(old, tracker_mem(A, sb), lane);
             }
+            tracker_clear_heads(tracker_mem(A, sb), lane);
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
+            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
             if (lane < NKMER / 32) s_flags[lane] = 0;
         } else {
@@ -2118,8 +2002,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 if (r >= A->rd.n_reads) break;
             }
             if (A->read_list) r = uniform32(A->read_list[r]);
+            tracker_clear_heads(tracker_mem(A, sb), lane);     // every bucket of the seed-cluster grid empty
             event_i = 0; n_parents = 0; cur = 0;
-            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_leaves = 0; T.n_alloc = 0;
+            T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
             if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
         }
@@ -2204,7 +2089,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
                 st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
-                st->n_leaves = T.n_leaves; st->n_alloc = T.n_alloc;
+                st->n_leaves = 0; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
                 if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; } }
             }

@@ -130,6 +130,8 @@ struct DevIndex {
     uint64_t primary, seq_len;
     uint64_t L2[5];
     uint32_t key_len_bits;      // > 0: (start, length, child index) pack into one 64-bit sort key with this many length bits
+    uint32_t bucket_shift;      // seed clusters are bucketed by ref_en_.start >> bucket_shift (k_map.hip, add_seed) ...
+    uint32_t n_buckets;         // ... into this many buckets per read
     uint32_t pad_;
     float thresholds[64];
 };
@@ -147,8 +149,8 @@ struct DevScratch {
     uint32_t off_keys;     // SortKey [2][keys_cap]   (unsorted | sorted)
     uint32_t off_seedp;    // SeedPath[max_seed_paths]
     uint32_t off_tasks;    // u64     [WAVE * MAX_REP_COPY_LIMIT]
-    uint32_t off_cl_dir;   // DirEnt  [max_clusters / 16]: sorted directory of the read's leaves (first key + pool index)
-    uint32_t off_cl_chunks;  // u32   [max_clusters / 16 / 64 + 1]: the pool chunks this read holds
+    uint32_t off_cl_dir;   // u32     [n_buckets]: heads of the read's seed-cluster buckets (node index + 1)
+    uint32_t off_cl_chunks;  // u32   [max_clusters / 4 / 512 + 1]: the pool chunks this read holds
     uint32_t off_state;    // SlotState
     // narrow sort keys (DevIndex::key_len_bits > 0): the children's 64-bit keys leave phase E as sorted streams
     uint32_t off_streams;  // u64     [6][max_paths]: stays, moves by base 0..3 (children of the sorted survivors), the rest

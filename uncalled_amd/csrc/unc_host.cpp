@@ -13,6 +13,7 @@
 #include <string>
 #include <chrono>
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "r94_model_table.h"
@@ -323,6 +324,15 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         ix->dev.pad_ = 0;
     }
     {
+        // the grid the seed clusters of a read are bucketed in (k_map.hip, add_seed): buckets of 2^shift rows, at most 2^16 per read,
+        // at least 2^12 rows wide, so that a window of 32768 rows (max_events <= 65535 is checked per mapper) spans few buckets
+        uint32_t bits = 1;
+        while ((n >> bits) != 0) ++bits;
+        uint32_t shift = bits > 28 ? bits - 16 : 12;
+        ix->dev.bucket_shift = shift;
+        ix->dev.n_buckets = (uint32_t)(n >> shift) + 2u;
+    }
+    {
         uint16_t valid[WAVE];
         for (int l = 0; l < WAVE; ++l) {
             valid[l] = 0;
@@ -473,7 +483,7 @@ static void free_scratch(DevScratch &sc) {
 
 // Regions of one slot (DevScratch), each 256-byte aligned; everything below 4 GB so that kernels address a slot as
 // uniform base + 32-bit offset.
-static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths) {
+static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, uint32_t n_buckets) {
     memset(&sc, 0, sizeof sc);
     sc.max_paths = P.max_paths;
     uint32_t kc = 64;
@@ -483,15 +493,15 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     sc.max_clusters = max_clusters;
     uint64_t off = 0;
     auto region = [&off](uint64_t bytes) { const uint64_t o = off; off += (bytes + 255) & ~255ull; return o; };
-    const uint64_t leaves = max_clusters / 16;     // directory entries: leaves are at least half full after a split
+    const uint64_t max_nodes = max_clusters / 4 ? max_clusters / 4 : 1;     // nodes of seed clusters a read may take from the pool
     const uint64_t o_paths = region(2ull * sc.max_paths * sizeof(PathRec));
     const uint64_t o_levels = region(LEVEL_RING * 4);
     const uint64_t o_order = region(2ull * sc.max_paths * 4);
     const uint64_t o_keys = region(2ull * sc.keys_cap * sizeof(SortKey));
     const uint64_t o_seedp = region((uint64_t)max_seed_paths * sizeof(SeedPath));
     const uint64_t o_tasks = region((uint64_t)WAVE * MAX_REP_COPY_LIMIT * 8);
-    const uint64_t o_cld = region(leaves * sizeof(DirEnt));
-    const uint64_t o_clc = region((leaves / CHUNK_LEAVES + 1) * 4);
+    const uint64_t o_cld = region(((uint64_t)n_buckets + 4) * 4);
+    const uint64_t o_clc = region((max_nodes / 512 + 1) * 4);
     const uint64_t o_state = region(sizeof(SlotState));
     const uint64_t o_streams = region(6ull * sc.max_paths * 8);
     const uint64_t o_info = region((uint64_t)sc.max_paths * 8);
@@ -505,14 +515,14 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     return UNC_OK;
 }
 
-static uint64_t scratch_slot_bytes(const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths) {
+static uint64_t scratch_slot_bytes(const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, uint32_t n_buckets) {
     DevScratch t;
-    return scratch_layout(t, P, max_clusters, max_seed_paths) == UNC_OK ? t.slot_bytes : ~0ull;
+    return scratch_layout(t, P, max_clusters, max_seed_paths, n_buckets) == UNC_OK ? t.slot_bytes : ~0ull;
 }
 
 static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, uint32_t max_clusters, uint32_t max_seed_paths,
-                         size_t *bytes_out) {
-    int rc = scratch_layout(sc, P, max_clusters, max_seed_paths);
+                         size_t *bytes_out, uint32_t n_buckets) {
+    int rc = scratch_layout(sc, P, max_clusters, max_seed_paths, n_buckets);
     if (rc) return rc;
     const size_t bytes = (size_t)n_slots * sc.slot_bytes;
     HIPCHK(hipMalloc((void **)&sc.base, bytes));
@@ -590,7 +600,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
         const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
-        const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0);
+        const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0, ix->dev.n_buckets);
         size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
         if (n_slots < n_waves) n_slots = n_waves;
@@ -607,7 +617,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     // per read: the directory of its seed-cluster leaves (16 bytes per leaf, 2^20 clusters by default); the leaves themselves
     // come from the pool below
     const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
-    int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes);
+    int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes, ix->dev.n_buckets);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     {
@@ -810,10 +820,10 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                     m->big_cap = 0; m->big_slots = 0;
                     size_t free_b = 0, total_b = 0;
                     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                    const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths);
+                    const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths, m->ix->dev.n_buckets);
                     const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
                     const size_t n = std::min(want, fit);
-                    int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr);
+                    int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr, m->ix->dev.n_buckets);
                     if (rc2) { free_scratch(m->big); return rc2; }
                     m->big_cap = cap; m->big_slots = n; m->big_at_limit = n == fit;
                 }
@@ -1039,25 +1049,49 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     HIPCHK(hipSetDevice(m->ix->device));
     SlotState s;
     HIPCHK(hipMemcpy(&s, slot_state(m->sc, 0), sizeof s, hipMemcpyDeviceToHost));
-    // flatten the two-level set (directory order, then slot order inside each leaf: hot keys, then cold parts)
-    std::vector<DirEnt> dir(s.n_leaves ? s.n_leaves : 1);
-    HIPCHK(hipMemcpy(dir.data(), m->sc.base + m->sc.off_cl_dir, (size_t)s.n_leaves * sizeof(DirEnt), hipMemcpyDeviceToHost));
-    uint32_t n = 0;
-    std::vector<char> leaf(LEAF_BYTES);
-    for (uint32_t L = 0; L < s.n_leaves; ++L) {
-        uint32_t c = 0;
-        HIPCHK(hipMemcpy(&c, m->pool.cnt + dir[L].leaf, 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(leaf.data(), m->pool.leaves + (size_t)dir[L].leaf * LEAF_BYTES, LEAF_BYTES, hipMemcpyDeviceToHost));
-        if (c == 0 || c > LEAF_KEYS) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: leaf %u holds %u clusters", L, c);
-        const ClusterKey *hot = reinterpret_cast<const ClusterKey *>(leaf.data());
-        const ClusterCold *cold = reinterpret_cast<const ClusterCold *>(leaf.data() + LEAF_COLD_OFF);
-        if (hot[0].rstart != dir[L].rstart || hot[0].evt_en != dir[L].evt_en) return fail(UNC_ERR_HIP, "seed-cluster directory entry %u is stale", L);
-        for (uint32_t e = 0; e < c; ++e, ++n) {
-            if (n >= cap) continue;
-            out[n].ref_st = cold[e].ref_st; out[n].ref_en_start = hot[e].rstart; out[n].ref_en_end = cold[e].rend;
-            out[n].evt_st = cold[e].evt_st; out[n].evt_en = hot[e].evt_en; out[n].total_len = hot[e].total_len; out[n].pad = 0;
+    // flatten the bucket grid (k_map.hip, add_seed): heads -> chains of nodes (hot keys, then cold parts), then set order
+    // (ref_en_.start descending, evt_en_ descending: seed_tracker.cpp:97-102)
+    const uint32_t n_buckets = m->ix->dev.n_buckets;
+    constexpr uint32_t NODE_K = 7, NODE_BYTES = 384, CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;
+    std::vector<uint32_t> heads(n_buckets);
+    HIPCHK(hipMemcpy(heads.data(), m->sc.base + m->sc.off_cl_dir, (size_t)n_buckets * 4, hipMemcpyDeviceToHost));
+    const uint32_t n_chunks = (s.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
+    std::vector<uint32_t> chunk_ids(n_chunks ? n_chunks : 1);
+    HIPCHK(hipMemcpy(chunk_ids.data(), m->sc.base + m->sc.off_cl_chunks, (size_t)n_chunks * 4, hipMemcpyDeviceToHost));
+    std::map<uint32_t, std::vector<char>> chunks;            // pool chunk -> its bytes
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        std::vector<char> &buf = chunks[chunk_ids[c]];
+        buf.resize((size_t)CHUNK_NODES * NODE_BYTES);
+        HIPCHK(hipMemcpy(buf.data(), m->pool.leaves + (size_t)chunk_ids[c] * CHUNK_NODES * NODE_BYTES, buf.size(), hipMemcpyDeviceToHost));
+    }
+    std::vector<unc_cluster_t> all;
+    for (uint32_t b = 0; b < n_buckets; ++b) {
+        uint32_t node1 = heads[b], guard = 0;
+        while (node1) {
+            const uint32_t node = node1 - 1;
+            auto it = chunks.find(node / CHUNK_NODES);
+            if (it == chunks.end() || ++guard > s.n_alloc + 1) return fail(UNC_ERR_HIP, "seed-cluster grid is inconsistent: bucket %u points outside the read's chunks", b);
+            const char *np = it->second.data() + (size_t)(node % CHUNK_NODES) * NODE_BYTES;
+            uint32_t hdr[4];
+            memcpy(hdr, np, 16);
+            if (hdr[0] > NODE_K) return fail(UNC_ERR_HIP, "seed-cluster grid is inconsistent: a node of bucket %u holds %u clusters", b, hdr[0]);
+            const ClusterKey *hot = reinterpret_cast<const ClusterKey *>(np + 16);
+            const ClusterCold *cold = reinterpret_cast<const ClusterCold *>(np + 16 + NODE_K * 16);
+            for (uint32_t e = 0; e < hdr[0]; ++e) {
+                if ((hot[e].rstart >> m->ix->dev.bucket_shift) != b) return fail(UNC_ERR_HIP, "seed-cluster grid is inconsistent: a cluster sits in the wrong bucket");
+                unc_cluster_t c;
+                c.ref_st = cold[e].ref_st; c.ref_en_start = hot[e].rstart; c.ref_en_end = cold[e].rend;
+                c.evt_st = cold[e].evt_st; c.evt_en = hot[e].evt_en; c.total_len = hot[e].total_len; c.pad = 0;
+                all.push_back(c);
+            }
+            node1 = hdr[1];
         }
     }
+    std::sort(all.begin(), all.end(), [](const unc_cluster_t &a, const unc_cluster_t &b) {
+        return a.ref_en_start > b.ref_en_start || (a.ref_en_start == b.ref_en_start && a.evt_en > b.evt_en);
+    });
+    uint32_t n = (uint32_t)all.size();
+    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = all[i];
     if (n != s.n_clusters) return fail(UNC_ERR_HIP, "seed-cluster set is inconsistent: %u keys, %u clusters", n, s.n_clusters);
     *n_out = s.n_clusters;
     if (max_map) {
@@ -1140,7 +1174,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     const size_t S = n_channels;
     size_t bytes = 0;
     {
-        int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes);
+        int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes, ix->dev.n_buckets);
         if (rc) return rc;
         HIPCHK(hipMemset(rt->sc.base, 0, bytes));
         // 16 chunks (about 50 000 clusters) per channel on average; a read that finds the pool dry fails with its status set
