@@ -291,6 +291,8 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     have_gpu = dev_name != "cpu"
     prefix, codes, lens = ensure_index(cache, rank, barrier, workload, dev_name, lib)
     ix = capi.Index(prefix, device=local_rank if have_gpu else 0, lib=lib)
+    if have_gpu:
+        torch.cuda.empty_cache()                 # blocks torch still caches from the index build: the mapper sizes its pool by what is free
     kw = dict(pool_chunks=a.pool_chunks)
     if not have_gpu:
         kw.update(n_slots=4, n_waves=2)          # lanesim plumbing test

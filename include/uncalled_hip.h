@@ -61,6 +61,7 @@ typedef struct { float range, offset, digitisation; } unc_calib_t;
 #define UNC_READ_OK 0u
 #define UNC_READ_CLUSTER_OVERFLOW 1u   /* seed-cluster scratch exhausted: result for this read is invalid */
 #define UNC_READ_SEED_OVERFLOW 2u      /* per-event seed list exhausted: result for this read is invalid */
+#define UNC_READ_POOL_DRY 16u          /* with CLUSTER_OVERFLOW: the shared pool of cluster nodes was empty (the read's own allowance was not used up) */
 #define UNC_READ_SORT_FAULT 8u        /* internal: the runs of child keys handed to the merge were not ascending (never expected; result invalid) */
 #define UNC_READ_NORM_FULL 4u          /* chunked path: >= 6000 unread events (the reference's #SKIP branch, mapper.cpp:336-351) */
 

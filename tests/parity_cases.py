@@ -256,9 +256,9 @@ def case_sliced_scheduler(lib, oracle_lib, example, goldens, max_paths=10000, sl
 
 
 def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2, n_waves=2, n_reads=12):
-    """The leaves of all seed-cluster sets come from one pool.  With fewer chunks than reads in flight some reads find it
-    dry; with a tiny leaf directory some outgrow that: both are mapped again after the batch (with the pool to themselves,
-    then with a longer directory) and every read still answers as the oracle does.  A roomy pool needs no second pass."""
+    """The nodes of all seed-cluster sets come from one pool.  With fewer chunks than reads in flight some reads find it
+    dry; with a tiny allowance of nodes some outgrow that: both are mapped again after the batch (with fewer reads sharing
+    the pool; with a larger allowance) and every read still answers as the oracle does.  A roomy pool needs no second pass."""
     dev_index = _index(lib, example)
     off_all = goldens["sim_offsets"]
     raw = goldens["sim_signal"][:int(off_all[n_reads])]
@@ -277,8 +277,13 @@ def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2,
     m3 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=64)
     hits3 = m3.map_batch(raw, off, cal)
     assert m3.last_remap()[0] == 0
+    # both causes in one batch: reads that find the pool dry run again with fewer fellows, reads past their own allowance
+    # (max_clusters / 4 nodes) with a larger one -- and a read may meet one cause after the other
+    m4 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60, pool_chunks=pool_chunks, max_clusters=16)
+    hits4 = m4.map_batch(raw, off, cal)
+    assert m4.last_remap()[0] > 0
     for name in capi.RESULT_FIELDS:
-        assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]), name
+        assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]) and np.array_equal(hits[name], hits4[name]), name
 
 
 def case_big_forests(lib, oracle_lib, example, goldens, tmp_path, monkeypatch, wide_too=True):

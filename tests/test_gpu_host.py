@@ -160,8 +160,10 @@ def test_realtime_pool_ordered_replay_gpu(unc, oracle_lib, example, goldens):
 
 
 def test_realtime_add_chunk_and_decision_loop_gpu(unc, oracle_lib, tmp_path, goldens):
-    from tests.test_realtime_host import case_add_chunk_resets_the_previous_read, case_client_sim_feeds_the_decision_loop
+    from tests.test_realtime_host import (case_add_chunk_resets_the_previous_read, case_client_sim_feeds_the_decision_loop,
+                                          case_oversized_chunk_is_refused)
     case_add_chunk_resets_the_previous_read(unc, oracle_lib, goldens)
+    case_oversized_chunk_is_refused(unc)
     case_client_sim_feeds_the_decision_loop(unc, tmp_path, goldens)
 
 

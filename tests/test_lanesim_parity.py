@@ -65,23 +65,6 @@ def test_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatc
 
 
 @pytest.fixture(scope="module")
-def sim_lib_top():
-    """The emulator library built with UNC_TOP_MIN=1: add_seed's LDS-sampled directory level, which production sets only
-    reach beyond 64 leaves (thousands of clusters), is then taken by the small test sets as well."""
-    import subprocess
-    from pathlib import Path
-    from uncalled_amd import capi
-    root = Path(__file__).resolve().parents[1]
-    subprocess.run(["make", "-s", "-C", str(root / "tests" / "lanesim"), "OUT=_build_top", "EXTRA=-DUNC_TOP_MIN=1"], check=True)
-    return capi.load(root / "tests" / "lanesim" / "_build_top" / "libuncalled_sim.so")
-
-
-def test_sampled_directory_search(sim_lib_top, oracle_lib, example, goldens):
-    pc.case_trace_matches_oracle_every_event(sim_lib_top, oracle_lib, example, goldens)
-    pc.case_cluster_pool_pressure(sim_lib_top, oracle_lib, example, goldens, 1, 1, n_reads=6)
-
-
-@pytest.fixture(scope="module")
 def sim_lib_norepair():
     """The emulator library built with UNC_MERGE_REPAIR=0: the runs of child keys reach the merge with their out-of-order
     pairs still in them, so the merge's own check has to notice and send the event through the bitonic network."""

@@ -113,6 +113,21 @@ def case_add_chunk_resets_the_previous_read(unc, po, goldens):
     assert mapped and mapped[0].is_mapped() and pool.all_finished()
 
 
+def case_oversized_chunk_is_refused(unc):
+    """A chunk longer than chunk_time * sample_rate (a client on another chunk time) is refused by add_chunk / try_add_chunk
+    and leaves the pool running: the reference's ReadBuffer would append it, the device side stages one chunk_len per
+    channel, and one bad chunk must not end the run."""
+    pool = unc.RealtimePool(_conf(unc, 2))
+    noise = (np.random.default_rng(4).normal(90.0, 12.0, 12000)).astype(np.float32).tolist()
+    assert not pool.add_chunk(unc.Chunk("big", 1, 1, 0, noise, 0, 4001))
+    assert not pool.try_add_chunk(unc.Chunk("big", 1, 1, 0, noise, 0, 8000))
+    assert pool.update() == [] and pool.active_count() == 0 and pool.all_finished()
+    assert pool.add_chunk(unc.Chunk("ok", 1, 2, 0, noise, 0, 4000))           # the channel still takes a regular chunk
+    assert pool.update() == [] and pool.active_count() == 1
+    assert not pool.add_chunk(unc.Chunk("ok", 1, 2, 4000, noise, 4000, 5000))  # ... and refuses an oversized one mid-read
+    assert pool.active_count() == 1
+
+
 def case_client_sim_feeds_the_decision_loop(unc, tmp_path, goldens):
     """ClientSim-shaped source over fast5 files + the enrich/deplete loop of scripts/uncalled:216-256 (uncalled_amd sim)."""
     off = goldens["sim_offsets"]
@@ -210,6 +225,11 @@ def test_realtime_pool_ordered_replay_matches_oracle(sim_host, oracle_lib, examp
 @pytest.mark.lanesim
 def test_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens):
     case_add_chunk_resets_the_previous_read(sim_host, oracle_lib, goldens)
+
+
+@pytest.mark.lanesim
+def test_oversized_chunk_is_refused(sim_host):
+    case_oversized_chunk_is_refused(sim_host)
 
 
 @pytest.mark.lanesim

@@ -86,9 +86,23 @@ static void remember_old(RealtimePool::Chan &c) {
     c.give_up = true; c.old_id = c.id; c.old_number = c.number; c.old_start = c.start; c.old_raw_len = c.raw_len;
 }
 
+// A chunk longer than chunk_time * sample_rate does not fit the per-channel staging of the device side: it is refused here
+// (add_chunk / try_add_chunk return false, as for a channel that is still busy) instead of failing the whole round later.
+bool RealtimePool::oversized(const Chunk &chunk) {
+    const uint64_t cap = (uint64_t)(prms_.chunk_time * prms_.sample_rate);
+    if (chunk.size() <= cap) return false;
+    if (!warned_oversized_) {
+        std::cerr << "Warning: chunk of " << chunk.size() << " samples on channel " << chunk.get_channel() << " is longer than chunk_time * sample_rate = "
+                  << cap << " and was refused (further ones are refused silently)\n";
+        warned_oversized_ = true;
+    }
+    return true;
+}
+
 // realtime_pool.cpp:74-110
 bool RealtimePool::add_chunk(Chunk &chunk) {
     if (stopped_) return false;
+    if (oversized(chunk)) return false;
     const uint16_t ch = chunk.get_channel_idx();
     if (ch >= chans_.size()) return false;
     Chan &c = chans_[ch];
@@ -114,6 +128,7 @@ bool RealtimePool::try_add_chunk(Chunk &chunk) {
     const uint16_t ch = chunk.get_channel_idx();
     if (ch >= chans_.size()) return false;
     Chan &c = chans_[ch];
+    if (oversized(chunk)) return false;
     if (chunk.empty()) {
         // all chunks of the read were handed out: give up once the last one is mapped and the read is still undecided
         if (c.active && !c.has_pending) {
@@ -181,7 +196,22 @@ std::vector<MapResult> RealtimePool::update() {
     if (signal.empty()) signal.push_back(0.f);
     std::vector<unc_rt_result_t> res(chunks.size());
     const int rc = unc_rt_process_chunks_f32(rt_, (uint32_t)chunks.size(), chunks.data(), signal.data(), 0, nullptr, res.data());
-    if (rc != UNC_OK && rc != UNC_ERR_OVERFLOW) { std::cerr << "Error: " << unc_last_error() << "\n"; abort(); }
+    if (rc != UNC_OK && rc != UNC_ERR_OVERFLOW) {
+        // the round was refused as a whole (an argument the device side does not accept): the reads it carried are reported
+        // unmapped and ended, the pool stays usable
+        std::cerr << "Error: " << unc_last_error() << " -- the " << chunks.size() << " reads of this round are reported unmapped\n";
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            const uint16_t ch = owner[i];
+            Chan &c = chans_[ch];
+            c.raw_len += chunks[i].n_samples;
+            Paf p = unmapped_paf(c.id, ch, c.start, c.raw_len);
+            p.set_ended();
+            ret.emplace_back((uint16_t)(ch + 1), c.number, p);
+            c.active = false; c.has_pending = false; c.pending_first = false;
+            c.pending.clear();
+        }
+        return ret;
+    }
     float ms_e = 0, ms_m = 0;
     unc_rt_last_timing(rt_, &ms_e, &ms_m);
     last_ms_ = ms_e + ms_m;

@@ -82,6 +82,8 @@ private:
     unc_rt_t *rt_ = nullptr;
     std::vector<Chan> chans_;
     bool stopped_ = false;
+    bool warned_oversized_ = false;
+    bool oversized(const Chunk &chunk);
     float last_ms_ = 0;
 };
 

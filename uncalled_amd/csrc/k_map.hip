@@ -102,20 +102,17 @@ struct Tracker {
 // at the first cluster that lies more than `event` rows back (seed_tracker.cpp:169-191: in_range needs r2 - r1 <= e2 - e1 <=
 // e2, a cluster further back is never a candidate and ends the scan).  Inside that window the scan's outcome does not depend
 // on any order but the set's own tie-break (among equally long candidates the first in set order), so a bucket is an UNORDERED
-// array: nodes of NODE_K clusters (hot key 16 B + cold part 32 B each) chained from a per-read table of bucket heads.  A seed
+// array: nodes of NODE_K = 5 clusters (hot key 16 B + cold part 32 B each, 256 B) chained from a per-read table of bucket heads.  A seed
 // costs the heads of its window's buckets (one coalesced load), their nodes (one load, one lane per cluster) and a store;
 // insert = append, erase = move the node's last cluster into the hole.  No directory, nothing to shift, nothing to split.
-// The bucket width (DevIndex::bucket_shift) is set per index so that a window of max_events rows spans at most 9 buckets
-// (9 x 7 = 63 lanes) and a read has at most 2^16 buckets.  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
+// The bucket width (DevIndex::bucket_shift) is set per index: at least 2^12 rows (a window of the default max_events spans at
+// most 9 buckets; 12 are gathered at once) and at most 2^15 buckets per read (a bucket costs a node of 256 bytes once it is used).  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
 // directory search, leaf load and leaf shift were three to five dependent memory round trips per seed.)
-constexpr uint32_t NODE_K = 7;
-constexpr uint32_t NODE_BYTES = 384;                   // header 16 + 7 hot keys + 7 cold parts = 352, padded to 3 x 128
-constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;
-constexpr uint32_t CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;      // nodes per pool chunk (512)
-constexpr uint32_t WIN_BUCKETS = 9;
+constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;      // (NODE_K = 5 clusters in 256 bytes: unc_dev_types.h)
+constexpr uint32_t WIN_BUCKETS = 12;                  // buckets gathered at once (12 x 5 = 60 lanes)
 constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 struct alignas(16) NodeHdr { uint32_t count, next, pad0, pad1; };            // next: node id + 1 (0: end of the chain)
-static_assert(CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES && NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES, "node layout");
+static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES && WIN_BUCKETS * NODE_K <= WAVE, "node layout");
 static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32, "seed-cluster record layout");
 struct PoolView {          // DevPool with its arrays typed as global memory
     gptr_t nodes;
@@ -136,21 +133,21 @@ struct TrackerMem {
 // NODE_NONE when the read has used up its allowance or the pool has run dry (the read then overflows and is mapped again later).
 __device__ __forceinline__ uint32_t tracker_new_node(Tracker &T, const TrackerMem &M, int lane) {
     const uint32_t a = T.n_alloc;
-    if (a >= M.max_nodes) return NODE_NONE;
+    if (a >= M.max_nodes) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return NODE_NONE; }
     uint32_t chunk;
-    if ((a & (CHUNK_NODES - 1)) == 0) {
+    if (a % CHUNK_NODES == 0) {
         uint32_t c = SCHED_EMPTY;
         if (lane == 0) {
             c = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
             if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2), c);
         }
         chunk = bcast32(c, 0);
-        if (chunk == SCHED_EMPTY) return NODE_NONE;
+        if (chunk == SCHED_EMPTY) { T.status |= UNC_READ_CLUSTER_OVERFLOW | UNC_READ_POOL_DRY; return NODE_NONE; }
     } else {
         chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2)));
     }
     T.n_alloc = a + 1;
-    return chunk * CHUNK_NODES + (a & (CHUNK_NODES - 1));
+    return chunk * CHUNK_NODES + a % CHUNK_NODES;
 }
 
 // the read is over: its chunks go back to the pool
@@ -361,7 +358,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             erase_ref(mt);                                               // its start moved into the seed's bucket
             wave_sync();
             // (the node found for inserting is not the one just shrunk: that one belongs to another bucket)
-            if (!insert_key(nk, nc)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
         }
         wave_sync();
     } else {
@@ -376,7 +373,7 @@ static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_ma
             ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
             ClusterCold nc; nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
             wave_sync();
-            if (!insert_key(nk, nc)) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
             T.n++;
             wave_sync();
         }
@@ -1941,7 +1938,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 const uint32_t cap_mask = A->sched.cap_mask, n_reads = A->rd.n_reads;
                 for (int tries = 0; tries < 4096 && !kind; ++tries) {
                     const bool more = ld_acq(&sc->next_read) < n_reads;
-                    if (more) {
+                    // admission control: while the pool of cluster nodes is below an eighth, reads in flight go first (they
+                    // give their chunks back when they end); a new read is only started when none of them is waiting
+                    const bool low = (int32_t)(ld_acq(&A->pool.q->tail) - ld_acq(&A->pool.q->head)) < (int32_t)(A->pool.n_chunks >> 3);
+                    if (more && (!low || tries >= 8)) {
                         const uint32_t fs = sched_pop(&sc->freeq, free_cells, cap_mask);
                         if (fs != SCHED_EMPTY) {
                             const uint32_t t = atomicAdd(&sc->next_read, 1u);

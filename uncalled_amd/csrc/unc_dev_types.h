@@ -69,6 +69,12 @@ constexpr uint32_t LEAF_KEYS = 64;
 constexpr uint32_t LEAF_COLD_OFF = LEAF_KEYS * 16;
 constexpr uint32_t LEAF_BYTES = LEAF_KEYS * 16 + LEAF_KEYS * 32;
 constexpr uint32_t CHUNK_LEAVES = 64;
+// the seed-cluster grid of k_map (add_seed): a pool chunk (CHUNK_LEAVES * LEAF_BYTES bytes) is cut into nodes of NODE_K clusters:
+// header 16 B (count, next + 1) | NODE_K hot keys of 16 B | NODE_K cold parts of 32 B
+constexpr uint32_t NODE_K = 5;
+constexpr uint32_t NODE_BYTES = 16 + NODE_K * 48;      // 256
+constexpr uint32_t CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;
+static_assert(NODE_BYTES == 256 && CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES, "node layout");
 
 struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
 

@@ -324,11 +324,11 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         ix->dev.pad_ = 0;
     }
     {
-        // the grid the seed clusters of a read are bucketed in (k_map.hip, add_seed): buckets of 2^shift rows, at most 2^16 per read,
+        // the grid the seed clusters of a read are bucketed in (k_map.hip, add_seed): buckets of 2^shift rows, at most 2^15 per read,
         // at least 2^12 rows wide, so that a window of 32768 rows (max_events <= 65535 is checked per mapper) spans few buckets
         uint32_t bits = 1;
         while ((n >> bits) != 0) ++bits;
-        uint32_t shift = bits > 28 ? bits - 16 : 12;
+        uint32_t shift = bits > 27 ? bits - 15 : 12;
         ix->dev.bucket_shift = shift;
         ix->dev.n_buckets = (uint32_t)(n >> shift) + 2u;
     }
@@ -460,6 +460,7 @@ struct unc_mapper {
     uint64_t big_cap = 0;
     size_t big_slots = 0;
     bool big_at_limit = false;     // big_slots is all the free HBM allowed
+    uint32_t *d_list = nullptr; size_t list_cap = 0;     // read ids of a re-map round
     uint32_t remap_reads = 0;      // reads of the last batch that were mapped again with more room, and what that cost
     float remap_ms = 0;
     uint32_t *d_next = nullptr;
@@ -501,7 +502,7 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     const uint64_t o_seedp = region((uint64_t)max_seed_paths * sizeof(SeedPath));
     const uint64_t o_tasks = region((uint64_t)WAVE * MAX_REP_COPY_LIMIT * 8);
     const uint64_t o_cld = region(((uint64_t)n_buckets + 4) * 4);
-    const uint64_t o_clc = region((max_nodes / 512 + 1) * 4);
+    const uint64_t o_clc = region((max_nodes / CHUNK_NODES + 1) * 4);
     const uint64_t o_state = region(sizeof(SlotState));
     const uint64_t o_streams = region(6ull * sc.max_paths * 8);
     const uint64_t o_info = region((uint64_t)sc.max_paths * 8);
@@ -563,7 +564,7 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     free_scratch(m->sc);
     free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
-                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells};
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells, m->d_list};
     free_pool(m->pool);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
@@ -621,16 +622,17 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     {
-        // the leaf pool: 8 chunks (1.5 MB, about 25 000 clusters) per read in flight on average, 64 (200 000 clusters) on
-        // references of 2^28 index rows and more, where off-target reads collect hundreds of thousands; at most half of
-        // what is left of the HBM.  A read that finds the pool dry is mapped again after the batch (below).
+        // the pool of cluster nodes: 8 chunks (1.5 MB, 6144 nodes) per read in flight on average, 64 on references of 2^26
+        // index rows and more, where a read touches thousands of buckets and off-target reads collect hundreds of thousands
+        // of clusters; at most 60% of what is left of the HBM.  k_map stops taking up new reads while the pool is nearly
+        // empty; a read that still finds it dry is mapped again after the batch (below).
         uint32_t n_chunks = opts ? opts->pool_chunks : 0;
         if (n_chunks == 0) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
             const size_t chunk_bytes = (size_t)CHUNK_LEAVES * (LEAF_BYTES + 4);
-            const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 28) ? 64 : 8);
-            n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 2 / chunk_bytes));
+            const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 26) ? 64 : 8);
+            n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
         }
         int rc2 = alloc_pool(m->pool, n_chunks, &bytes);
         if (rc2) return rc2;
@@ -797,57 +799,80 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->ix->device));
         m->wave_busy = (grid && m->ms_map > 0 && khz > 0) ? (double)ticks / ((double)grid * (double)m->ms_map * (double)khz) : 0.0;
     }
-    // The reference's SeedTracker is an unbounded std::set.  A read that found the leaf pool dry, or whose directory of
-    // leaves is full, is mapped again after the batch: first on the same scratch with the whole pool to itself and its few
-    // fellows, then with a 16x longer directory and a quarter of the reads in flight per round, until it fits.
+    // The reference's SeedTracker is an unbounded std::set.  Reads whose set did not fit are mapped again after the batch, by
+    // cause: a read that found the pool of nodes DRY runs again on the same scratch with fewer and fewer reads sharing the
+    // pool (n_waves, a quarter of that, ... down to one read with the whole pool); a read that used up its own ALLOWANCE
+    // (max_clusters / 4 nodes) runs again on scratch with a 16x larger allowance, up to 2^26 clusters.
     {
-        std::vector<uint32_t> redo;
-        for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) redo.push_back(i);
-        m->remap_reads = (uint32_t)redo.size();
+        std::vector<uint32_t> dry, full, work;
+        auto classify = [&](uint32_t i) {
+            const uint32_t stt = m->h_results[i].status;
+            if (stt & UNC_READ_POOL_DRY) dry.push_back(i);
+            else if (stt & UNC_READ_CLUSTER_OVERFLOW) full.push_back(i);
+        };
+        for (uint32_t i = 0; i < n_reads; ++i) classify(i);
+        m->remap_reads = (uint32_t)(dry.size() + full.size());
         m->remap_ms = 0;
         const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
         size_t limit = m->n_waves;
-        for (int round = 0; !redo.empty() && cap <= (1ull << 26); ++round, limit = std::max<size_t>(1, limit / 4)) {
-            const DevScratch *sc = &m->sc;
-            size_t slots = std::min<size_t>(redo.size(), m->n_slots);
-            if (round > 0) {
-                cap *= 16;
-                if (cap > (1ull << 26)) break;
-                const size_t want = std::min<size_t>(std::max<size_t>(redo.size(), 64), m->n_waves);
-                if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
-                    free_scratch(m->big);
-                    m->big_cap = 0; m->big_slots = 0;
-                    size_t free_b = 0, total_b = 0;
-                    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                    const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths, m->ix->dev.n_buckets);
-                    const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
-                    const size_t n = std::min(want, fit);
-                    int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr, m->ix->dev.n_buckets);
-                    if (rc2) { free_scratch(m->big); return rc2; }
-                    m->big_cap = cap; m->big_slots = n; m->big_at_limit = n == fit;
-                }
-                sc = &m->big;
-                slots = std::min(m->big_slots, redo.size());
+        // one pass over `work` with at most `slots` reads in flight; the reads that overflowed again are sorted by cause
+        auto run_round = [&](const DevScratch &sc, size_t slots) -> int {
+            if (work.size() > m->list_cap) {
+                if (m->d_list) (void)hipFree(m->d_list);
+                m->d_list = nullptr; m->list_cap = 0;
+                HIPCHK(hipMalloc((void **)&m->d_list, work.size() * 4));
+                m->list_cap = work.size();
             }
-            slots = std::min<size_t>(slots, limit);
-            uint32_t *d_list = nullptr;
-            HIPCHK(hipMalloc((void **)&d_list, redo.size() * 4));
-            HIPCHK(hipMemcpyAsync(d_list, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(m->d_list, work.data(), work.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
             launch_pool_init(m->pool, st);
             DevReads rd2 = rd;
-            rd2.n_reads = (uint32_t)redo.size();
-            launch_map(m->ix->dev, *sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, m->pool, d_list);
+            rd2.n_reads = (uint32_t)work.size();
+            launch_map(m->ix->dev, sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, m->pool, m->d_list);
             HIPCHK(hipGetLastError());
+            const uint32_t lo = *std::min_element(work.begin(), work.end()), hi = *std::max_element(work.begin(), work.end());
+            HIPCHK(hipMemcpyAsync(m->h_results.data() + lo, m->d_results + lo, (size_t)(hi - lo + 1) * sizeof(DevResult), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            std::vector<uint32_t> still;
-            for (uint32_t i : redo) {
-                HIPCHK(hipMemcpy(&m->h_results[i], m->d_results + i, sizeof(DevResult), hipMemcpyDeviceToHost));
-                if (m->h_results[i].status & UNC_READ_CLUSTER_OVERFLOW) still.push_back(i);
+            for (uint32_t i : work) classify(i);
+            work.clear();
+            return UNC_OK;
+        };
+        auto scratch_now = [&]() -> const DevScratch & { return cap == m->sc.max_clusters ? m->sc : m->big; };
+        while (!dry.empty() || !full.empty()) {
+            if (!dry.empty()) {
+                const DevScratch &sc = scratch_now();
+                const size_t have = cap == m->sc.max_clusters ? m->n_slots : m->big_slots;
+                const size_t slots = std::min({dry.size(), have, limit});
+                work.swap(dry);
+                // (reads that ran out of allowance wait in `full` meanwhile: at this allowance they would only overflow again)
+                int rc2 = run_round(sc, slots);
+                if (rc2) return rc2;
+                if (!dry.empty()) {
+                    if (slots <= 1) break;           // one read with the whole pool to itself and still dry: reported (raise pool_chunks)
+                    limit = std::max<size_t>(1, slots / 4);
+                }
+                continue;
             }
-            (void)hipFree(d_list);
-            redo.swap(still);
+            cap *= 16;
+            if (cap > (1ull << 26)) break;
+            const size_t want = std::min<size_t>(std::max<size_t>(full.size(), 64), m->n_waves);
+            if (m->big_cap != cap || (m->big_slots < want && !m->big_at_limit)) {
+                free_scratch(m->big);
+                m->big_cap = 0; m->big_slots = 0;
+                size_t free_b = 0, total_b = 0;
+                HIPCHK(hipMemGetInfo(&free_b, &total_b));
+                const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths, m->ix->dev.n_buckets);
+                const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
+                const size_t n = std::min(want, fit);
+                int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr, m->ix->dev.n_buckets);
+                if (rc2) { free_scratch(m->big); return rc2; }
+                m->big_cap = cap; m->big_slots = n; m->big_at_limit = n == fit;
+            }
+            const size_t slots = std::min({full.size(), m->big_slots, limit});
+            work.swap(full);
+            int rc2 = run_round(m->big, slots);
+            if (rc2) return rc2;
         }
         m->remap_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_redo).count();
     }
@@ -1052,7 +1077,6 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     // flatten the bucket grid (k_map.hip, add_seed): heads -> chains of nodes (hot keys, then cold parts), then set order
     // (ref_en_.start descending, evt_en_ descending: seed_tracker.cpp:97-102)
     const uint32_t n_buckets = m->ix->dev.n_buckets;
-    constexpr uint32_t NODE_K = 7, NODE_BYTES = 384, CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;
     std::vector<uint32_t> heads(n_buckets);
     HIPCHK(hipMemcpy(heads.data(), m->sc.base + m->sc.off_cl_dir, (size_t)n_buckets * 4, hipMemcpyDeviceToHost));
     const uint32_t n_chunks = (s.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
