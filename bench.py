@@ -269,7 +269,7 @@ def a_reads(a, workload):
 def measured_traffic(a, workload):
     """HBM bytes per launch of k_map from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected
     from inside this process): used only when they were taken on this workload and batch size, else null."""
-    pmc = ROOT / "profiles" / "r02_pmc_k_map.json"
+    pmc = ROOT / "profiles" / "r03_pmc_k_map.json"
     if not pmc.exists():
         return None, "no PMC pass committed for this kernel"
     d = json.loads(pmc.read_text())
@@ -279,6 +279,27 @@ def measured_traffic(a, workload):
     if d.get("kernel_state"):
         src += "; " + d["kernel_state"]
     return float(d["hbm_bytes_per_launch"]), src
+
+
+def issue_roofline(a, workload, launch_ms, clock_hz):
+    """Issue side of k_map: wave-instructions of one launch (SQ_INSTS of the committed rocprofv3 pass on this workload and batch
+    size -- the count is a property of kernel + batch, the duration is this run's) / (1024 SIMDs x clock x launch time)."""
+    sq = ROOT / "profiles" / "r03_pmc_sq_summary.json"
+    if not sq.exists():
+        return None
+    d = json.loads(sq.read_text())
+    insts = d.get("counters", {}).get("SQ_INSTS")
+    if d.get("workload", "ecoli") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload) or not insts:
+        return None
+    c = d["counters"]
+    util = insts / (1024 * clock_hz * launch_ms * 1e-3)
+    out = {"wave_instructions_per_launch": insts, "simds": 1024, "clock_ghz": clock_hz * 1e-9, "utilisation": util,
+           "source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_INSTS on this batch) / this run's launch time",
+           "wave_cycle_shares": {k: round(v, 4) for k, v in d.get("derived", {}).items() if k.startswith("wave_cycle_share_")},
+           "per_read": {k[:-9]: round(v) for k, v in d.get("derived", {}).items() if k.endswith("_per_read")}}
+    if c.get("SQ_INSTS_VALU"):
+        out["valu_utilisation"] = c["SQ_INSTS_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
+    return out
 
 
 def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, dist, barrier, cache, lib, dev_name, extras, cpu_budget,
@@ -369,6 +390,14 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
         ev_ms = float(np.mean(ms_ev))
         achieved = map_bytes / (map_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(a, workload)
+        clock_hz = 2.4e9
+        if have_gpu:
+            clock_hz = float(getattr(torch.cuda.get_device_properties(local_rank), "clock_rate", 2.4e6)) * 1e3
+        issue = issue_roofline(a, workload, map_ms, clock_hz)
+        # what binds k_map: neither roofline -- its wavefronts wait on dependent scattered loads (wave_cycle_shares below)
+        bound_note = ("hbm is the stated roofline; measured: issue slots %.0f %% used, waves waiting on memory %.0f %% of their cycles -> "
+                      "latency of dependent scattered accesses, not bandwidth and not issue" %
+                      (100 * issue["utilisation"], 100 * issue["wave_cycle_shares"].get("wave_cycle_share_wait_any", 0))) if issue else None
         res.update({
             "config": {"workload": WORKLOAD_TEXT[workload] + READS_TEXT,
                        "reads_per_gpu_per_step": n_reads, "parallelism": f"reads sharded over {world} GPU(s), index replicated",
@@ -391,6 +420,8 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        "index_seq_len": int(ix.size), "index_device_bytes": int(ix.device_bytes())},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / map_bytes) if traffic else None,
+                         "issue": issue, "bound_note": bound_note,
                          "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms,
                          "whole_path_bytes_per_step": ev_bytes + map_bytes,
                          "k_events": {"algorithmic_bytes_per_launch": ev_bytes, "launch_ms": ev_ms,

@@ -74,7 +74,7 @@ for spec in sys.argv[2:]:
             bad = [f for f in capi.RESULT_FIELDS if not np.array_equal(hits[f], first[f])]
             same = "IDENTICAL" if not bad else "MISMATCH in %s (%d reads)" % (bad, int(sum((hits[f] != first[f]).sum() for f in bad)))
         print({k: round(v / tot, 3) for k, v in pc.items() if v})
-        print(spec.split("/")[-1], "k_events ms:", [round(x, 2) for x in te], "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", same, flush=True)
+        print(spec.split("/")[-1], "k_events ms:", [round(x, 2) for x in te], "k_map ms:", [round(x, 1) for x in t], "wave_busy %.3f" % busy, "slots", m.n_slots if hasattr(m, "n_slots") else "?", "remap", m.last_remap() if hasattr(m, "last_remap") else "?", same, flush=True)
         m.close(); ix.close()
     except Exception as e:   # a bad variant must not hide the others
         print(Path(lib).name, "FAILED:", repr(e)[:300], flush=True)

@@ -1,13 +1,22 @@
 #!/bin/bash
-# Dev tool (GPU box): SQ counters of k_map on the bench's own 50 k-read E. coli batch, one rocprofv3 pass per group
-# (--pmc with --kernel-trace only).  Each pass maps the batch ONCE with the given library (tools/dev/ab_libs.py, one run).
+# Dev tool (GPU box): hardware counters of k_map on the bench's own 50 k-read E. coli batch, one rocprofv3 pass per group
+# (--pmc with --kernel-trace only).  Each pass maps the batch ONCE with the given library (tools/dev/ab_libs.py, one run);
+# the passes cf / cw run the known-byte calibration kernels (tools/dev/pmc_calib.py) under FETCH_SIZE / WRITE_SIZE.
 #   bash tools/dev/pmc_sq.sh <outdir> [lib.so] [reads] [groups...]
+# Summaries (written BEFORE the large kernel traces are deleted, durations taken from each pass's own trace):
+#   <outdir>/summary.json         SQ counters + derived shares           (-> profiles/rNN_pmc_sq_summary.json)
+#   <outdir>/pmc_k_map.json       calibrated FETCH_SIZE + WRITE_SIZE     (-> profiles/rNN_pmc_k_map.json; bench.py reads it)
 OUT=${1:-gpurun_out/pmc_sq}; LIB=${2:-uncalled_amd/libuncalled_hip.so}; READS=${3:-50000}; shift 3
-GROUPS_=${@:-a b c d}
+GROUPS_=${@:-a b d f w cf cw}
 ROOT=$(pwd); mkdir -p $ROOT/$OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift
+  rm -rf $ROOT/$OUT/$name
   AB_NOPROF=1 AB_RUNS=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/$OUT/$name -o pmc -- \
         python $ROOT/tools/dev/ab_libs.py $READS $ROOT/$LIB > $ROOT/$OUT/$name.log 2>&1 || echo "pass $name failed"; tail -1 $ROOT/$OUT/$name.log; }
+calib() { name=$1; shift
+  rm -rf $ROOT/$OUT/$name
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/$OUT/$name -o calib -- \
+        python $ROOT/tools/dev/pmc_calib.py > $ROOT/$OUT/$name.log 2>&1 || echo "pass $name failed"; tail -1 $ROOT/$OUT/$name.log; }
 for g in $GROUPS_; do
 case $g in
 a) run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM ;;
@@ -17,8 +26,11 @@ d) run d SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU
 e) run e SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_IFETCH SQ_IFETCH_LEVEL SQ_LEVEL_WAVES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE ;;
 f) run f FETCH_SIZE ;;
 w) run w WRITE_SIZE ;;
+cf) calib cf FETCH_SIZE ;;
+cw) calib cw WRITE_SIZE ;;
 esac
 done
 cd $ROOT
-find $OUT -name "*_kernel_trace.csv" -size +3M -delete
 python tools/dev/summarise_sq.py $OUT $READS
+if [ -d $OUT/f ] && [ -d $OUT/w ]; then python tools/dev/summarise_pmc.py $OUT $OUT/pmc_k_map.json $READS ecoli f w cf cw | tail -12; fi
+find $OUT -name "*_kernel_trace.csv" -size +3M -delete      # (after the summaries: they take the durations from these)

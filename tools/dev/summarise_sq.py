@@ -20,15 +20,19 @@ for d in sorted(p for p in src.iterdir() if p.is_dir()):
             if "k_map" in r.get("Kernel_Name", ""):
                 tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 disp.add(r.get("Dispatch_Id")); names.add(r["Counter_Name"])
+    if not cc:
+        continue
+    if not kt:
+        raise SystemExit(f"{d}: no kernel trace beside the counters (deleted before summarising?)")
     dur = []
     for f in kt:
-        if cc and Path(f).stat().st_mtime + 600 < Path(cc[0]).stat().st_mtime:
-            raise SystemExit(f"{f} is older than the counters of its own pass")
+        if abs(Path(f).stat().st_mtime - Path(cc[0]).stat().st_mtime) > 600:
+            raise SystemExit(f"{f} was not written by the pass that wrote {cc[0]}")
         for r in csv.DictReader(open(f)):
             if "k_map" in r.get("Kernel_Name", ""):
                 dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
     passes[d.name] = {"counters": sorted(names), "k_map_dispatches": len(disp), "k_map_ms_under_pmc": dur}
-res = {"reads_per_launch": reads, "kernel": "unc::k_map<false>", "passes": passes, "counters": tot,
+res = {"workload": "ecoli", "reads_per_launch": reads, "kernel": "unc::k_map<false, true> (32-bit rows)", "passes": passes, "counters": tot,
        "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (MI355X_MICROARCH.md); one k_map dispatch per pass"}
 g = tot.get
 der = {}
@@ -43,6 +47,17 @@ for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ
         der[k[3:].lower() + "_per_read"] = g(k) / reads
 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INST_CYCLES_VALU"):
     der["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INST_CYCLES_VALU"))
+# issue utilisation: wave-instructions / (1024 SIMDs x clock x k_map's duration in the pass that counted them); the clock is
+# the 2.4 GHz peak engine clock (MI355X_MICROARCH.md), so this is a lower bound on the share of issue slots used
+CLOCK_HZ, SIMDS = 2.4e9, 1024
+for name, p in passes.items():
+    if "SQ_INSTS" in p["counters"] and p["k_map_ms_under_pmc"]:
+        ms = sum(p["k_map_ms_under_pmc"])
+        der["issue_utilisation"] = g("SQ_INSTS") / (SIMDS * CLOCK_HZ * ms * 1e-3)
+        der["issue_utilisation_note"] = f"SQ_INSTS / (1024 SIMDs x 2.4 GHz x {ms:.1f} ms of k_map under the counters)"
+    if "SQ_INSTS_VALU" in p["counters"] and p["k_map_ms_under_pmc"]:
+        ms = sum(p["k_map_ms_under_pmc"])
+        der["valu_issue_utilisation"] = g("SQ_INSTS_VALU") / (SIMDS * CLOCK_HZ * ms * 1e-3)
 res["derived"] = der
 out.write_text(json.dumps(res, indent=1))
 print(json.dumps(res, indent=1))

@@ -109,7 +109,6 @@ struct Tracker {
 // most 9 buckets; 12 are gathered at once) and at most 2^15 buckets per read (a bucket costs a node of 256 bytes once it is used).  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
 // directory search, leaf load and leaf shift were three to five dependent memory round trips per seed.)
 constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;      // (NODE_K = 5 clusters in 256 bytes: unc_dev_types.h)
-constexpr uint32_t WIN_BUCKETS = 12;                  // buckets gathered at once (12 x 5 = 60 lanes)
 constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 struct alignas(16) NodeHdr { uint32_t count, next, pad0, pad1; };            // next: node id + 1 (0: end of the chain)
 static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES && WIN_BUCKETS * NODE_K <= WAVE, "node layout");

@@ -71,10 +71,15 @@ constexpr uint32_t LEAF_BYTES = LEAF_KEYS * 16 + LEAF_KEYS * 32;
 constexpr uint32_t CHUNK_LEAVES = 64;
 // the seed-cluster grid of k_map (add_seed): a pool chunk (CHUNK_LEAVES * LEAF_BYTES bytes) is cut into nodes of NODE_K clusters:
 // header 16 B (count, next + 1) | NODE_K hot keys of 16 B | NODE_K cold parts of 32 B
-constexpr uint32_t NODE_K = 5;
-constexpr uint32_t NODE_BYTES = 16 + NODE_K * 48;      // 256
+#ifndef UNC_NODE_K
+#define UNC_NODE_K 5
+#endif
+constexpr uint32_t NODE_K = UNC_NODE_K;
+constexpr uint32_t NODE_BYTES = (16 + NODE_K * 48 + 127) / 128 * 128;      // 256 (384 for 7 clusters, 512 for 10)
 constexpr uint32_t CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;
-static_assert(NODE_BYTES == 256 && CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES, "node layout");
+constexpr uint32_t WIN_BUCKETS = 64 / NODE_K;          // buckets whose nodes one wavefront looks at together (12 x 5 = 60 lanes)
+constexpr uint32_t BUCKET_SHIFT_MIN = WIN_BUCKETS >= 9 ? 12 : WIN_BUCKETS >= 5 ? 13 : 14;   // a window of 2^15 rows fits WIN_BUCKETS
+static_assert(CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES, "node layout");
 
 struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
 

@@ -328,7 +328,7 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         // at least 2^12 rows wide, so that a window of 32768 rows (max_events <= 65535 is checked per mapper) spans few buckets
         uint32_t bits = 1;
         while ((n >> bits) != 0) ++bits;
-        uint32_t shift = bits > 27 ? bits - 15 : 12;
+        uint32_t shift = bits > 15 + BUCKET_SHIFT_MIN ? bits - 15 : BUCKET_SHIFT_MIN;
         ix->dev.bucket_shift = shift;
         ix->dev.n_buckets = (uint32_t)(n >> shift) + 2u;
     }
