@@ -583,7 +583,13 @@ def main():
         torch.cuda.set_device(local_rank)
     dev_name = f"cuda:{local_rank}" if have_gpu else "cpu"
     dist = None
+    placement = None
     if world > 1:
+        # each rank's host threads (this one, the library's staging / loader threads) on the NUMA node of its GPU
+        from uncalled_amd.numa import pin_to_gpu_node
+        placement = pin_to_gpu_node(local_rank, world) if have_gpu else None
+        if placement:
+            log(f"rank {rank}: host threads -> {placement}")
         import torch.distributed as dist
         backend = os.environ.get("UNC_DIST_BACKEND", "nccl" if have_gpu else "gloo")
         if backend == "nccl":
@@ -619,6 +625,8 @@ def main():
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
+        if placement:
+            out["config"]["host_placement_rank0"] = placement
     # secondary blocks: N = 1 only (BASELINE config 4 shards 2 M reads over 8 GPUs = 250 k per GPU: one GPU's share is
     # what a single box can measure; the same code path runs on every rank)
     if world == 1 and a.workload == "ecoli" and have_gpu:

@@ -86,3 +86,30 @@ def test_bench_py_two_ranks_gloo(sim_lib, tmp_path):
     assert abs(b["value"] - 3 * 2 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6     # whole job: both ranks' reads
     assert b["verify"]["all_steps_identical"] and b["verify"]["steps_hashed"] == 2
     assert "cpu_baseline" not in b and "secondary" not in b                               # N > 1: neither is run
+
+
+def test_numa_placement_plan(tmp_path):
+    """uncalled_amd/numa.py: a rank's host threads go to the NUMA node of its GPU (sysfs), to an equal share of the allowed
+    cores when the platform names no node, and stay put on one GPU -- worked out against a fake sysfs tree."""
+    from uncalled_amd import numa
+    assert numa.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and numa.parse_cpulist("") == []
+    sysfs = tmp_path / "sys"
+    for bdf, node in (("0000:c1:00.0", 1), ("0000:05:00.0", -1)):
+        d = sysfs / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    for node, cpus in ((0, "0-7"), (1, "8-15")):
+        d = sysfs / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    allowed = set(range(16))
+    cpus, how = numa.plan(3, 8, allowed, "0000:c1:00.0", str(sysfs))
+    assert cpus == list(range(8, 16)) and "numa node 1" in how
+    cpus, how = numa.plan(3, 8, set(range(4, 12)), "0000:c1:00.0", str(sysfs))       # only the allowed cores of the node
+    assert cpus == [8, 9, 10, 11]
+    cpus, how = numa.plan(3, 8, allowed, "0000:05:00.0", str(sysfs))                 # node -1: equal shares
+    assert cpus == [6, 7] and "share 3 of 8" in how
+    cpus, how = numa.plan(0, 1, allowed, None, str(sysfs))                           # one GPU, nothing known: untouched
+    assert cpus == sorted(allowed) and how == "left as is"
+    out = numa.pin_to_gpu_node(0, 1, str(sysfs))                                     # never raises, also without a GPU
+    assert "how" in out

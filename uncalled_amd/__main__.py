@@ -129,7 +129,9 @@ def map_multi_gpu(args, argv, make_cmd=worker_cmd):
             lists.append(lst.name)
             lst.write("\n".join(files) + "\n")
             lst.close()
-            procs.append(subprocess.Popen(make_cmd(args, lst.name, dev), stdout=subprocess.PIPE, text=True, bufsize=1))
+            # UNC_PIN_WORLD: the worker keeps its host threads (HDF5 loader, staging, PAF writer) on its GPU's NUMA node
+            procs.append(subprocess.Popen(make_cmd(args, lst.name, dev), stdout=subprocess.PIPE, text=True, bufsize=1,
+                                          env={**os.environ, "UNC_PIN_WORLD": str(len(shards))}))
         threads = [threading.Thread(target=pump, args=(p,)) for p in procs]
         for t in threads:
             t.start()
@@ -165,6 +167,10 @@ def map_cmd(args):
     _assert_exists(conf.bwa_prefix + ".uncl")
     if conf.read_list:
         _assert_exists(conf.read_list)
+    pin_world = int(os.environ.get("UNC_PIN_WORLD", "0") or 0)
+    if pin_world > 1:
+        from .numa import pin_to_gpu_node
+        sys.stderr.write("GPU %d: host threads -> %s\n" % (args.device, pin_to_gpu_node(args.device, pin_world)))
     mapper = unc.MapPool(conf)
     sys.stderr.write("Loading fast5s\n")
     for f in load_fast5s(args.fast5s, args.recursive):
