@@ -300,7 +300,7 @@ def get_parser():
     p.add_argument("-c", "--max-chunks", type=int, default=1000000, help="Will give up on a read after this many chunks have been processed")
     p.add_argument("--chunk-time", type=float, default=1, help="Length of chunks in seconds")
     p.add_argument("--device", type=int, default=0, help="GPU ordinal")
-    p.add_argument("--batch-reads", type=int, default=None, help="Reads per GPU batch (default: as many as the mapper keeps in flight)")
+    p.add_argument("--batch-reads", type=int, default=None, help="Reads per GPU batch (default: four times what the mapper keeps in flight; the first batch is one load)")
     p.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use: one worker process each, fast5 files dealt round-robin")
 
     p = sp.add_parser("sim", help="Simulate real-time targeted sequencing from fast5 files (enrich / deplete decisions per read)")

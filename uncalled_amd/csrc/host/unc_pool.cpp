@@ -295,18 +295,22 @@ MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(conf) {
         std::cerr << "Error: " << unc_last_error() << "\n";   // Mapper::load_static aborts on a bad index, mapper.cpp:118-127
         abort();
     }
-    // a batch = as many reads as the mapper keeps in flight (the time-sliced scheduler of k_map needs them all at once
-    // to find the long reads early); --batch-reads overrides
+    // a batch = four times as many reads as the mapper keeps in flight: every unc_map_batch call ends with the few reads that
+    // run to max_events on a nearly idle chip, and at one load of the slots that tail is a third of the call (round 3: 11.5 k
+    // reads/s end to end against 17 k in HBM); the FIRST batch is one load of the slots, so that the first PAF lines do not
+    // wait for 65 k reads to be read from disk.  --batch-reads overrides; kBatchBytes caps the page-locked memory of a batch.
     uint32_t geo[5] = {0, 0, 0, 0, 0};
     unc_mapper_geometry(mapper_, geo);
-    batch_reads_ = conf.batch_reads ? conf.batch_reads : (geo[1] ? geo[1] : 4096);
+    first_batch_reads_ = geo[1] ? geo[1] : 4096;
+    batch_reads_ = conf.batch_reads ? conf.batch_reads : 4 * first_batch_reads_;
+    if (first_batch_reads_ > batch_reads_) first_batch_reads_ = batch_reads_;
     free_.push_back(0);
     free_.push_back(1);
 }
 
 MapPool::~MapPool() {
     stop();
-    for (Batch &b : bufs_) if (b.raw) unc_host_free(b.raw);
+    for (Batch &b : bufs_) release(b);
     if (mapper_) unc_mapper_free(mapper_);
     if (ix_) unc_index_free(ix_);
 }
@@ -317,15 +321,33 @@ void MapPool::add_fast5(const std::string &fname) {
     cv_.notify_all();       // an idle loader picks it up
 }
 
+void MapPool::release(Batch &b) {
+    if (b.raw) { if (b.pinned) unc_host_free(b.raw); else free(b.raw); }
+    b.raw = nullptr; b.cap = 0;
+}
+
+// Room for `need` samples.  Page-locked memory while the driver hands it out; pageable memory (the C ABI takes either, the
+// copy to the device is then staged by the runtime) with one warning when it does not -- a full pinned pool is no reason to
+// end a run.  The old buffer is released before the new one is the only copy only in the sense that both exist during memcpy.
 bool MapPool::grow(Batch &b, uint64_t need) {
     if (need <= b.cap) return true;
     uint64_t cap = b.cap ? b.cap : (64ull << 20);
     while (cap < need) cap *= 2;
+    if (cap > kBatchBytes / 2 && need <= kBatchBytes / 2) cap = kBatchBytes / 2;      // never past the byte cap of a batch
+    bool pinned = true;
     int16_t *p = static_cast<int16_t *>(unc_host_alloc(cap * 2));
-    if (!p) return false;
+    if (!p) {
+        pinned = false;
+        p = static_cast<int16_t *>(malloc(cap * 2));
+        if (!p) return false;
+        if (!warned_pageable_) {
+            std::cerr << "Warning: no page-locked host memory for a staging buffer of " << (cap * 2 >> 20) << " MB: using pageable memory (slower copies)\n";
+            warned_pageable_ = true;
+        }
+    }
     if (b.used) memcpy(p, b.raw, b.used * 2);
-    if (b.raw) unc_host_free(b.raw);
-    b.raw = p; b.cap = cap;
+    release(b);
+    b.raw = p; b.cap = cap; b.pinned = pinned;
     return true;
 }
 
@@ -344,10 +366,18 @@ void MapPool::loader_main() {
         }
         Batch &b = bufs_[bi];
         b.used = 0; b.off.assign(1, 0); b.cal.clear(); b.meta.clear();
-        while (b.meta.size() < batch_reads_) {
+        const uint32_t target = batches_staged_ == 0 ? first_batch_reads_ : batch_reads_;
+        bool failed = false;
+        while (b.meta.size() < target) {
             if (reader_.buffered() == 0 && (reader_.empty() || reader_.fill_buffer() == 0)) break;
+            // (a batch is also closed by bytes: whole reads with -c 1000000 are tens of MB each)
+            if (!b.meta.empty() && (b.used + reader_.front_size() + 1) * 2 > kBatchBytes) break;
             RawRead r = reader_.pop_read();
-            if (!grow(b, b.used + r.signal.size() + 1)) { std::cerr << "Error: out of page-locked host memory\n"; abort(); }
+            if (!grow(b, b.used + r.signal.size() + 1)) {
+                std::cerr << "Error: out of host memory for a staging buffer (" << ((b.used + r.signal.size()) * 2 >> 20) << " MB); read " << r.id << " is dropped\n";
+                failed = true;
+                break;
+            }
             if (!r.signal.empty()) memcpy(b.raw + b.used, r.signal.data(), r.signal.size() * 2);
             b.used += r.signal.size();
             b.off.push_back(b.used);
@@ -364,6 +394,8 @@ void MapPool::loader_main() {
             if (stopped_) break;
             continue;
         }
+        (void)failed;
+        ++batches_staged_;
         staged_.push_back(bi);
         cv_.notify_all();
     }

@@ -28,7 +28,7 @@ struct Conf {
     float chunk_time = 1.0f, sample_rate = 4000.0f;
     std::string fast5_list, read_list;
     int device = 0;                  // GPU ordinal
-    uint32_t batch_reads = 0;        // reads handed to one unc_map_batch call (0 = as many as the mapper keeps in flight)
+    uint32_t batch_reads = 0;        // reads handed to one unc_map_batch call (0 = four times what the mapper keeps in flight)
     // realtime (conf.hpp:57-96 RealtimeParams): what the decision loop of scripts/uncalled:216-256 reads
     int realtime_mode = 0;           // RealtimePool::DEPLETE / ENRICH
     int active_chs = 0;              // RealtimePool::FULL / EVEN / ODD
@@ -85,6 +85,7 @@ public:
     bool empty();
     RawRead pop_read();
     uint32_t buffered() const { return (uint32_t)buffered_.size(); }
+    uint64_t front_size() const { return buffered_.empty() ? 0 : buffered_.front().signal.size(); }   // samples of the read pop_read hands out next
     bool all_buffered() const;
 
 private:
@@ -120,7 +121,8 @@ public:
 private:
     struct ReadMeta { std::string id; uint16_t channel_idx; uint64_t start_sample; };
     struct Batch {
-        int16_t *raw = nullptr;        // page-locked
+        int16_t *raw = nullptr;        // page-locked (pageable when the driver has none left)
+        bool pinned = true;
         uint64_t cap = 0, used = 0;
         std::vector<uint64_t> off;
         std::vector<unc_calib_t> cal;
@@ -129,11 +131,15 @@ private:
     void loader_main();
     void mapper_main();
     bool grow(Batch &b, uint64_t need);
+    void release(Batch &b);
+    static constexpr uint64_t kBatchBytes = 8ull << 30;     // staged samples of one batch (two batches exist)
     Conf conf_;
     Fast5Reader reader_;
     unc_index_t *ix_ = nullptr;
     unc_mapper_t *mapper_ = nullptr;
-    uint32_t batch_reads_ = 0;
+    uint32_t batch_reads_ = 0, first_batch_reads_ = 0;
+    uint64_t batches_staged_ = 0;
+    bool warned_pageable_ = false;
     Batch bufs_[2];
     std::deque<int> free_, staged_;       // indices into bufs_
     std::deque<std::string> new_files_;   // add_fast5 -> loader thread
