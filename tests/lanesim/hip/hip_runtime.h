@@ -213,6 +213,9 @@ static inline float __fadd_rn(float a, float b) { volatile float r = a + b; retu
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __fma_rn(double a, double b, double c) { return std::fma(a, b, c); }
+static inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 

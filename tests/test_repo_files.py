@@ -40,3 +40,16 @@ def test_nothing_in_the_package_is_ignored_except_build_outputs(tracked):
 def test_generators_are_committed(tracked):
     for gen in ("tools/gen_threshs_table.py", "tools/gen_model_table.py", "tests/golden/make_goldens.py"):
         assert gen in tracked
+
+
+def test_division_by_window_length_is_exact(tmp_path):
+    """k_events.hip divides by the window lengths 3 and 6 with a multiply and two FMAs (div_w): the sampled run of the checker
+    (every 97th float, 2^22 random double significands at the guard's edge exponents) must agree with the division bit for bit;
+    the full run (all floats, 2^33 doubles) is tests/dev/check_div_const.c without an argument."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "check_div_const"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(root / "tests" / "dev" / "check_div_const.c"), "-lm"], check=True)
+    out = subprocess.run([str(exe), "quick"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "0 differ" in out.stdout.splitlines()[0] and "0 differ" in out.stdout.splitlines()[1]

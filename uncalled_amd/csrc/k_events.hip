@@ -32,50 +32,91 @@ struct Detector {
     bool valid_peak;
 };
 
-// event_detector.cpp:221-279.  `other` is the long detector when `det` is the short one.
-__device__ __forceinline__ bool peak_detect(Detector &det, Detector *long_det, float current_value, uint32_t buf_mid,
-                                            float peak_height) {
-    if (det.masked_to >= buf_mid) return false;
-    if (det.peak_pos == -1) {
-        if (current_value < det.peak_value) {
-            det.peak_value = current_value;
-        } else if (__fsub_rn(current_value, det.peak_value) > peak_height) {
-            det.peak_value = current_value;
-            det.peak_pos = (int32_t)buf_mid;
-        }
-    } else {
-        if (current_value > det.peak_value) {
-            det.peak_value = current_value;
-            det.peak_pos = (int32_t)buf_mid;
-        }
-        if (long_det != nullptr) {
-            if (det.peak_value > det.threshold) {
-                long_det->masked_to = (uint32_t)det.peak_pos + det.window_length;
-                long_det->peak_pos = -1;
-                long_det->peak_value = FLT_MAX;
-                long_det->valid_peak = false;
-            }
-        }
-        if (__fsub_rn(det.peak_value, current_value) > peak_height && det.peak_value > det.threshold) {
-            det.valid_peak = true;
-        }
-        if (det.valid_peak && (buf_mid - (uint32_t)det.peak_pos) > det.window_length / 2) {
-            det.peak_pos = -1;
-            det.peak_value = current_value;
-            det.valid_peak = false;
-            return true;
-        }
+// event_detector.cpp:221-279 as straight-line code: 64 lanes follow 64 reads whose detectors are in different states at every
+// sample, so every branch of the written-out form below is taken by some lane and the wavefront pays for all of them plus the
+// exec-mask bookkeeping in between (round 3, profiles/r03_ab_k_events.log: 31.6 -> 27.4 ms per 50 k reads); here both arms are computed and selected (the arithmetic is the same single operations:
+// one float subtraction per comparison against peak_height, no contraction).  `long_det` is the long detector when `det` is
+// the short one.
+__device__ __forceinline__ bool peak_detect(Detector &det, Detector *long_det, float cur, uint32_t buf_mid, float peak_height) {
+    const bool act = !(det.masked_to >= buf_mid);
+    const bool idle = det.peak_pos == -1;                       // no candidate yet: following the minimum
+    const float pv = det.peak_value;
+    // -- idle arm
+    const bool a_lt = cur < pv;
+    const bool a_rise = !a_lt && (__fsub_rn(cur, pv) > peak_height);
+    const float a_pv = (a_lt || a_rise) ? cur : pv;
+    const int32_t a_pos = a_rise ? (int32_t)buf_mid : -1;
+    // -- tracking arm
+    const bool b_gt = cur > pv;
+    const float b_pv = b_gt ? cur : pv;
+    const int32_t b_pos = b_gt ? (int32_t)buf_mid : det.peak_pos;
+    const bool b_over = b_pv > det.threshold;
+    const bool b_valid = det.valid_peak || ((__fsub_rn(b_pv, cur) > peak_height) && b_over);
+    const bool b_emit = b_valid && ((buf_mid - (uint32_t)b_pos) > det.window_length / 2);
+    const bool trk = act && !idle;
+    if (long_det != nullptr) {
+        const bool m = trk && b_over;
+        long_det->masked_to = m ? (uint32_t)b_pos + det.window_length : long_det->masked_to;
+        long_det->peak_pos = m ? -1 : long_det->peak_pos;
+        long_det->peak_value = m ? FLT_MAX : long_det->peak_value;
+        long_det->valid_peak = m ? false : long_det->valid_peak;
     }
-    return false;
+    const float n_pv = idle ? a_pv : (b_emit ? cur : b_pv);
+    const int32_t n_pos = idle ? a_pos : (b_emit ? -1 : b_pos);
+    const bool n_valid = idle ? det.valid_peak : (b_emit ? false : b_valid);
+    det.peak_value = act ? n_pv : pv;
+    det.peak_pos = act ? n_pos : det.peak_pos;
+    det.valid_peak = act ? n_valid : det.valid_peak;
+    return trk && b_emit;
 }
+
+// ---- x / 3 and x / 6, correctly rounded, in three operations instead of the division sequence (a dozen dependent FP64
+// operations for a double).  With y = RN(1 / d):  q = RN(x * y);  r = x - d * q (one FMA: exact, q is within 2 ulp of x / d and r a
+// small multiple of ulp(q));  q' = RN(q + r * y).  The real number q + r * y differs from x / d by |r * y * eps| < 2^-50 ulp, and
+// for d = 3 * 2^k the quotient of a p-bit significand m is never closer than 1/6 ulp to a rounding boundary (2m - 6k - 3 is an
+// odd integer), and equally far from the next representable number unless it is one -- so the last rounding lands on RN(x / d),
+// the value the reference's division instruction (built without FMA contraction, setup.py:121) produces.  Outside the range
+// where neither q nor r can leave the normal numbers (zero, subnormal quotients, infinities, NaN) the division itself is
+// used; tests/dev/check_div_const.c checks the float version over every float and the double version on 2^33 samples.
+#ifndef UNC_EXACT_DIV_CONST
+#define UNC_EXACT_DIV_CONST 1
+#endif
+// FAST = the three-operation form, unconditionally (straight-line code: the sixteen t-statistics of a block interleave);
+// `bad` collects whether any operand was outside the range the argument covers -- the caller then recomputes with FAST = false.
+template <uint32_t W, bool FAST> __device__ __forceinline__ double div_w(double x, bool &bad) {
+    static_assert(W == 3 || W == 6, "the argument above is for 3 * 2^k");
+    if constexpr (FAST) {
+        const double ax = fabs(x);
+        bad |= !(ax >= 0x1p-900 && ax <= 0x1p900);
+        constexpr double d = (double)W, y = 1.0 / (double)W;
+        const double q = __dmul_rn(x, y);
+        const double r = __fma_rn(-d, q, x);
+        return __fma_rn(r, y, q);
+    } else {
+        return x / (double)W;
+    }
+}
+template <uint32_t W, bool FAST> __device__ __forceinline__ float div_w(float x, bool &bad) {
+    static_assert(W == 3 || W == 6, "the argument above is for 3 * 2^k");
+    if constexpr (FAST) {
+        const float ax = fabsf(x);
+        bad |= !(ax >= 0x1p-100f && ax <= 0x1p100f);
+        constexpr float d = (float)W, y = 1.0f / (float)W;
+        const float q = __fmul_rn(x, y);
+        const float r = __fmaf_rn(-d, q, x);
+        return __fmaf_rn(r, y, q);
+    } else {
+        return __fdiv_rn(x, (float)W);
+    }
+}
+constexpr bool EV_FAST_DIV = UNC_EXACT_DIV_CONST != 0;
 
 // event_detector.cpp:174-219 with the ring addressed by ABSOLUTE position (slot = pos & 15).
 // `st_pos` is the position the reference's `(buf_mid - w) % 13` lands on (it wraps for
 // buf_mid < w, where slot (2^32 + buf_mid - w) % 13 == buf_mid + 6 still holds C[buf_mid + 6]).
-__device__ __forceinline__ float tstat(const double *sum, const double *sumsq, int lane, uint32_t t, uint32_t buf_mid,
-                                       uint32_t w) {
-    if (t <= 2 * w) return 0.0f;
-    const float wf = (float)w;
+template <uint32_t W, bool FAST>
+__device__ __forceinline__ float tstat_ring(const double *sum, const double *sumsq, int lane, uint32_t buf_mid, bool &bad) {
+    constexpr uint32_t w = W;
     uint32_t st_pos = buf_mid >= w ? buf_mid - w : buf_mid + 6;
     uint32_t i = (buf_mid & (RING - 1)) * WAVE + lane, st = (st_pos & (RING - 1)) * WAVE + lane,
              en = ((buf_mid + w) & (RING - 1)) * WAVE + lane;
@@ -83,13 +124,21 @@ __device__ __forceinline__ float tstat(const double *sum, const double *sumsq, i
     double sumsq1 = sumsq[i] - sumsq[st];
     float sum2 = (float)(sum[en] - sum[i]);
     float sumsq2 = (float)(sumsq[en] - sumsq[i]);
-    float mean1 = (float)(sum1 / (double)wf);
-    float mean2 = __fdiv_rn(sum2, wf);
-    float m1sq = __fmul_rn(mean1, mean1), q2 = __fdiv_rn(sumsq2, wf), m2sq = __fmul_rn(mean2, mean2);
-    float combined_var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)q2) - (double)m2sq);
+    float mean1 = (float)div_w<W, FAST>(sum1, bad);
+    float mean2 = div_w<W, FAST>(sum2, bad);
+    float m1sq = __fmul_rn(mean1, mean1), q2 = div_w<W, FAST>(sumsq2, bad), m2sq = __fmul_rn(mean2, mean2);
+    float combined_var = (float)(((div_w<W, FAST>(sumsq1, bad) - (double)m1sq) + (double)q2) - (double)m2sq);
     combined_var = fmaxf(combined_var, FLT_MIN);
     float delta_mean = __fsub_rn(mean2, mean1);
-    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(__fdiv_rn(combined_var, wf)));
+    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(div_w<W, FAST>(combined_var, bad)));
+}
+template <uint32_t W>
+__device__ __forceinline__ float tstat(const double *sum, const double *sumsq, int lane, uint32_t t, uint32_t buf_mid) {
+    if (t <= 2 * W) return 0.0f;
+    bool bad = false;
+    float v = tstat_ring<W, EV_FAST_DIV>(sum, sumsq, lane, buf_mid, bad);
+    if (bad) v = tstat_ring<W, false>(sum, sumsq, lane, buf_mid, bad);
+    return v;
 }
 
 // ---- k_events: register-window detector ----------------------------------------------------------------------------
@@ -99,20 +148,20 @@ constexpr int WIN = 12 + EB;          // window of cumulative sums: positions ba
 // compute_tstat (event_detector.cpp:174-219) for the sample whose newest cumulative sum sits at window index `ni`:
 // buf_mid = ni - 6, the two windows end / start there.  `st` = index of C[buf_mid - w] (the caller resolves the
 // reference's wrap for the first samples).
-__device__ __forceinline__ float tstat_win(const double *C, const double *Q, int ni, int st, uint32_t w) {
-    const float wf = (float)w;
-    const int i = ni - 6, en = i + (int)w;
+template <uint32_t W, bool FAST>
+__device__ __forceinline__ float tstat_win(const double *C, const double *Q, int ni, int st, bool &bad) {
+    const int i = ni - 6, en = i + (int)W;
     double sum1 = C[i] - C[st];
     double sumsq1 = Q[i] - Q[st];
     float sum2 = (float)(C[en] - C[i]);
     float sumsq2 = (float)(Q[en] - Q[i]);
-    float mean1 = (float)(sum1 / (double)wf);
-    float mean2 = __fdiv_rn(sum2, wf);
-    float m1sq = __fmul_rn(mean1, mean1), q2 = __fdiv_rn(sumsq2, wf), m2sq = __fmul_rn(mean2, mean2);
-    float combined_var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)q2) - (double)m2sq);
+    float mean1 = (float)div_w<W, FAST>(sum1, bad);
+    float mean2 = div_w<W, FAST>(sum2, bad);
+    float m1sq = __fmul_rn(mean1, mean1), q2 = div_w<W, FAST>(sumsq2, bad), m2sq = __fmul_rn(mean2, mean2);
+    float combined_var = (float)(((div_w<W, FAST>(sumsq1, bad) - (double)m1sq) + (double)q2) - (double)m2sq);
     combined_var = fmaxf(combined_var, FLT_MIN);
     float delta_mean = __fsub_rn(mean2, mean1);
-    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(__fdiv_rn(combined_var, wf)));
+    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(div_w<W, FAST>(combined_var, bad)));
 }
 
 struct EvRun {                        // what EventDetector carries from sample to sample
@@ -175,8 +224,9 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P, uint3
         Q[12] = Q[11] + (double)__fmul_rn(s, s);
         E.t++;
         const uint32_t buf_mid = E.t - 7;
-        const float t1 = E.t <= 2 * UNC_WINDOW1 ? 0.0f : tstat_win(C, Q, 12, buf_mid >= UNC_WINDOW1 ? 6 - UNC_WINDOW1 : 12, UNC_WINDOW1);
-        const float t2 = E.t <= 2 * UNC_WINDOW2 ? 0.0f : tstat_win(C, Q, 12, buf_mid >= UNC_WINDOW2 ? 6 - UNC_WINDOW2 : 12, UNC_WINDOW2);
+        bool bad = false;      // (head and tail samples: the division itself)
+        const float t1 = E.t <= 2 * UNC_WINDOW1 ? 0.0f : tstat_win<UNC_WINDOW1, false>(C, Q, 12, buf_mid >= UNC_WINDOW1 ? 6 - UNC_WINDOW1 : 12, bad);
+        const float t2 = E.t <= 2 * UNC_WINDOW2 ? 0.0f : tstat_win<UNC_WINDOW2, false>(C, Q, 12, buf_mid >= UNC_WINDOW2 ? 6 - UNC_WINDOW2 : 12, bad);
         fsm_step(E, P, t1, t2, buf_mid, C[4], means, mcap);
 #pragma unroll
         for (int i = 0; i < 12; ++i) { C[i] = C[i + 1]; Q[i] = Q[i + 1]; }
@@ -199,10 +249,18 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P, uint3
             C[12 + j] = C[11 + j] + (double)s;
             Q[12 + j] = Q[11 + j] + (double)__fmul_rn(s, s);
         }
+        bool bad = false;
 #pragma unroll
         for (int j = 0; j < EB; ++j) {
-            t1[j] = tstat_win(C, Q, 12 + j, 6 + j - UNC_WINDOW1, UNC_WINDOW1);
-            t2[j] = tstat_win(C, Q, 12 + j, 6 + j - UNC_WINDOW2, UNC_WINDOW2);
+            t1[j] = tstat_win<UNC_WINDOW1, EV_FAST_DIV>(C, Q, 12 + j, 6 + j - UNC_WINDOW1, bad);
+            t2[j] = tstat_win<UNC_WINDOW2, EV_FAST_DIV>(C, Q, 12 + j, 6 + j - UNC_WINDOW2, bad);
+        }
+        if (bad) {       // an operand outside the range of the short division (a flat-zero window, say): the block again, dividing
+#pragma unroll      // (static indices: C / Q / t1 / t2 stay in registers)
+            for (int j = 0; j < EB; ++j) {
+                t1[j] = tstat_win<UNC_WINDOW1, false>(C, Q, 12 + j, 6 + j - UNC_WINDOW1, bad);
+                t2[j] = tstat_win<UNC_WINDOW2, false>(C, Q, 12 + j, 6 + j - UNC_WINDOW2, bad);
+            }
         }
 #pragma unroll
         for (int j = 0; j < EB; ++j) {
@@ -336,8 +394,8 @@ __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const floa
         s_sumsq[cur] = s_sumsq[prv] + (double)ss;
         t++;
         const uint32_t buf_mid = t - 7;
-        const float t1 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW1);
-        const float t2 = tstat(s_sum, s_sumsq, lane, t, buf_mid, UNC_WINDOW2);
+        const float t1 = tstat<UNC_WINDOW1>(s_sum, s_sumsq, lane, t, buf_mid);
+        const float t2 = tstat<UNC_WINDOW2>(s_sum, s_sumsq, lane, t, buf_mid);
         const bool p1 = peak_detect(sd, &ld, t1, buf_mid, P.peak_height);
         const bool p2 = peak_detect(ld, nullptr, t2, buf_mid, P.peak_height);
         if (!(p1 || p2)) continue;

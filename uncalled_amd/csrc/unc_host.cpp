@@ -925,10 +925,14 @@ extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_
     DevReads rd;
     int rc = stage_batch(m, n_reads, raw, offsets, calib, 0, st, &rd);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(m->ev[0], st));
     launch_events(rd, m->P, st, m->ev_rpw);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev[1], st));
     HIPCHK(hipMemcpyAsync(info, m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));     // unc_mapper_last_timing: k_events alone
+    m->ms_map = 0;
     uint64_t tot = 0;
     for (uint32_t i = 0; i < n_reads; ++i) { means_offsets[i] = tot; tot += info[i].n_events; }
     means_offsets[n_reads] = tot;
