@@ -73,13 +73,23 @@ p.wait()
 dt = time.time() - t0
 stamps.append((dt, n_lines))
 t_first = stamps[0][0]
-# steady state: from the first line of the SECOND half of the output to the last line
-half = [x for x in stamps if x[1] >= n_lines // 2]
-steady = (n_lines - half[0][1]) / (dt - half[0][0]) if len(half) > 1 and dt > half[0][0] else None
+# PAF lines arrive batch by batch (a burst per unc_map_batch call).  Steady state = everything after the FIRST burst (whose
+# arrival time holds the interpreter start, the index load and the first batch's load): lines after it / time after it.
+bursts, cur = [], [stamps[0]]
+for a, b in zip(stamps, stamps[1:]):
+    if b[0] - a[0] > 0.2:
+        bursts.append(cur[-1]); cur = []
+    cur.append(b)
+bursts.append(cur[-1] if cur else stamps[-1])
+steady = None
+if len(bursts) > 1 and bursts[-1][0] > bursts[0][0]:
+    steady = (bursts[-1][1] - bursts[0][1]) / (bursts[-1][0] - bursts[0][0])
 print(json.dumps({"workload": "python -m uncalled_amd map <ecoli_syn> <dir of multi-fast5 files>", "reads": n, "fast5_files": len(files),
                   "fast5_bytes": sum(f.stat().st_size for f in files), "wall_s_incl_process_start_and_index_load": dt,
                   "reads_per_sec_end_to_end": n_lines / dt, "first_paf_line_after_s": t_first,
-                  "reads_per_sec_steady_state": steady, "steady_state_note": "second half of the PAF lines, by arrival time in the parent process",
+                  "reads_per_sec_steady_state": steady,
+                  "steady_state_note": "PAF lines after the first batch's burst / time after it (bursts = runs of lines less than 0.2 s apart)",
+                  "bursts_end_s_and_lines": [(round(t, 2), k) for t, k in bursts],
                   "fast5_reader_alone_reads_per_sec": n_read / t_reader if t_reader > 0 else None,
                   "fast5_reader_note": "Fast5Reader.pop_read over the same files on one thread, nothing else running: the ceiling of MapPool's loader thread",
                   "paf_lines": n_lines, "mapped": mapped, "rc": p.returncode,

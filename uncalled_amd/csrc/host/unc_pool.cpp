@@ -331,8 +331,8 @@ void MapPool::release(Batch &b) {
 // end a run.  The old buffer is released before the new one is the only copy only in the sense that both exist during memcpy.
 bool MapPool::grow(Batch &b, uint64_t need) {
     if (need <= b.cap) return true;
-    uint64_t cap = b.cap ? b.cap : (64ull << 20);
-    while (cap < need) cap *= 2;
+    uint64_t cap = b.cap ? 2 * b.cap : (32ull << 20);            // at least double, at least what is asked for (in 32 M-sample steps)
+    if (cap < need) cap = (need + (32ull << 20) - 1) / (32ull << 20) * (32ull << 20);
     if (cap > kBatchBytes / 2 && need <= kBatchBytes / 2) cap = kBatchBytes / 2;      // never past the byte cap of a batch
     bool pinned = true;
     int16_t *p = static_cast<int16_t *>(unc_host_alloc(cap * 2));
@@ -369,11 +369,26 @@ void MapPool::loader_main() {
         const uint32_t target = batches_staged_ == 0 ? first_batch_reads_ : batch_reads_;
         bool failed = false;
         while (b.meta.size() < target) {
+            // the GPU has nothing to do and one load of its slots is staged: hand that over now.  Batches thus grow from one
+            // load towards four as long as reading keeps ahead of mapping, and the GPU never waits for a full batch.
+            if (b.meta.size() >= first_batch_reads_ && (b.meta.size() & 255u) == 0) {
+                std::lock_guard<std::mutex> lk(mtx_);
+                if (!mapper_busy_ && staged_.empty()) break;
+            }
             if (reader_.buffered() == 0 && (reader_.empty() || reader_.fill_buffer() == 0)) break;
             // (a batch is also closed by bytes: whole reads with -c 1000000 are tens of MB each)
             if (!b.meta.empty() && (b.used + reader_.front_size() + 1) * 2 > kBatchBytes) break;
             RawRead r = reader_.pop_read();
-            if (!grow(b, b.used + r.signal.size() + 1)) {
+            // a buffer that must grow goes straight to what a FULL batch will need, also while the short first batch is being
+            // read: page-locking is slow (seconds for the 4-5 GB of a batch) and holds up the HIP calls of the mapping thread
+            // meanwhile, so both buffers reach their final size during the first two batches and never grow again
+            uint64_t need = b.used + r.signal.size() + 1;
+            if (need > b.cap && b.meta.size() >= 16) {
+                const uint64_t est = (uint64_t)((double)b.used / (double)b.meta.size() * (double)batch_reads_ * 1.1);
+                if (est > need) need = est < kBatchBytes / 2 ? est : kBatchBytes / 2;
+                if (need < b.used + r.signal.size() + 1) need = b.used + r.signal.size() + 1;
+            }
+            if (!grow(b, need)) {
                 std::cerr << "Error: out of host memory for a staging buffer (" << ((b.used + r.signal.size()) * 2 >> 20) << " MB); read " << r.id << " is dropped\n";
                 failed = true;
                 break;

@@ -2090,7 +2090,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
                 st->n_leaves = 0; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
-                if constexpr (PROF) { if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; } }
+                if constexpr (PROF) {
+                    if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; }
+                    else if (resume) { for (int i = 0; i < 12; ++i) st->cyc[i] = (fresh ? 0ull : st->cyc[i]) + s_cyc[i]; }   // chunked mode: summed over a read's launches
+                }
             }
             if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
             if (!sliced) break;

@@ -1172,10 +1172,21 @@ struct unc_rt {
     std::vector<RtHostChan> chans;
     std::vector<SlotState> h_state;
     std::vector<unc_evt_info_t> h_info;
+    // dev: UNC_RT_PROFILE=1 launches the cycle-counting instantiation of k_map and prints the phase shares of all finished reads on free
+    bool profile = false;
+    uint64_t cyc_sum[12] = {0};
 };
 
 extern "C" void unc_rt_free(unc_rt_t *rt) {
     if (!rt) return;
+    if (rt->profile) {
+        static const char *names[12] = {"probs", "extend_rest", "sort", "walk", "sources", "sa", "add_seed", "rest", "e1_parents", "e2_fm", "e3_slots", "e4_children"};
+        double tot = 0;
+        for (uint64_t c : rt->cyc_sum) tot += (double)c;
+        fprintf(stderr, "UNC_RT_PROFILE phase cycle shares of the finished reads:");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.3f", names[i], tot > 0 ? (double)rt->cyc_sum[i] / tot : 0.0);
+        fprintf(stderr, "\n");
+    }
     (void)hipSetDevice(rt->ix->device);
     free_pool(rt->pool);
     void *ptrs[] = {rt->sc.base,
@@ -1199,6 +1210,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     unc_rt *rt = new unc_rt();
     struct Guard { unc_rt *p; ~Guard() { if (p) unc_rt_free(p); } } guard{rt};
     rt->ix = ix; rt->P = *p; rt->n_channels = n_channels;
+    { const char *e = getenv("UNC_RT_PROFILE"); rt->profile = e && e[0] == '1'; }
     const size_t S = n_channels;
     size_t bytes = 0;
     {
@@ -1335,7 +1347,8 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
         rd.means = rt->d_ring; rd.moff = rt->d_moff; rd.info = rt->d_info; rd.n_reads = n_act;
         rd.tgt_mean = rt->ix->model_mean; rd.tgt_stdv = rt->ix->model_stdv;
         rd.ring0 = rt->d_ring0; rd.new_read = rt->d_newread; rd.ring_mod = NORM_LEN;
-        launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st, rt->pool);
+        launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st, rt->pool, nullptr, nullptr, nullptr,
+                   rt->profile);
         HIPCHK(hipEventRecord(rt->ev[2], st));
         HIPCHK(hipGetLastError());
         rt->h_info.resize(n_act);
@@ -1390,6 +1403,7 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
             results[i].state = UNC_RT_MAPPING;
             rt_unmapped(rt, hc, s, &inf, &results[i].hit);                  // progress so far (event_i, counters)
         }
+        if (rt->profile && hc.state == 0) for (int k = 0; k < 12; ++k) rt->cyc_sum[k] += s.cyc[k];
     }
     if (worst) return fail(worst, "device scratch overflow on at least one channel (see hit.status)");
     return UNC_OK;
