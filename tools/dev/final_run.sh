@@ -1,6 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): the measurements that go into profiles/ (round 3).  Usage: tools/dev/final_run.sh [stage ...]
 #   tests    pytest -m gpu (everything, grch38 included)
+#   smoke    __graft_entry__.smoke()
 #   pmc      counters of the SHIPPED k_map on the bench's own batch (50 k E. coli reads), one rocprofv3 pass per group:
 #            SQ wave-cycle shares (a), instruction mix (b), SQ_INSTS (d), FETCH_SIZE / WRITE_SIZE (f, w) and their known-byte
 #            calibration kernels (cf, cw) -> gpurun_out/final/pmc/{summary,pmc_k_map}.json, copied to profiles/r03_* so that
@@ -9,11 +10,13 @@
 #   stats    the E. coli headline under rocprofv3 --kernel-trace --stats
 #   e2e      python -m uncalled_amd map on multi-fast5 files (end to end: HDF5 -> staging -> GPU -> PAF text)
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
-STAGES=${@:-tests pmc bench stats}   # pmc before bench: the bench line reads `traffic` / `issue` from the summaries the pmc stage writes
+STAGES=${@:-tests smoke pmc bench stats}   # pmc before bench: the bench line reads `traffic` / `issue` from the summaries the pmc stage writes
 for s in $STAGES; do
 case $s in
 tests)
   (timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log); tail -3 $OUT/pytest_gpu.log ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log ;;
 pmc)
   bash tools/dev/pmc_sq.sh gpurun_out/final/pmc uncalled_amd/libuncalled_hip.so 50000 a b d f w cf cw > $OUT/pmc.log 2>&1; tail -5 $OUT/pmc.log
   cp $OUT/pmc/summary.json profiles/r03_pmc_sq_summary.json; cp $OUT/pmc/pmc_k_map.json profiles/r03_pmc_k_map.json
