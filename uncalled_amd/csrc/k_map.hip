@@ -2079,7 +2079,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
             g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
         }
-        if (done && !resume) tracker_release(T, tracker_mem(A, sb), lane);   // batch mode: the leaves go back to the pool at once
+        // the read is decided: its nodes go back to the pool at once -- in batch mode and in chunked (realtime) mode, where an idle
+        // channel would otherwise pin them until its next read arrives; the step-wise trace (resume without a ring) keeps them
+        // readable for unc_trace_clusters
+        if (done && (!resume || A->rd.ring_mod)) tracker_release(T, tracker_mem(A, sb), lane);
         if (resume || !done) {
             if (lane == 0) {
                 st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;

@@ -1217,8 +1217,13 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
         int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes, ix->dev.n_buckets);
         if (rc) return rc;
         HIPCHK(hipMemset(rt->sc.base, 0, bytes));
-        // 16 chunks (about 50 000 clusters) per channel on average; a read that finds the pool dry fails with its status set
-        rc = alloc_pool(rt->pool, (uint32_t)std::max<size_t>(64, S * 16), &bytes);
+        // the channels' node pool: 16 chunks (12 288 nodes) per channel on average, 64 on references of 2^26 rows and more (a read
+        // there touches tens of thousands of buckets); UNC_RT_POOL_CHUNKS overrides.  A channel's chunks go back when its read is
+        // decided; a read that finds the pool dry fails with its status set (there is no second pass in chunked mode).
+        size_t per_ch = ix->seq_len >= (1ull << 26) ? 64 : 16;
+        size_t n_chunks = S * per_ch;
+        if (const char *e = getenv("UNC_RT_POOL_CHUNKS")) { const long v = atol(e); if (v > 0) n_chunks = (size_t)v; }
+        rc = alloc_pool(rt->pool, (uint32_t)std::max<size_t>(64, n_chunks), &bytes);
         if (rc) return rc;
     }
 #define RALLOC(ptr, type, count)                                   \
