@@ -32,4 +32,5 @@ e2e)
 esac
 done
 find $OUT -name "*_kernel_trace.csv" -size +3M -delete   # keep the merge-back small: the stats / counter files carry what is needed
-ls -la $OUT | head -40
+find $ROOT/gpurun_out -type f -size +6M -delete          # gpurun merges back at most 64 MiB and drops EVERYTHING beyond that
+du -sh $ROOT/gpurun_out; ls -la $OUT | head -40

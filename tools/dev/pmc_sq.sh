@@ -33,4 +33,9 @@ done
 cd $ROOT
 python tools/dev/summarise_sq.py $OUT $READS
 if [ -d $OUT/f ] && [ -d $OUT/w ]; then python tools/dev/summarise_pmc.py $OUT $OUT/pmc_k_map.json $READS ecoli f w cf cw | tail -12; fi
-find $OUT -name "*_kernel_trace.csv" -size +3M -delete      # (after the summaries: they take the durations from these)
+# (after the summaries, which take counters and durations from these files:) what goes home is k_map's and the calibration kernels'
+# rows only -- the complete CSVs of seven passes are more than gpurun merges back
+for f in $(find $OUT -name "*_counter_collection.csv" -o -name "*_kernel_trace.csv"); do
+  (head -1 $f; grep -E "k_map|k_calib" $f) > ${f%.csv}_k_map_rows.csv; rm -f $f
+done
+find $OUT -type f -size +4M -delete
