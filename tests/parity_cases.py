@@ -123,9 +123,9 @@ def case_synthetic_batch(lib, oracle_lib, example, goldens, max_paths, n_reads):
                 assert int(hits[i][name]) == int(goldens["sim_hits"][i][f[name]]), (i, name)
 
 
-def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens):
+def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens, dev_index=None):
     """Path buffer (order, ranges, k-mers, prob-sum windows, flags) and the seed-cluster set after every map_next."""
-    dev_index = _index(lib, example)
+    dev_index = dev_index or _index(lib, example)
     raw = example["signal"][:6000]
     cal = capi.make_calib(1, example["range"], example["offset"], example["digitisation"])
     m = capi.Mapper(dev_index, n_slots=1)
@@ -151,6 +151,23 @@ def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens):
     assert steps > 100
     dh, oh = m.trace_finish(), om.trace_finish()
     assert_hits_equal([dh], [oh], "trace")
+
+
+def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4):
+    """The seed-cluster grid with buckets of 2^shift rows instead of 2^12: on the 20 k-row example index a seed's window then
+    spans hundreds of buckets (add_seed's gather runs in several rounds of WIN_BUCKETS), clusters move from bucket to bucket as
+    they grow, and every bucket holds a cluster or none -- per event against the oracle's set, then a batch."""
+    monkeypatch.setenv("UNC_BUCKET_SHIFT", str(shift))
+    ix = capi.Index(example["prefix"], lib=lib)
+    monkeypatch.delenv("UNC_BUCKET_SHIFT", raising=False)
+    case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens, dev_index=ix)
+    oix = oracle_lib.Index(example["prefix"])
+    n = 8
+    off = goldens["sim_offsets"][:n + 1].copy()
+    raw = goldens["sim_signal"][:int(off[n])]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    hits = capi.Mapper(ix, n_slots=3).map_batch(raw, off, cal)
+    assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "narrow buckets")
 
 
 def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, n_reads=9, max_chunks=None, long_read=False):

@@ -53,6 +53,11 @@ def test_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens):
     pc.case_cluster_overflow_remap(hip_lib, oracle_lib, example, goldens)
 
 
+@pytest.mark.parametrize("shift", [4, 8])
+def test_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shift):
+    pc.case_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shift)
+
+
 def test_wide_sort_keys(hip_lib, oracle_lib, example, goldens, monkeypatch):
     pc.case_wide_sort_keys(hip_lib, oracle_lib, example, goldens, monkeypatch)
 

@@ -42,6 +42,11 @@ def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
 
+@pytest.mark.parametrize("shift", [4, 8])
+def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift):
+    pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
+
+
 def test_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens):
     pc.case_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens)
 

@@ -329,6 +329,9 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         uint32_t bits = 1;
         while ((n >> bits) != 0) ++bits;
         uint32_t shift = bits > 15 + BUCKET_SHIFT_MIN ? bits - 15 : BUCKET_SHIFT_MIN;
+        // UNC_BUCKET_SHIFT (tests): narrower buckets, so that the small test references have windows of many buckets
+        // (several gathers per seed) and clusters that move between buckets
+        if (const char *e = getenv("UNC_BUCKET_SHIFT")) { const long v = atol(e); if (v >= 2 && v <= 30 && (n >> v) < (1ull << 22)) shift = (uint32_t)v; }
         ix->dev.bucket_shift = shift;
         ix->dev.n_buckets = (uint32_t)(n >> shift) + 2u;
     }
