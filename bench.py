@@ -415,7 +415,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                                                    "the PAF `mt` tag; reads share wavefronts in time slices of 1024 events, so this is not service time)"},
                        "k_map_code_object": mapper.kernel_info(),
                        "remapped_reads": {"n": remap_n, "ms": round(remap_ms, 1),
-                                          "note": "reads that found the seed-cluster leaf pool dry, mapped again after the batch (inside the step)"},
+                                          "note": "reads that found the seed-cluster node pool dry, mapped again after the batch (inside the step)"},
                        "reads_in_flight": mapper.geometry(),
                        "index_seq_len": int(ix.size), "index_device_bytes": int(ix.device_bytes())},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -546,7 +546,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None,
                     help="reads per GPU per step of the headline workload (default: 50 000 = BASELINE config 2; UNC_BENCH_READS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pool-chunks", type=int, default=0, help="chunks of the seed-cluster leaf pool (0 = library default)")
+    ap.add_argument("--pool-chunks", type=int, default=0, help="chunks of the seed-cluster node pool (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed passes (PCIe-inclusive rate, phase cycle shares)")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "grch38", "realtime", "example"], default="ecoli",
                     help="headline workload (the driver runs the default: BASELINE config 2)")

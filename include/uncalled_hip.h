@@ -160,18 +160,19 @@ int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sampl
  * body of MapPool::MapperThread::run (map_pool.cpp:130-158), for a whole batch of reads. */
 typedef struct {
     uint32_t n_slots;        /* reads in flight = per-read scratch slots (0 = 4 x n_waves, memory permitting) */
-    uint32_t max_clusters;   /* seed clusters a read's leaf directory is sized for (16 bytes of scratch per 16 clusters; 0 = 2^20;
-                              * reads that outgrow it are mapped again with a 16x longer directory) */
+    uint32_t max_clusters;   /* a read's allowance of the shared node pool: max_clusters / 4 nodes (of 5 clusters; 0 = 2^20);
+                              * reads that outgrow it are mapped again with a 16x larger allowance */
     uint32_t max_seed_paths; /* seed-valid paths per event (0 = 2 * max_paths, the bound) */
     uint32_t slice_events;   /* with n_slots > n_waves a wavefront parks a read after this many events and takes the
                               * next task (a new read while a slot is free, else the longest-parked read); 0 = 1024 */
-    uint32_t n_waves;        /* resident wavefronts of the persistent k_map grid (0 = 12 per CU) */
-    uint32_t pool_chunks;    /* the seed-cluster leaves of ALL reads in flight come from one pool, a chunk of 64 leaves (192 KB, up to 4096
-                              * clusters) at a time: chunks in the pool (0 = 8 per slot, 64 per slot for references of 2^28 index rows
-                              * and more, at most half of the free HBM); a read that finds it dry is mapped again after the batch */
+    uint32_t n_waves;        /* resident wavefronts of the persistent k_map grid (0 = 16 per CU) */
+    uint32_t pool_chunks;    /* the seed-cluster nodes of ALL reads in flight come from one pool, a chunk of 192 KB (768 nodes) at a
+                              * time: chunks in the pool (0 = 8 per slot, 64 per slot for references of 2^26 index rows and more, at
+                              * most 60 % of the free HBM); k_map stops admitting reads while the pool is nearly empty, and a read
+                              * that still finds it dry is mapped again after the batch */
     uint32_t reserved_;      /* 0 */
     uint32_t events_reads_per_wave;   /* k_events: reads (lanes in use) per wavefront, 1..64 (0 = 64; measured on 50 k reads:
-                              * 64 -> 31 ms, 32 -> 42 ms, 16 -> 69 ms: the kernel is bound by instruction issue) */
+                              * 64 -> 27 ms, 32 -> 36 ms: the kernel is bound by instruction issue) */
 } unc_mapper_opts_t;
 
 int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out);
@@ -195,9 +196,9 @@ int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
  * instantiation of k_map is about 2 % slower) */
 void unc_mapper_set_profile(unc_mapper_t *m, int on);
 /* what unc_mapper_create settled on: [0] resident wavefronts, [1] reads in flight (slots), [2] events per time slice
- * (0: one read per wavefront until it is done), [3] chunks in the seed-cluster leaf pool, [4] clusters a read's leaf directory holds */
+ * (0: one read per wavefront until it is done), [3] chunks in the seed-cluster node pool, [4] max_clusters (a read's allowance x 4) */
 void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5);
-/* reads of the last batch that found the seed-cluster leaf pool dry (or their leaf directory full) and were mapped again
+/* reads of the last batch that found the seed-cluster node pool dry (or used up their own allowance) and were mapped again
  * after the batch, and the wall-clock milliseconds that took (part of the batch, not of unc_mapper_last_timing) */
 void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms);
 /* mean lifetime of the persistent wavefronts of the last batch's k_map launch / the launch duration (both from the

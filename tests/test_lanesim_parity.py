@@ -42,7 +42,7 @@ def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
 
-@pytest.mark.parametrize("shift", [4, 8])
+@pytest.mark.parametrize("shift", [4])          # (8 as well on the GPU)
 def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift):
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
@@ -62,7 +62,7 @@ def test_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slic
 
 @pytest.mark.parametrize("pool_chunks,n_waves", [(1, 1)])
 def test_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
-    pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=6)
+    pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=5)
 
 
 def test_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
@@ -86,4 +86,4 @@ def test_merge_check_and_fallback(sim_lib_norepair, oracle_lib, example, goldens
 
 
 def test_merge_walk_mid_reference(sim_lib, oracle_lib, tmp_path):
-    pc.case_mid_reference(sim_lib, oracle_lib, tmp_path)
+    pc.case_mid_reference(sim_lib, oracle_lib, tmp_path, n=2, cut=6000)          # (3 reads of 8000 samples on the GPU)

@@ -38,8 +38,8 @@ constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
 constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
 __shared__ __attribute__((aligned(16))) float s_probs[NKMER];      // match log-probs of the current event
 __shared__ uint32_t s_flags[NKMER / 32];                            // sources_added_
-// one carved buffer for the per-pass staging of phase E, reused as the merge tile of the sort, the source list of phase F and
-// the sampled directory of add_seed: with the probs table a wavefront stays under 10 KB of LDS, so that 16 fit a CU
+// one carved buffer for the per-pass staging of phase E, reused as the merge tile of the sort and the source list of phase F:
+// with the probs table a wavefront stays under 10 KB of LDS, so that 16 fit a CU
 // (phase E, 32-bit rows: FM results 2 KB | parents' rows 512 B | history 512 | last / sub / moves / meta 4 x 256 | child
 // descriptors 640 | the children's run positions 640; the candidate list shares the last two, which are written after it is dead)
 constexpr uint32_t S_E_WORDS = (CAND_MAX * 8 + 2 * WAVE * 4 + WAVE * 8 + 4 * WAVE * 4 + 2 * CHILD_MAX * 2) / 8;
@@ -58,7 +58,7 @@ struct MapArgs {
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
     DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
-    DevPool pool;               // leaves of the seed-cluster sets
+    DevPool pool;               // nodes of the seed-cluster grids
 };
 
 // ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
@@ -988,7 +988,7 @@ __device__ __forceinline__ TrackerMem tracker_mem(kargs_t A, gptr_t sb) {
     M.sb = sb; M.off_heads = A->sc.off_cl_dir; M.off_chunks = A->sc.off_cl_chunks;
     M.max_nodes = A->sc.max_clusters / 4 ? A->sc.max_clusters / 4 : 1u;
     M.n_buckets = A->ix.n_buckets; M.shift = A->ix.bucket_shift;
-    M.pool.nodes = (gptr_t)A->pool.leaves;
+    M.pool.nodes = (gptr_t)A->pool.nodes;
     M.pool.q = A->pool.q; M.pool.cells = A->pool.cells; M.pool.cap_mask = A->pool.cap_mask;
     return M;
 }
@@ -1829,7 +1829,7 @@ static __device__ __noinline__ void phase_F(kargs_t A_, gptr_t sb_, int lane) {
 }
 
 // ---------------- T + G: seeds -> SeedTracker, then the confidence test ----------------
-// SA look-ups for all seeds in parallel, then SeedTracker::add_seed in the reference's order on the pooled B+-tree;
+// SA look-ups for all seeds in parallel, then SeedTracker::add_seed in the reference's order on the bucket grid;
 // get_final / check_map_conf (seed_tracker.cpp:129-143,259-262).  Returns this lane's SA look-ups | LF steps << 32.
 template <bool PROF>
 static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane) {
@@ -2091,7 +2091,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
                 st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
-                st->n_leaves = 0; st->n_alloc = T.n_alloc;
+                st->reserved0 = 0; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
                 if constexpr (PROF) {
                     if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; }
@@ -2153,7 +2153,7 @@ void launch_sched_init(const DevSched &S, hipStream_t st) {
     const uint32_t cap = S.cap_mask + 1u;
     hipLaunchKernelGGL(k_sched_init, dim3((cap + 255) / 256), dim3(256), 0, st, S);
 }
-// every chunk of the leaf pool free
+// every chunk of the node pool free
 __global__ void k_pool_init(DevPool B) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = B.cap_mask + 1u;
     if (i < cap) {

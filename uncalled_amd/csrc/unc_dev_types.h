@@ -54,32 +54,26 @@ constexpr int KEYB_MOVES_SHIFT = 11;     // 5 bits: popcount(event_moves_)
 // A path that passed is_seed_valid (mapper.cpp:842-863): its FM rows become seeds
 struct alignas(8) SeedPath { uint64_t start; uint32_t count; uint32_t evt; uint32_t ref_len; uint32_t pad; };
 
-// SeedTracker state (seed_tracker.hpp:69-110): the std::set<SeedCluster> (ordered by ref_en_.start desc, evt_en_ desc) is a
-// two-level B+-tree per read.
-//   leaf  = up to 64 clusters in set order, values inline: 64 hot keys of 16 bytes (all the forward scan of add_seed reads:
-//           ref_en_.start, evt_en_, total_len_) followed by 64 cold parts of 32 bytes (what a merge needs on top: ref_st_,
-//           ref_en_.end, evt_st_) = 3 KB.  Leaves come from ONE pool per mapper, a chunk of 64 leaves (192 KB) at a time,
-//           through a ring of free chunk ids: a read takes what it needs -- tens of clusters on a bacterial reference,
-//           hundreds of thousands for an off-target read on a human-sized one -- and gives it back when it is done.
-//   dir   = per read, sorted: first key of every leaf + the leaf's pool index (16 bytes per leaf)
+// SeedTracker state (seed_tracker.hpp:69-110): the std::set<SeedCluster> (ordered by ref_en_.start desc, evt_en_ desc) is kept per
+// read as a GRID OF BUCKETS over ref_en_.start (k_map.hip, add_seed): unordered nodes of NODE_K clusters chained from a per-read
+// table of bucket heads.  A cluster = a hot key of 16 bytes (all the scan of add_seed reads: ref_en_.start, evt_en_, total_len_) + a
+// cold part of 32 bytes (what a merge needs on top: ref_st_, ref_en_.end, evt_st_).
+//   node  = header 16 B (count, next node + 1) | NODE_K hot keys | NODE_K cold parts, padded to a multiple of 128 bytes
+//   pool  = ONE per mapper: chunks of POOL_CHUNK_BYTES handed out through a ring of free chunk ids; a read takes what it needs --
+//           tens of nodes on a bacterial reference, tens of thousands for an off-target read on a human-sized one -- and gives
+//           it back when it is decided
 struct alignas(16) ClusterKey { uint64_t rstart; uint32_t evt_en; uint32_t total_len; };      // hot part of a cluster
 struct alignas(16) ClusterCold { uint64_t ref_st, rend; uint32_t evt_st; uint32_t pad[3]; };  // cold part
-struct alignas(16) DirEnt { uint64_t rstart; uint32_t evt_en; uint32_t leaf; };               // directory entry
-constexpr uint32_t LEAF_KEYS = 64;
-constexpr uint32_t LEAF_COLD_OFF = LEAF_KEYS * 16;
-constexpr uint32_t LEAF_BYTES = LEAF_KEYS * 16 + LEAF_KEYS * 32;
-constexpr uint32_t CHUNK_LEAVES = 64;
-// the seed-cluster grid of k_map (add_seed): a pool chunk (CHUNK_LEAVES * LEAF_BYTES bytes) is cut into nodes of NODE_K clusters:
-// header 16 B (count, next + 1) | NODE_K hot keys of 16 B | NODE_K cold parts of 32 B
+constexpr uint32_t POOL_CHUNK_BYTES = 192u << 10;      // 768 nodes of 256 bytes
 #ifndef UNC_NODE_K
 #define UNC_NODE_K 5
 #endif
 constexpr uint32_t NODE_K = UNC_NODE_K;
 constexpr uint32_t NODE_BYTES = (16 + NODE_K * 48 + 127) / 128 * 128;      // 256 (384 for 7 clusters, 512 for 10)
-constexpr uint32_t CHUNK_NODES = CHUNK_LEAVES * LEAF_BYTES / NODE_BYTES;
+constexpr uint32_t CHUNK_NODES = POOL_CHUNK_BYTES / NODE_BYTES;
 constexpr uint32_t WIN_BUCKETS = 64 / NODE_K;          // buckets whose nodes one wavefront looks at together (12 x 5 = 60 lanes)
 constexpr uint32_t BUCKET_SHIFT_MIN = WIN_BUCKETS >= 9 ? 12 : WIN_BUCKETS >= 5 ? 13 : 14;   // a window of 2^15 rows fits WIN_BUCKETS
-static_assert(CHUNK_NODES * NODE_BYTES == CHUNK_LEAVES * LEAF_BYTES, "node layout");
+static_assert(CHUNK_NODES * NODE_BYTES == POOL_CHUNK_BYTES, "node layout");
 
 struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
 
@@ -91,7 +85,7 @@ struct alignas(16) SlotState {
     uint32_t cur;            // which of the two path buffers holds the parents
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
-    uint32_t n_clusters, n_lens, len_max1, len_max2, n_leaves, n_alloc;   // n_alloc: leaves taken from the read's own chunks so far
+    uint32_t n_clusters, n_lens, len_max1, len_max2, reserved0, n_alloc;  // n_alloc: nodes taken from the read's own chunks so far
     uint32_t n_surv;         // the first n_surv parents are the last walk's survivors, in sorted order (sources follow)
     uint32_t pad_[1];
     float len_sum;
@@ -113,10 +107,9 @@ struct alignas(64) SchedCtl {
     uint32_t next_read, pad0[15];
     SchedQueue freeq, parkq;
 };
-// The leaf pool of the seed-cluster sets (see ClusterKey): chunk ids travel through a ring like the scheduler's.
+// The node pool of the seed-cluster grids (see ClusterKey): chunk ids travel through a ring like the scheduler's.
 struct DevPool {
-    char *leaves;               // [n_chunks * CHUNK_LEAVES][LEAF_BYTES]
-    uint32_t *cnt;              // [n_chunks * CHUNK_LEAVES] clusters per leaf
+    char *nodes;                // [n_chunks][POOL_CHUNK_BYTES]
     SchedQueue *q;
     SchedCell *cells;
     uint32_t cap_mask, n_chunks;

@@ -458,8 +458,8 @@ struct unc_mapper {
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     float wall_khz = 0;            // device wall clock rate (ticks per ms)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
-    DevPool pool{};                // leaves of the seed-cluster sets, shared by every read in flight
-    DevScratch big{};              // scratch with a longer leaf directory for the reads that outgrew a slot's (kept between batches)
+    DevPool pool{};                // nodes of the seed-cluster grids, shared by every read in flight
+    DevScratch big{};              // scratch with a larger node allowance for the reads that outgrew a slot's (kept between batches)
     uint64_t big_cap = 0;
     size_t big_slots = 0;
     bool big_at_limit = false;     // big_slots is all the free HBM allowed
@@ -537,7 +537,7 @@ static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, 
 }
 
 static void free_pool(DevPool &p) {
-    void *ptrs[] = {p.leaves, p.cnt, p.q, p.cells};
+    void *ptrs[] = {p.nodes, p.q, p.cells};
     for (void *x : ptrs) if (x) (void)hipFree(x);
     memset(&p, 0, sizeof p);
 }
@@ -547,15 +547,13 @@ static int alloc_pool(DevPool &p, uint32_t n_chunks, size_t *bytes_out) {
     uint32_t cap = 64;
     while (cap < n_chunks) cap <<= 1;
     p.cap_mask = cap - 1; p.n_chunks = n_chunks;
-    const size_t n_leaves = (size_t)n_chunks * CHUNK_LEAVES;
-    HIPCHK(hipMalloc((void **)&p.leaves, n_leaves * LEAF_BYTES));
-    HIPCHK(hipMalloc((void **)&p.cnt, n_leaves * 4));
+    HIPCHK(hipMalloc((void **)&p.nodes, (size_t)n_chunks * POOL_CHUNK_BYTES));
     HIPCHK(hipMalloc((void **)&p.q, sizeof(SchedQueue)));
     HIPCHK(hipMalloc((void **)&p.cells, (size_t)cap * sizeof(SchedCell)));
     launch_pool_init(p, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    if (bytes_out) *bytes_out += n_leaves * (LEAF_BYTES + 4) + (size_t)cap * sizeof(SchedCell);
+    if (bytes_out) *bytes_out += (size_t)n_chunks * POOL_CHUNK_BYTES + (size_t)cap * sizeof(SchedCell);
     return UNC_OK;
 }
 
@@ -618,8 +616,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     size_t bytes = 0;
     // every seed of an event is either an ended parent or a surviving child: 2 * max_paths bounds the per-event list
     const uint32_t msp = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
-    // per read: the directory of its seed-cluster leaves (16 bytes per leaf, 2^20 clusters by default); the leaves themselves
-    // come from the pool below
+    // per read: the table of bucket heads of its seed-cluster grid and the list of its pool chunks; max_clusters / 4 is the number
+    // of nodes a read may take from the pool below (its allowance)
     const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
     int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes, ix->dev.n_buckets);
     if (rc_) return rc_;
@@ -633,7 +631,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         if (n_chunks == 0) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
-            const size_t chunk_bytes = (size_t)CHUNK_LEAVES * (LEAF_BYTES + 4);
+            const size_t chunk_bytes = POOL_CHUNK_BYTES;
             const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 26) ? 64 : 8);
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
         }
@@ -1093,7 +1091,7 @@ extern "C" int unc_trace_clusters(unc_mapper_t *m, unc_cluster_t *out, uint32_t 
     for (uint32_t c = 0; c < n_chunks; ++c) {
         std::vector<char> &buf = chunks[chunk_ids[c]];
         buf.resize((size_t)CHUNK_NODES * NODE_BYTES);
-        HIPCHK(hipMemcpy(buf.data(), m->pool.leaves + (size_t)chunk_ids[c] * CHUNK_NODES * NODE_BYTES, buf.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(buf.data(), m->pool.nodes + (size_t)chunk_ids[c] * POOL_CHUNK_BYTES, buf.size(), hipMemcpyDeviceToHost));
     }
     std::vector<unc_cluster_t> all;
     for (uint32_t b = 0; b < n_buckets; ++b) {
@@ -1158,7 +1156,7 @@ struct unc_rt {
     unc_params_t P;
     uint32_t n_channels = 0;
     DevScratch sc;
-    DevPool pool{};               // leaves of the channels' seed-cluster sets (a channel keeps its chunks until its next read)
+    DevPool pool{};               // nodes of the channels' seed-cluster grids (a channel keeps its chunks until its read is decided)
     RtChan *d_chans = nullptr;
     float *d_ring = nullptr;
     RtChunkDesc *d_desc = nullptr;

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
 #define UNC_AS_GLOBAL __attribute__((address_space(1)))
 #define UNC_AS_CONST __attribute__((address_space(4)))
 #endif
-typedef UNC_AS_GLOBAL char *gptr_t;            // global memory (a read's scratch slot, the leaf pool)
+typedef UNC_AS_GLOBAL char *gptr_t;            // global memory (a read's scratch slot, the node pool)
 typedef const UNC_AS_GLOBAL char *cgptr_t;
 
 // Global access as (uniform base, 32-bit byte offset): lets the compiler address with an SGPR base plus one VGPR
