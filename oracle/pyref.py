@@ -99,6 +99,14 @@ def set_max_paths(n):
     lib().ref_set_max_paths(n)
 
 
+def set_params(p):
+    """Mapper::PRMS from a pyoracle.Params / capi.Params (same field names), for Mappers constructed afterwards"""
+    f = lib().ref_set_params
+    f.argtypes = [C.c_uint32] * 5 + [C.c_float] * 7 + [C.c_uint32, C.c_float, C.c_float]
+    f(p.min_rep_len, p.max_rep_copy, p.max_paths, p.max_consec_stay, p.max_events, p.max_stay_frac, p.min_seed_prob,
+      p.threshold1, p.threshold2, p.peak_height, p.min_mean, p.max_mean, p.min_map_len, p.min_mean_conf, p.min_top_conf)
+
+
 def calibrate(raw_i16, rng, offset, digitisation):
     raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
     out = np.empty(raw.size, dtype=np.float32)

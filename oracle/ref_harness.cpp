@@ -75,6 +75,16 @@ int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events
 }
 
 void ref_set_max_paths(uint32_t max_paths) { Mapper::PRMS.max_paths = max_paths; }
+void ref_set_params(uint32_t min_rep_len, uint32_t max_rep_copy, uint32_t max_paths, uint32_t max_consec_stay, uint32_t max_events,
+                    float max_stay_frac, float min_seed_prob, float threshold1, float threshold2, float peak_height,
+                    float min_mean, float max_mean, uint32_t min_map_len, float min_mean_conf, float min_top_conf) {
+    auto &P = Mapper::PRMS;
+    P.min_rep_len = min_rep_len; P.max_rep_copy = max_rep_copy; P.max_paths = max_paths; P.max_consec_stay = max_consec_stay;
+    P.max_events = max_events; P.max_stay_frac = max_stay_frac; P.min_seed_prob = min_seed_prob;
+    P.event_prms.threshold1 = threshold1; P.event_prms.threshold2 = threshold2; P.event_prms.peak_height = peak_height;
+    P.event_prms.min_mean = min_mean; P.event_prms.max_mean = max_mean;
+    P.seed_prms.min_map_len = min_map_len; P.seed_prms.min_mean_conf = min_mean_conf; P.seed_prms.min_top_conf = min_top_conf;
+}
 void *ref_mapper_new(void) { return new Mapper(); }
 void ref_mapper_free(void *m) { delete static_cast<Mapper *>(m); }
 

@@ -44,6 +44,11 @@ typedef struct {
 int ref_init(const char *bwa_prefix, const char *idx_preset, uint32_t max_events);
 /* Mapper::PRMS.max_paths for Mappers constructed afterwards (mapper.cpp:33,83-86) */
 void ref_set_max_paths(uint32_t max_paths);
+/* The mapping, event-detector and seed-tracker parameters of Mapper::PRMS (mapper.hpp:49-72, event_detector.hpp Params,
+ * seed_tracker.hpp:75-79) for Mappers constructed afterwards; v = the 15 values in the order of the arguments' names */
+void ref_set_params(uint32_t min_rep_len, uint32_t max_rep_copy, uint32_t max_paths, uint32_t max_consec_stay, uint32_t max_events,
+                    float max_stay_frac, float min_seed_prob, float threshold1, float threshold2, float peak_height,
+                    float min_mean, float max_mean, uint32_t min_map_len, float min_mean_conf, float min_top_conf);
 void *ref_mapper_new(void);
 void ref_mapper_free(void *m);
 

@@ -153,6 +153,39 @@ def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens, dev
     assert_hits_equal([dh], [oh], "trace")
 
 
+# Parameter sets away from the reference's defaults (mapper.cpp:29-40, event_detector.cpp:17-26, seed_tracker.cpp:28-32): each
+# moves a decision the default run hardly ever takes the other way.  tests/test_oracle.py pins the oracle against the live
+# reference on every one of them; the device is compared with the oracle.
+PARAM_VARIANTS = [
+    dict(max_rep_copy=5, min_rep_len=12),                       # repeat seeds: fewer copies, only after 12 moves (mapper.cpp:858-861)
+    dict(max_consec_stay=3, max_stay_frac=0.25),                # stay children cut earlier (:470-483), stricter seed validity (:852-854)
+    dict(min_seed_prob=-3.2),                                   # fewer seed-valid paths
+    dict(max_events=350),                                       # reads that run out of events (:381-405)
+    dict(min_map_len=15, min_mean_conf=3.0, min_top_conf=1.2),  # earlier, weaker success (seed_tracker.cpp:129-143)
+    dict(threshold1=1.7, threshold2=8.0, peak_height=0.35, min_mean=55.0, max_mean=130.0),   # another segmentation, events dropped by mean
+    dict(max_paths=150, max_rep_copy=64, max_consec_stay=12),   # the max_paths cut-off with long stays and the largest repeat copy
+]
+
+
+def variant_params(base, overrides):
+    for k, v in overrides.items():
+        setattr(base, k, v)
+    return base
+
+
+def case_parameter_variants(lib, oracle_lib, example, goldens, n=6):
+    dev_index = _index(lib, example)
+    oix = oracle_lib.Index(example["prefix"])
+    off = goldens["sim_offsets"][:n + 1].copy()
+    raw = goldens["sim_signal"][:int(off[n])]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    for ov in PARAM_VARIANTS:
+        p = variant_params(capi.default_params(lib), ov)
+        hits = capi.Mapper(dev_index, params=p, n_slots=3).map_batch(raw, off, cal)
+        want = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True)
+        assert_hits_equal(hits, want, str(ov))
+
+
 def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4):
     """The seed-cluster grid with buckets of 2^shift rows instead of 2^12: on the 20 k-row example index a seed's window then
     spans hundreds of buckets (add_seed's gather runs in several rounds of WIN_BUCKETS), clusters move from bucket to bucket as

@@ -58,6 +58,10 @@ def test_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shif
     pc.case_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
 
+def test_parameter_variants(hip_lib, oracle_lib, example, goldens):
+    pc.case_parameter_variants(hip_lib, oracle_lib, example, goldens)
+
+
 def test_merge_walk_mid_reference(hip_lib, oracle_lib, tmp_path):
     pc.case_mid_reference(hip_lib, oracle_lib, tmp_path)
 

@@ -114,6 +114,35 @@ def test_simulated_reads_map_to_their_origin(goldens):
     assert ok >= 35
 
 
+def test_parameter_variants_equal_live_reference(oracle_lib, ref_lib, example, goldens):
+    """The oracle against the reference's object code on parameter sets away from the defaults (tests/parity_cases.py
+    PARAM_VARIANTS: repeat-seed limits, stay limits, seed probability, max_events, the tracker's confidence thresholds, the
+    detector's thresholds, a small max_paths with long stays) -- the sets the device is then compared with the oracle on."""
+    from tests.parity_cases import PARAM_VARIANTS, variant_params
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    ix = po.Index(example["prefix"])
+    off = goldens["sim_offsets"]
+    sigs = [goldens["ex_calibrated"]] + [
+        po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+        for i in range(8)]
+    try:
+        n_unmapped = 0
+        for ov in PARAM_VARIANTS:
+            p = variant_params(po.default_params(), ov)
+            pr.set_params(p)
+            om, rm = po.Mapper(ix, p), pr.Mapper()
+            for i, sig in enumerate(sigs):
+                h, r = om.map_read(sig), rm.map_read(sig)
+                assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), (ov, i)
+                assert (int(h["event_i"]), int(h["n_events"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == \
+                       (r.event_i, r.n_events, r.n_nbr, r.n_sa, r.n_lf), (ov, i)
+                n_unmapped += 0 if int(h["mapped"]) else 1
+        assert n_unmapped > 0          # (some variant must have changed an outcome, or the sets test nothing)
+    finally:
+        pr.set_params(po.default_params())
+
+
 @pytest.mark.parametrize("max_paths", [10000, 300])
 def test_oracle_equals_live_reference(oracle_lib, ref_lib, example, goldens, max_paths):
     """Live comparison with the reference's object code, incl. the max_paths cut-off logic (mapper.cpp:480,507,521)
