@@ -1,6 +1,8 @@
 """CPU tests of the test oracle itself: the plain-C restatement (oracle/unc_oracle.c) is pinned against
 (a) the committed goldens generated from the reference's own object code (tests/golden/make_goldens.py), and
 (b) that object code live, wherever /root/reference exists (this container)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -112,6 +114,26 @@ def test_simulated_reads_map_to_their_origin(goldens):
         assert pos - 50 <= row[f["rf_st"]] <= pos + 1500 + 50
         ok += 1
     assert ok >= 35
+
+
+def test_parameter_variants_match_golden(oracle_lib, example, goldens):
+    """The oracle on the parameter sets of PARAM_VARIANTS against tests/golden/param_variant_goldens.npz (the reference's
+    outputs, generated by tests/golden/make_param_goldens.py): runs where the reference is absent."""
+    from tests.parity_cases import PARAM_VARIANTS, variant_params
+    po = oracle_lib
+    g = np.load(Path(__file__).resolve().parent / "golden" / "param_variant_goldens.npz")
+    assert list(g["variants"]) == [repr(sorted(v.items())) for v in PARAM_VARIANTS], "regenerate the goldens: the variant list changed"
+    ix = po.Index(example["prefix"])
+    off = goldens["sim_offsets"]
+    sigs = [goldens["ex_calibrated"]] + [
+        po.calibrate(goldens["sim_signal"][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+        for i in range(8)]
+    for vi, ov in enumerate(PARAM_VARIANTS):
+        om = po.Mapper(ix, variant_params(po.default_params(), ov))
+        for i, sig in enumerate(sigs):
+            h = om.map_read(sig)
+            for f, v in _gold_hit(goldens, g["hits"][vi, i]).items():
+                assert int(h[f]) == v, (ov, i, f)
 
 
 def test_parameter_variants_equal_live_reference(oracle_lib, ref_lib, example, goldens):
