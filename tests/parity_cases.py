@@ -203,6 +203,51 @@ def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4)
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "narrow buckets")
 
 
+# chunked-path sets: (parameter overrides, chunk length in samples)
+CHUNK_VARIANTS = [
+    (dict(threshold1=1.7, threshold2=8.0, peak_height=0.35, min_mean=55.0, max_mean=130.0), 4000),
+    (dict(min_seed_prob=-3.2, max_consec_stay=3, max_stay_frac=0.25), 2000),         # half-second chunks
+    (dict(min_map_len=15, min_mean_conf=3.0, min_top_conf=1.2, max_events=350), 1000),
+]
+
+
+def case_chunked_variants(lib, oracle_lib, example, goldens, n_channels=2, n_reads=6):
+    """The chunked path on parameter sets away from the defaults and with other chunk lengths (the detector, the event
+    profiler, the rolling normaliser and the mapper all see different event streams): device vs oracle, per read."""
+    from uncalled_amd.realtime import MapPoolOrd
+    po = oracle_lib
+    dev_index = _index(lib, example)
+    oix = po.Index(example["prefix"])
+    off = goldens["sim_offsets"]
+    reads = [(example["signal"], (example["range"], example["offset"], example["digitisation"]))]
+    for i in range(n_reads - 1):
+        reads.append((goldens["sim_signal"][int(off[i]):int(off[i + 1])], (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)))
+    names = dev_index.seq_names()
+    for ov, chunk_len in CHUNK_VARIANTS:
+        p = variant_params(capi.default_params(lib), ov)
+        p.chunk_time = chunk_len / p.sample_rate
+        pool = MapPoolOrd(dev_index, n_channels=n_channels, params=p)
+        assert pool.chunk_len == chunk_len
+        oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_channels)]
+        want, got = {}, {}
+        for i, (raw, cal) in enumerate(reads):
+            pool.add_read(i % n_channels, i, raw, cal, key=i)
+            want[i] = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+        rounds = 0
+        while pool.running():
+            for key, r in pool.update():
+                got[key] = r
+            rounds += 1
+            assert rounds < 4000
+        for i in range(len(reads)):
+            h, o = got[i]["hit"], want[i]
+            assert int(h["status"]) == 0
+            assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), (ov, chunk_len, i)
+            for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+                assert int(h[f]) == int(o[f]), (ov, chunk_len, i, f)
+            assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), (ov, chunk_len, i)
+
+
 def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, n_reads=9, max_chunks=None, long_read=False):
     """Config 5's path: reads replayed chunk by chunk over a few channels (MapPoolOrd semantics) through
     unc_rt_process_chunks; per-channel state persists across chunks AND reads.  Checked against the oracle fed the

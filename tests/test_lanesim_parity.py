@@ -47,6 +47,10 @@ def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shif
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
 
+def test_chunked_variants(sim_lib, oracle_lib, example, goldens):
+    pc.case_chunked_variants(sim_lib, oracle_lib, example, goldens, n_channels=2, n_reads=4)     # 6 reads on the GPU
+
+
 def test_parameter_variants(sim_lib, oracle_lib, example, goldens):
     pc.case_parameter_variants(sim_lib, oracle_lib, example, goldens, n=4)       # 6 reads per set on the GPU
 

@@ -256,6 +256,26 @@ def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, golden
     pr.lib().ref_set_max_chunks(1000000)
 
 
+def test_chunked_path_variants_equal_live_reference(oracle_lib, ref_lib, example, goldens):
+    """The chunked path of the oracle against the reference's (Mapper::new_read(Chunk&) / add_chunk / process_chunk / map_chunk)
+    on the parameter sets and chunk lengths of tests/parity_cases.py CHUNK_VARIANTS, reads one after the other on ONE Mapper."""
+    from tests.parity_cases import CHUNK_VARIANTS, variant_params
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    ix = po.Index(example["prefix"])
+    try:
+        for ov, chunk_len in CHUNK_VARIANTS:
+            p = variant_params(po.default_params(), ov)
+            pr.set_params(p)
+            om, rm = po.Mapper(ix, p), pr.Mapper()
+            for i, sig in enumerate(_chunk_signals(po, goldens)[:8]):
+                (h, hu), (r, ru) = om.chunk_read(sig, chunk_len), rm.chunk_read(sig, chunk_len, i)
+                assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), (ov, chunk_len, i)
+                assert (hu, int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (ru, r.event_i, r.n_nbr, r.n_sa, r.n_lf), (ov, chunk_len, i)
+    finally:
+        pr.set_params(po.default_params())
+
+
 def test_edge_case_reads_equal_live_reference(oracle_lib, ref_lib, example):
     """The reads of parity_cases.case_events_edge_cases (shorter than the detector windows, flat, negative samples, every
     head / tail length of the device kernel's blocked loop) through the reference's own EventDetector / Normalizer and,
