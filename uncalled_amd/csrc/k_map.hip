@@ -2,21 +2,22 @@
 //
 // Replaces Mapper::map_next (mapper.cpp:433-663) + PathBuffer::make_child/make_source (751-807) +
 // Mapper::update_seeds (665-700) + SeedTracker::add_seed/get_final (seed_tracker.cpp:129-232) for a
-// whole batch.  One event of one read is processed as a sequence of wave-cooperative phases:
+// whole batch.  One event of one read is processed as a sequence of wave-cooperative phases, each an
+// out-of-line function:
 //
 //   P  1024 match log-probs of the normalised event (pore_model.hpp:163-165) -> LDS
 //   E  parents, 64 per pass in the reference's visiting order: thresholds -> candidate (parent,base)
 //      pairs compacted through LDS -> FM get_neighbor with every lane busy -> child slots by prefix
-//      sum (honouring the max_paths cut-off) -> one lane per child writes a 64-byte record (the
-//      parent's staged in LDS: no global read) and a 16-byte sort key
-//   S  wavefront bitonic sort of the keys in registers (global-memory network beyond 512 children)
+//      sum (honouring the max_paths cut-off) -> one lane per child writes a 32-byte record and files
+//      its 64-bit key into the stream of its class (map_sort.h)
+//   S  narrow keys: repair + merge of the streams, the last merge walked in place in LDS;
+//      wide keys (human-sized references) and small events: bitonic network
 //   W  walk in sorted order: duplicate-range pruning, per-k-mer gap sources from a segmented
 //      prefix-max, survivors -> next parent list, seed-valid survivors -> seed list
 //   F  full-range sources for k-mers not covered (sources_added_ bitmap in LDS)
-//   T  SA look-ups for all seeds in parallel (<=31 dependent LF steps each), then the SeedTracker
-//      update in the reference's order on a sorted 16-byte key array + append-only payload pool
+//   T  SA look-ups for all seeds in parallel, then the SeedTracker update in the reference's order
+//      on the bucket grid (map_tracker.h)
 //   G  confidence test (get_final / check_map_conf) -> SUCCESS, or next event
-//   M  every 4th event: the prob-sum rings of the paths still alive are brought up to date (PathRec)
 //
 // Integer/range results are bit-exact with the reference; float expressions are written one IEEE
 // operation at a time (compile with -ffp-contract=off; the reference is built without FMA).
@@ -29,864 +30,12 @@
 #include "wave_prims.h"
 
 
+#include "map_lds.h"
+#include "map_sched.h"
+#include "map_tracker.h"
+#include "map_sort.h"
+
 namespace unc {
-
-
-// ---- LDS of a wavefront (a workgroup is one wavefront): file scope, so that the phases of an event, which are separate
-// functions, all see it as LDS ----
-constexpr int CAND_MAX = 4 * WAVE;    // candidate (parent, base) pairs per pass
-constexpr int CHILD_MAX = 5 * WAVE;   // children per pass
-__shared__ __attribute__((aligned(16))) float s_probs[NKMER];      // match log-probs of the current event
-__shared__ uint32_t s_flags[NKMER / 32];                            // sources_added_
-// one carved buffer for the per-pass staging of phase E, reused as the merge tile of the sort and the source list of phase F:
-// with the probs table a wavefront stays under 10 KB of LDS, so that 16 fit a CU
-// (phase E, 32-bit rows: FM results 2 KB | parents' rows 512 B | history 512 | last / sub / moves / meta 4 x 256 | child
-// descriptors 640 | the children's run positions 640; the candidate list shares the last two, which are written after it is dead)
-constexpr uint32_t S_E_WORDS = (CAND_MAX * 8 + 2 * WAVE * 4 + WAVE * 8 + 4 * WAVE * 4 + 2 * CHILD_MAX * 2) / 8;
-__shared__ __attribute__((aligned(16))) uint64_t s_e[S_E_WORDS];
-
-struct MapArgs {
-    DevIndex ix;
-    DevScratch sc;
-    DevReads rd;
-    unc_params_t P;
-    DevResult *results;
-    uint32_t *next_read;    // work-queue head
-    uint32_t max_steps;     // map_next calls per launch (0xFFFFFFFF = run to completion)
-    uint32_t resume;        // 1: continue the read saved in SlotState (trace / chunked mode)
-    const uint32_t *read_list;  // batch mode: the queue hands out read_list[t] instead of t (re-runs of selected reads)
-    const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
-    unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
-    DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
-    DevPool pool;               // nodes of the seed-cluster grids
-};
-
-// ---- scheduler queues (lane 0 only).  Vyukov's bounded MPMC ring: cell.seq == pos: free for the push at pos;
-// == pos + 1: holds the value of that push; a pop at pos leaves pos + cap.  At most n_slots <= cap ids exist, so a push
-// never finds its cell occupied by a live value -- at worst by a pop that has not yet released it.
-constexpr uint32_t SCHED_EMPTY = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t ld_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ void sched_push(SchedQueue *q, SchedCell *cells, uint32_t mask, uint32_t v) {
-    const uint32_t pos = atomicAdd(&q->tail, 1u);
-    SchedCell *c = cells + (pos & mask);
-    while (ld_acq(&c->seq) != pos) __builtin_amdgcn_s_sleep(1);
-    c->val = v;
-    st_rel(&c->seq, pos + 1u);
-}
-
-__device__ __forceinline__ uint32_t sched_pop(SchedQueue *q, SchedCell *cells, uint32_t mask) {
-    for (;;) {
-        const uint32_t pos = ld_acq(&q->head);
-        SchedCell *c = cells + (pos & mask);
-        const int32_t dif = (int32_t)(ld_acq(&c->seq) - (pos + 1u));
-        if (dif < 0) return SCHED_EMPTY;
-        if (dif == 0 && atomicCAS(&q->head, pos, pos + 1u) == pos) {
-            const uint32_t v = c->val;
-            st_rel(&c->seq, pos + mask + 1u);
-            return v;
-        }
-    }
-}
-
-struct Tracker {
-    uint32_t n, n_lens, max1, max2, status, n_alloc;      // n_alloc: nodes taken from the read's own chunks so far
-    float len_sum;
-    ClusterVal mm;
-};
-
-// SeedTracker's std::set<SeedCluster> (ordered by ref_en_.start descending, evt_en_ descending) as a GRID OF BUCKETS over
-// ref_en_.start.  add_seed only ever looks at the clusters whose start lies in [seed start - seed event, seed start]: from
-// lower_bound(seed) the reference scans towards smaller starts, takes the best-supported cluster the seed can extend, and stops
-// at the first cluster that lies more than `event` rows back (seed_tracker.cpp:169-191: in_range needs r2 - r1 <= e2 - e1 <=
-// e2, a cluster further back is never a candidate and ends the scan).  Inside that window the scan's outcome does not depend
-// on any order but the set's own tie-break (among equally long candidates the first in set order), so a bucket is an UNORDERED
-// array: nodes of NODE_K = 5 clusters (hot key 16 B + cold part 32 B each, 256 B) chained from a per-read table of bucket heads.  A seed
-// costs the heads of its window's buckets (one coalesced load), their nodes (one load, one lane per cluster) and a store;
-// insert = append, erase = move the node's last cluster into the hole.  No directory, nothing to shift, nothing to split.
-// The bucket width (DevIndex::bucket_shift) is set per index: at least 2^12 rows (a window of the default max_events spans at
-// most 9 buckets; 12 are gathered at once) and at most 2^15 buckets per read (a bucket costs a node of 256 bytes once it is used).  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
-// directory search, leaf load and leaf shift were three to five dependent memory round trips per seed.)
-constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;      // (NODE_K = 5 clusters in 256 bytes: unc_dev_types.h)
-constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
-struct alignas(16) NodeHdr { uint32_t count, next, pad0, pad1; };            // next: node id + 1 (0: end of the chain)
-static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES && WIN_BUCKETS * NODE_K <= WAVE, "node layout");
-static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32, "seed-cluster record layout");
-struct PoolView {          // DevPool with its arrays typed as global memory
-    gptr_t nodes;
-    SchedQueue *q;
-    SchedCell *cells;
-    uint32_t cap_mask;
-};
-struct TrackerMem {
-    gptr_t sb;             // the read's slot: bucket heads and chunk list live there
-    uint32_t off_heads;    // u32 [n_buckets]: first node of the bucket + 1 (0: empty)
-    uint32_t off_chunks;   // u32 [max_nodes / CHUNK_NODES + 1]
-    uint32_t max_nodes;
-    uint32_t n_buckets, shift;
-    PoolView pool;         // nodes
-};
-
-// A fresh node for this read: the next one of its newest chunk, or the first of a chunk popped off the pool's ring.
-// NODE_NONE when the read has used up its allowance or the pool has run dry (the read then overflows and is mapped again later).
-__device__ __forceinline__ uint32_t tracker_new_node(Tracker &T, const TrackerMem &M, int lane) {
-    const uint32_t a = T.n_alloc;
-    if (a >= M.max_nodes) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return NODE_NONE; }
-    uint32_t chunk;
-    if (a % CHUNK_NODES == 0) {
-        uint32_t c = SCHED_EMPTY;
-        if (lane == 0) {
-            c = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
-            if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2), c);
-        }
-        chunk = bcast32(c, 0);
-        if (chunk == SCHED_EMPTY) { T.status |= UNC_READ_CLUSTER_OVERFLOW | UNC_READ_POOL_DRY; return NODE_NONE; }
-    } else {
-        chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2)));
-    }
-    T.n_alloc = a + 1;
-    return chunk * CHUNK_NODES + a % CHUNK_NODES;
-}
-
-// the read is over: its chunks go back to the pool
-__device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
-    const uint32_t n_chunks = (T.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
-    for (uint32_t i = (uint32_t)lane; i < n_chunks; i += WAVE)
-        sched_push(M.pool.q, M.pool.cells, M.pool.cap_mask, gld<uint32_t>(M.sb, M.off_chunks + (i << 2)));
-    T.n_alloc = 0; T.n = 0;
-    wave_sync();
-}
-// a read starts with every bucket empty
-__device__ __forceinline__ void tracker_clear_heads(const TrackerMem &M, int lane) {
-    const uint32_t n16 = (M.n_buckets + 3) / 4;
-    for (uint32_t i = (uint32_t)lane; i < n16; i += WAVE) gst(M.sb, M.off_heads + (i << 4), make_uint4(0u, 0u, 0u, 0u));
-    wave_sync();
-}
-
-// std::multiset<u32> all_lens_ reduced to what get_final reads: its size and its two largest values.
-__device__ __forceinline__ void lens_insert(Tracker &T, uint32_t v) {
-    T.n_lens++;
-    if (v > T.max1) { T.max2 = T.max1; T.max1 = v; }
-    else if (v > T.max2) T.max2 = v;
-}
-// replace one instance of p by q > p (seed_tracker.cpp:201-203)
-__device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q) {
-    if (p == T.max1) { T.max1 = q; }                                   // (q, max2)
-    else if (p == T.max2) { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else T.max2 = q; }
-    else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
-}
-
-__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, d); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
-    return v;
-}
-
-// one cluster as add_seed carries it between the gather and the commit (all fields uniform)
-struct ClusterRef { uint32_t found, node, slot, cnt, next, tl, e; uint64_t r; };
-// the lane `src` holds the cluster: its fields to every lane
-__device__ __forceinline__ ClusterRef cluster_ref(uint32_t node, uint32_t slot, const NodeHdr &h, const ClusterKey &k, int src) {
-    ClusterRef c;
-    c.found = 1; c.node = bcast32(node, src); c.slot = bcast32(slot, src); c.cnt = bcast32(h.count, src); c.next = bcast32(h.next, src);
-    c.tl = bcast32(k.total_len, src); c.e = bcast32(k.evt_en, src); c.r = bcast64(k.rstart, src);
-    return c;
-}
-__device__ __forceinline__ gptr_t node_ptr(const TrackerMem &M, uint32_t node) { return M.pool.nodes + (size_t)node * NODE_BYTES; }
-__device__ __forceinline__ void node_store(const TrackerMem &M, uint32_t node, uint32_t slot, const ClusterKey &k, const ClusterCold &c) {
-    const gptr_t p = node_ptr(M, node);
-    gst(p, NODE_HOT_OFF + (slot << 4), k);
-    gst(p, NODE_COLD_OFF + (slot << 5), c);
-}
-__device__ __forceinline__ void node_hdr_store(const TrackerMem &M, uint32_t node, uint32_t count, uint32_t next) {
-    NodeHdr h; h.count = count; h.next = next; h.pad0 = 0; h.pad1 = 0;
-    gst(node_ptr(M, node), 0u, h);
-}
-
-// SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform; stores by lane 0)
-static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt, int lane) {
-    if (T.status) return;
-    const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
-    const uint32_t e2 = evt;
-
-    // ---- gather: the buckets that hold starts in [r2 - e2, r2], highest first; lane = (bucket j, slot s) of the bucket's current node
-    const uint64_t r_lo = r2 > (uint64_t)e2 ? r2 - (uint64_t)e2 : 0ull;
-    const uint32_t b_hi = (uint32_t)(r2 >> M.shift), b_lo = (uint32_t)(r_lo >> M.shift);
-    const uint32_t nb = b_hi - b_lo + 1u;                         // <= WIN_BUCKETS for max_events < 2^15 (the default is 30 000)
-    const uint32_t j = (uint32_t)lane / NODE_K, s = (uint32_t)lane % NODE_K;
-    uint32_t head0 = 0;                                           // head of the seed's own bucket
-
-    ClusterRef best; best.found = 0; best.node = best.slot = best.cnt = best.next = best.tl = best.e = 0; best.r = 0;   // best-supported candidate among the near ones
-    ClusterRef f0 = best;                                         // the cluster exactly e2 rows back with evt_en 0, if there is one
-    bool f_other = false;                                         // ... and whether another cluster sits exactly e2 rows back (it ends the scan first)
-    bool exists = false;                                          // an equivalent key (r2, e2) is in the set
-    uint64_t lb_r = 0; uint32_t lb_e = 0; bool lb_have = false;   // key at lower_bound(seed): the first in set order not before the seed
-    uint32_t ins_node = 0, ins_cnt = 0, ins_next = 0;             // a node of the seed's own bucket with room (id + 1)
-    for (uint32_t jb = 0; jb < nb; jb += WIN_BUCKETS) {
-    const bool active = j < WIN_BUCKETS && jb + j < nb;
-    uint32_t node1 = active ? gld<uint32_t>(M.sb, M.off_heads + ((b_hi - jb - j) << 2)) : 0u;      // node id + 1
-    if (jb == 0) head0 = bcast32(node1, 0);
-    while (__any(node1 != 0u)) {
-        NodeHdr h; h.count = 0; h.next = 0; h.pad0 = h.pad1 = 0;
-        ClusterKey k; k.rstart = 0; k.evt_en = 0; k.total_len = 0;
-        if (node1) {
-            const cgptr_t p = node_ptr(M, node1 - 1u);
-            h = gld<NodeHdr>(p, 0u);
-            k = gld<ClusterKey>(p, NODE_HOT_OFF + (s << 4));
-        }
-        const bool valid = node1 != 0u && s < h.count;
-        const uint64_t r1 = k.rstart;
-        const uint32_t e1 = k.evt_en, tl = k.total_len;
-        // not before the seed in set order, and not further back than e2 rows
-        const bool in_win = valid && r1 <= r2 && !(r1 == r2 && e1 > e2) && (r2 - r1) <= (uint64_t)e2;
-        const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
-        const bool in_range = in_win && e1 <= e2 && dr <= de && dr >= de / 12;       // :178-181
-        const bool farE = in_win && dr == (uint64_t)e2;                              // r2 - r1 >= e2: a non-candidate here ends the scan
-        if (__any(valid && r1 == r2 && e1 == e2)) exists = true;
-        // a node of the seed's own bucket with a free slot
-        if (!ins_node) {
-            const uint64_t m = __ballot(jb == 0 && j == 0 && s == 0 && node1 != 0u && h.count < NODE_K);
-            if (m) { ins_node = bcast32(node1, 0); ins_cnt = bcast32(h.count, 0); ins_next = bcast32(h.next, 0); }
-        }
-        // lower bound: the largest (r1, e1) in the window
-        {
-            const uint64_t mr = wave_max64(in_win ? r1 + 1ull : 0ull);               // (+1: a start of 0 still counts)
-            if (mr) {
-                const uint32_t me = wave_max32(in_win && r1 + 1ull == mr ? e1 + 1u : 0u);
-                if (!lb_have || mr - 1ull > lb_r || (mr - 1ull == lb_r && me - 1u > lb_e)) { lb_r = mr - 1ull; lb_e = me - 1u; }
-                lb_have = true;
-            }
-        }
-        // near candidates: the longest wins, among equally long ones the first in set order = the largest (r1, e1)
-        {
-            const bool cand = in_range && !farE;
-            const uint64_t cm = __ballot(cand);
-            if (cm) {
-                const uint32_t m_tl = wave_max32(cand ? tl + 1u : 0u) - 1u;
-                const bool s1 = cand && tl == m_tl;
-                const uint64_t m_r = wave_max64(s1 ? r1 + 1ull : 0ull) - 1ull;
-                const bool s2 = s1 && r1 == m_r;
-                const uint32_t m_e = wave_max32(s2 ? e1 + 1u : 0u) - 1u;
-                const uint64_t wm = __ballot(s2 && e1 == m_e);
-                const int src = __ffsll((unsigned long long)wm) - 1;
-                const bool better = !best.found || m_tl > best.tl || (m_tl == best.tl && (m_r > best.r || (m_r == best.r && m_e > best.e)));
-                if (better) best = cluster_ref(node1 - 1u, s, h, k, src);
-            }
-        }
-        // clusters exactly e2 rows back
-        {
-            if (__any(farE && e1 > 0u)) f_other = true;
-            const uint64_t fm = __ballot(farE && e1 == 0u);
-            if (fm) f0 = cluster_ref(node1 - 1u, s, h, k, __ffsll((unsigned long long)fm) - 1);
-        }
-        node1 = node1 ? h.next : 0u;          // on along the chains
-    }
-    }
-    // the scan reaches the clusters e2 rows back after all nearer ones, in order of descending evt_en: any of them with evt_en > 0
-    // is out of range and ends it; the one with evt_en 0 is in range (r2 - r1 = e2 - e1) and is taken when it is longer
-    ClusterRef mt = best;
-    if (f0.found && !f_other && (!best.found || f0.tl > best.tl)) mt = f0;
-
-    // where a new key goes: a free slot of the seed's own bucket, or a fresh node at its head
-    auto insert_key = [&](const ClusterKey &nk, const ClusterCold &nc) -> bool {
-        if (ins_node) {
-            if (lane == 0) { node_store(M, ins_node - 1u, ins_cnt, nk, nc); node_hdr_store(M, ins_node - 1u, ins_cnt + 1u, ins_next); }
-        } else {
-            const uint32_t id = tracker_new_node(T, M, lane);
-            if (id == NODE_NONE) return false;
-            if (lane == 0) {
-                node_store(M, id, 0u, nk, nc); node_hdr_store(M, id, 1u, head0);
-                gst(M.sb, M.off_heads + (b_hi << 2), id + 1u);
-            }
-        }
-        return true;
-    };
-    // take the cluster c out of its node: the node's last cluster moves into the hole
-    auto erase_ref = [&](const ClusterRef &c) {
-        const uint32_t last = c.cnt - 1u;
-        if (c.slot != last) {
-            const cgptr_t p = node_ptr(M, c.node);
-            const ClusterKey lk = gld<ClusterKey>(p, NODE_HOT_OFF + (last << 4));
-            const ClusterCold lc = gld<ClusterCold>(p, NODE_COLD_OFF + (last << 5));
-            wave_sync();
-            if (lane == 0) node_store(M, c.node, c.slot, lk, lc);
-        }
-        if (lane == 0) node_hdr_store(M, c.node, last, c.next);
-    };
-
-    if (mt.found) {
-        const ClusterCold mp = gld<ClusterCold>(node_ptr(M, mt.node), NODE_COLD_OFF + (mt.slot << 5));
-        ClusterVal a;
-        a.ref_st = mp.ref_st; a.rstart = mt.r; a.rend = mp.rend;
-        a.evt_st = mp.evt_st; a.evt_en = mt.e; a.total_len = mt.tl;
-        const uint32_t prev_len = a.total_len;
-        // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
-        uint8_t growth = 0;
-        if (r2 < a.rend) {
-            if (ref_en > a.rend) { growth = (uint8_t)(ref_en - a.rend); a.rend = ref_en; }
-            a.rstart = r2;
-        } else {
-            growth = (uint8_t)ref_len;
-            a.rstart = r2;
-            a.rend = ref_en;
-        }
-        a.evt_en = e2;
-        a.total_len += growth;
-        if (a.total_len != prev_len) {
-            T.len_sum = __fadd_rn(T.len_sum, (float)(a.total_len - prev_len));
-            lens_replace(T, prev_len, a.total_len);
-            if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
-        }
-        // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2).  The insert collides -- and the cluster is
-        // dropped -- when that key is already in the set and is not the matched cluster itself (which then sits at the lower bound)
-        ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = a.total_len;
-        ClusterCold nc; nc.ref_st = a.ref_st; nc.rend = a.rend; nc.evt_st = a.evt_st; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
-        const bool is_lb = lb_have && mt.r == lb_r && mt.e == lb_e;
-        wave_sync();
-        if (!is_lb && exists) {
-            erase_ref(mt);
-            T.n--;
-        } else if ((uint32_t)(mt.r >> M.shift) == b_hi) {
-            if (lane == 0) node_store(M, mt.node, mt.slot, nk, nc);      // same bucket: the cluster stays where it is
-        } else {
-            erase_ref(mt);                                               // its start moved into the seed's bucket
-            wave_sync();
-            // (the node found for inserting is not the one just shrunk: that one belongs to another bucket)
-            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
-        }
-        wave_sync();
-    } else {
-        // new cluster (:218-228): the bookkeeping happens even when the set insert collides
-        lens_insert(T, ref_len);
-        T.len_sum = __fadd_rn(T.len_sum, (float)ref_len);
-        if (ref_len >= min_map_len && ref_len > T.mm.total_len) {
-            T.mm.ref_st = r2; T.mm.rstart = r2; T.mm.rend = ref_en;
-            T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
-        }
-        if (!exists) {
-            ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
-            ClusterCold nc; nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
-            wave_sync();
-            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
-            T.n++;
-            wave_sync();
-        }
-    }
-}
-
-// ---- sorting ------------------------------------------------------------------------------------
-
-__device__ __forceinline__ bool key_gt(uint64_t a1, uint64_t b1, uint64_t a2, uint64_t b2) {
-    return a1 > a2 || (a1 == a2 && b1 > b2);
-}
-
-// Bitonic network over keys held E per lane (block element q = lane*E + e, global index p = base + q).
-// merge_stages runs the stages j = j_from, j_from/2, .., 1 of merge size k: the j < E stages stay inside a
-// lane (static register indices), the j >= E stages cross lanes (at most 6 per merge).
-template <int E>
-__device__ __forceinline__ void merge_stages(uint64_t (&a)[E], uint64_t (&b)[E], uint32_t base, uint32_t k, uint32_t j_from,
-                                             int lane) {
-    for (uint32_t j = j_from; j > 0; j >>= 1) {
-        if (j >= (uint32_t)E) {
-            const uint32_t d = j / (uint32_t)E;          // lane distance
-            const bool lower = ((uint32_t)lane & d) == 0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                uint64_t pa = xor_lane64(a[e], d);
-                uint64_t pb = xor_lane64(b[e], d);
-                uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
-                bool up = (p & k) == 0;
-                bool want_min = lower == up;
-                bool gt = key_gt(a[e], b[e], pa, pb);
-                if (want_min ? gt : !gt) { a[e] = pa; b[e] = pb; }
-            }
-        } else {
-#pragma unroll
-            for (int jj = 1; jj < E; jj <<= 1) {
-                if (j == (uint32_t)jj) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (!(e & jj)) {
-                            const int pe = e | jj;
-                            uint32_t p = base + (uint32_t)lane * E + (uint32_t)e;
-                            bool up = (p & k) == 0;
-                            bool gt = key_gt(a[e], b[e], a[pe], b[pe]);
-                            if (up ? gt : !gt) {
-                                uint64_t ta = a[e], tb = b[e];
-                                a[e] = a[pe]; b[e] = b[pe];
-                                a[pe] = ta; b[pe] = tb;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void block_load(uint64_t (&a)[E], uint64_t (&b)[E], const UNC_AS_GLOBAL SortKey *in, uint32_t base, uint32_t n, int lane) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) { const SortKey k = g_load(in + i); a[e] = k.a; b[e] = k.b; }
-        else { a[e] = ~0ull; b[e] = ~0ull; }
-    }
-}
-template <int E>
-__device__ __forceinline__ void block_store(const uint64_t (&a)[E], const uint64_t (&b)[E], UNC_AS_GLOBAL SortKey *out, uint32_t base, uint32_t lim, int lane) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-        if (i < lim) { SortKey k; k.a = a[e]; k.b = b[e]; g_store(out + i, k); }
-    }
-}
-
-// n <= 64*E: the whole sort in registers
-template <int E>
-static __device__ __noinline__ void sort_regs(const UNC_AS_GLOBAL SortKey *in_, UNC_AS_GLOBAL SortKey *out_, uint32_t n_, int lane) {
-    const UNC_AS_GLOBAL SortKey *const in = uniform_ptr(in_);
-    UNC_AS_GLOBAL SortKey *const out = uniform_ptr(out_);
-    const uint32_t n = uniform32(n_);
-    uint64_t a[E], b[E];
-    block_load<E>(a, b, in, 0, n, lane);
-    for (uint32_t k = 2; k <= 64u * E; k <<= 1) merge_stages<E>(a, b, 0, k, k >> 1, lane);
-    block_store<E>(a, b, out, 0, n, lane);
-}
-
-constexpr int GS_BATCH = 4;     // passes of a global sort stage whose loads are issued together (N / 2 / 64 >= 8 passes)
-// n > 512: 512-key blocks are sorted / merged in registers, only the stages with j >= 512 go through memory
-static __device__ __noinline__ void sort_hybrid(const UNC_AS_GLOBAL SortKey *in_, UNC_AS_GLOBAL SortKey *out_, uint32_t n_, int lane) {
-    const UNC_AS_GLOBAL SortKey *const in = uniform_ptr(in_);
-    UNC_AS_GLOBAL SortKey *const out = uniform_ptr(out_);
-    const uint32_t n = uniform32(n_);
-    constexpr int E = 8;
-    constexpr uint32_t B = 64u * E;
-    uint32_t N = 2 * B;
-    while (N < n) N <<= 1;
-    uint64_t a[E], b[E];
-    for (uint32_t base = 0; base < N; base += B) {      // padded blocks sort like any other (keys = max)
-        block_load<E>(a, b, in, base, n, lane);
-        for (uint32_t k = 2; k <= B; k <<= 1) merge_stages<E>(a, b, base, k, k >> 1, lane);
-        block_store<E>(a, b, out, base, N, lane);
-    }
-    wave_sync();
-    for (uint32_t k = 2 * B; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j >= B; j >>= 1) {
-            // the pairs of one stage are disjoint: four passes' worth of loads are in flight before the first store (the
-            // stage is otherwise one dependent memory round trip per 64 pairs)
-            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
-                SortKey x[GS_BATCH], y[GS_BATCH];
-                uint32_t ii[GS_BATCH];
-#pragma unroll
-                for (int u = 0; u < GS_BATCH; ++u) {
-                    const uint32_t t = t0 + 64u * u + (uint32_t)lane;
-                    ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    x[u] = g_load(out + ii[u]); y[u] = g_load(out + (ii[u] | j));
-                }
-#pragma unroll
-                for (int u = 0; u < GS_BATCH; ++u) {
-                    const bool up = (ii[u] & k) == 0;
-                    const bool gt = key_gt(x[u].a, x[u].b, y[u].a, y[u].b);
-                    if (up ? gt : !gt) { g_store(out + ii[u], y[u]); g_store(out + (ii[u] | j), x[u]); }
-                }
-            }
-            wave_sync();
-        }
-        for (uint32_t base = 0; base < N; base += B) {
-            block_load<E>(a, b, out, base, N, lane);
-            merge_stages<E>(a, b, base, k, B >> 1, lane);
-            block_store<E>(a, b, out, base, N, lane);
-        }
-        wave_sync();
-    }
-}
-
-// ---- narrow mode: start, length and creation index of a child fit one 64-bit key (index-dependent, decided at load:
-// DevIndex::key_len_bits).  Half the data to move per sort stage; the seed_prob
-// ordering inside runs of equal ranges is recovered afterwards by a segmented max over the children's info words.
-// The network is the all-ascending form of the bitonic sorter: a merge of size k starts with the "flip" stage
-// (element q against q ^ (k - 1), the mirror image inside its k-group) and continues with the half-cleaners
-// j = k/4 .. 1 (q against q ^ j); the lower index always keeps the minimum.  Every sorted run is ascending, so the
-// +inf padding behind the n real keys never moves and whole blocks / pairs made of padding are skipped.
-template <int E>
-__device__ __forceinline__ void asc_stages64(uint64_t (&a)[E], uint32_t j_from, int lane) {
-    for (uint32_t j = j_from; j > 0; j >>= 1) {
-        if (j >= (uint32_t)E) {
-            const uint32_t d = j / (uint32_t)E;
-            const bool lower = ((uint32_t)lane & d) == 0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint64_t pa = xor_lane64(a[e], d);
-                const bool gt = a[e] > pa;
-                if (lower ? gt : !gt) a[e] = pa;
-            }
-        } else {
-#pragma unroll
-            for (int jj = 1; jj < E; jj <<= 1) {
-                if (j == (uint32_t)jj) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (!(e & jj)) {
-                            const int pe = e | jj;
-                            if (a[e] > a[pe]) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// flip stage of a merge of size k <= 64 * E inside a block
-template <int E>
-__device__ __forceinline__ void flip_stage64(uint64_t (&a)[E], uint32_t k, int lane) {
-    if (k > (uint32_t)E) {
-        const uint32_t kl = k / (uint32_t)E;                 // lanes per k-group; partner lane = lane ^ (kl - 1), register E-1-e
-        const bool lower = ((uint32_t)lane & (kl >> 1)) == 0;
-        uint64_t pa[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) pa[e] = xor_lane64(a[E - 1 - e], kl - 1u);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool gt = a[e] > pa[e];
-            if (lower ? gt : !gt) a[e] = pa[e];
-        }
-    } else {
-#pragma unroll
-        for (int kk = 2; kk <= E; kk <<= 1) {
-            if (k == (uint32_t)kk) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int pe = e ^ (kk - 1);
-                    if (pe > e && a[e] > a[pe]) { const uint64_t t = a[e]; a[e] = a[pe]; a[pe] = t; }
-                }
-            }
-        }
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void block_sort64(uint64_t (&a)[E], int lane) {
-    for (uint32_t k = 2; k <= 64u * E; k <<= 1) {
-        flip_stage64<E>(a, k, lane);
-        asc_stages64<E>(a, k >> 2, lane);
-    }
-}
-
-// ---- narrow keys arrive as RUNS.  Phase E files a child's key by what it is: stays and the moves with base 0..3 of the
-// sorted survivors (five runs that come out ascending: a stay keeps its parent's range, and one backward-search step with a
-// fixed base maps ascending ranges to ascending ranges; the four bases' rows are disjoint blocks of the index in base
-// order), and the children of sources (run 5, no order).  KeyArr<R> is a sequence made of R such runs back to back; every
-// field is uniform.
-template <int R> struct KeyArr {
-    uint32_t adj[R];    // byte offset of run r inside the slot, minus 8 * (first index of run r)
-    uint32_t cum[R];    // first index of run r (cum[0] = 0)
-    uint32_t n;
-};
-template <int R> __device__ __forceinline__ uint64_t ka_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
-    uint32_t a = K.adj[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
-    return gld<uint64_t>(sb, a + (i << 3));
-}
-template <int R> __device__ __forceinline__ KeyArr<R> ka_uniform(const KeyArr<R> &K) {
-    KeyArr<R> U;
-#pragma unroll
-    for (int r = 0; r < R; ++r) { U.adj[r] = uniform32(K.adj[r]); U.cum[r] = uniform32(K.cum[r]); }
-    U.n = uniform32(K.n);
-    return U;
-}
-__device__ __forceinline__ KeyArr<1> ka_single(uint32_t off, uint32_t n) { KeyArr<1> K; K.adj[0] = off; K.cum[0] = 0; K.n = n; return K; }
-
-// n <= 64 * E keys of K -> out (byte offset in the slot), sorted
-template <int E>
-static __device__ __noinline__ void sort_regs64(gptr_t sb_, KeyArr<6> K_, uint32_t out_off_, int lane) {
-    const gptr_t sb = uniform_ptr(sb_);
-    const uint32_t out_off = uniform32(out_off_);
-    const KeyArr<6> K = ka_uniform(K_);
-    const uint32_t n = K.n;
-    uint64_t a[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        a[e] = i < n ? ka_load(sb, K, i) : ~0ull;
-    }
-    block_sort64<E>(a, lane);
-    wave_sync();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
-        if (i < n) gst(sb, out_off + (i << 3), a[e]);
-    }
-}
-
-static __device__ __noinline__ void sort_hybrid64(gptr_t sb_, KeyArr<6> K_, uint32_t out_off, int lane) {
-    const gptr_t sb = uniform_ptr(sb_);
-    const KeyArr<6> K = ka_uniform(K_);
-    const uint32_t n = K.n;
-    UNC_AS_GLOBAL uint64_t *const out = reinterpret_cast<UNC_AS_GLOBAL uint64_t *>(sb + uniform32(out_off));
-    constexpr int E = 8;
-    constexpr uint32_t B = 64u * E;
-    uint32_t N = 2 * B;
-    while (N < n) N <<= 1;
-    uint64_t a[E];
-    for (uint32_t base = 0; base < n; base += B) {          // blocks that hold real keys
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
-            a[e] = i < n ? ka_load(sb, K, i) : ~0ull;
-        }
-        block_sort64<E>(a, lane);
-        wave_sync();                                          // (in place: the block is loaded before any of it is stored)
-#pragma unroll
-        for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
-    }
-    wave_sync();
-    for (uint32_t k = 2 * B; k <= N; k <<= 1) {
-        // flip: i against i ^ (k - 1); a pair whose upper element is padding (>= n) has nothing to exchange.  The pairs of
-        // one stage are disjoint: four passes' worth of loads are in flight before the first store (a stage is otherwise one
-        // dependent memory round trip per 64 pairs, and three such stages were most of this sort's time)
-        for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
-            uint64_t x[GS_BATCH], y[GS_BATCH];
-            uint32_t ii[GS_BATCH], pp[GS_BATCH];
-#pragma unroll
-            for (int u = 0; u < GS_BATCH; ++u) {
-                const uint32_t t = t0 + 64u * u + (uint32_t)lane;
-                ii[u] = ((t & ~((k >> 1) - 1)) << 1) | (t & ((k >> 1) - 1));
-                pp[u] = ii[u] ^ (k - 1);
-                x[u] = 0; y[u] = 0;
-                if (pp[u] < n) { x[u] = out[ii[u]]; y[u] = out[pp[u]]; }
-            }
-#pragma unroll
-            for (int u = 0; u < GS_BATCH; ++u)
-                if (pp[u] < n && x[u] > y[u]) { out[ii[u]] = y[u]; out[pp[u]] = x[u]; }
-        }
-        wave_sync();
-        for (uint32_t j = k >> 2; j >= B; j >>= 1) {
-            for (uint32_t t0 = 0; t0 < N / 2; t0 += 64 * GS_BATCH) {
-                if (uniform32((((t0 & ~(j - 1)) << 1) | (t0 & (j - 1))) | j) >= n) continue;   // p grows with t: the whole batch is padding
-                uint64_t x[GS_BATCH], y[GS_BATCH];
-                uint32_t ii[GS_BATCH];
-#pragma unroll
-                for (int u = 0; u < GS_BATCH; ++u) {
-                    const uint32_t t = t0 + 64u * u + (uint32_t)lane;
-                    ii[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    x[u] = 0; y[u] = 0;
-                    if ((ii[u] | j) < n) { x[u] = out[ii[u]]; y[u] = out[ii[u] | j]; }
-                }
-#pragma unroll
-                for (int u = 0; u < GS_BATCH; ++u)
-                    if ((ii[u] | j) < n && x[u] > y[u]) { out[ii[u]] = y[u]; out[ii[u] | j] = x[u]; }
-            }
-            wave_sync();
-        }
-        // the register stages of this merge, two blocks per trip to memory where a second one with real keys exists
-        for (uint32_t base = 0; base < n; base += 2 * B) {
-            const bool two = base + B < n;
-            uint64_t b2[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
-                b2[e] = two ? out[base + B + (uint32_t)lane * E + (uint32_t)e] : ~0ull;
-            }
-            asc_stages64<E>(a, B >> 1, lane);
-            if (two) asc_stages64<E>(b2, B >> 1, lane);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
-                if (two) out[base + B + (uint32_t)lane * E + (uint32_t)e] = b2[e];
-            }
-        }
-        wave_sync();
-    }
-}
-
-// any number of keys, by size class
-static __device__ __noinline__ void sort_any64(gptr_t sb, KeyArr<6> K, uint32_t out_off, int lane) {
-    const uint32_t n = uniform32(K.n);
-    if (n <= 64) sort_regs64<1>(sb, K, out_off, lane);
-    else if (n <= 128) sort_regs64<2>(sb, K, out_off, lane);
-    else if (n <= 256) sort_regs64<4>(sb, K, out_off, lane);
-    else if (n <= 512) sort_regs64<8>(sb, K, out_off, lane);
-    else sort_hybrid64(sb, K, out_off, lane);
-}
-
-// ---- merging two ascending runs (merge path).  The output is cut into tiles of MERGE_TILE keys; a tile's share of A
-// and B is staged in LDS, each lane finds where its MERGE_C outputs start by a binary search on its diagonal and merges
-// them sequentially.  Work per key: one LDS read and a dozen lane instructions, against ~60 compare-exchanges of the
-// bitonic network -- provided the inputs ARE ascending.  The caller checks the result (`verify`) and sorts the keys the
-// hard way if it is not (an event where the runs of phase E were not ascending after all).
-constexpr uint32_t MERGE_MIN = 256;     // fewer children than this go straight through the bitonic network
-#ifndef UNC_MERGE_REPAIR
-#define UNC_MERGE_REPAIR 1              // (tests build the emulator library with 0: the runs then reach the merge unrepaired, its check
-#endif                                  //  must notice and the event must take the bitonic network instead, with the same result)
-constexpr bool MERGE_REPAIR = UNC_MERGE_REPAIR != 0;
-constexpr uint32_t MERGE_C = 9;
-constexpr uint32_t MERGE_TILE = MERGE_C * WAVE;
-// LDS slot of tile element i: one pad slot per 8 keys, so that lanes whose reading positions are a multiple of 8 keys
-// apart (the typical distance) do not all fall on the same banks
-__device__ __forceinline__ uint32_t mslot(uint32_t i) { return i + (i >> 3); }
-constexpr uint32_t MERGE_LDS_KEYS = MERGE_TILE + MERGE_TILE / 8 + 1;
-static_assert(MERGE_LDS_KEYS <= S_E_WORDS && NKMER * 4 <= S_E_WORDS * 8, "merge tile / source list must fit the staging buffer");
-
-// how many of the first d keys of merge(A, B) come from A (keys distinct): the first mid with !(A[mid] < B[d - 1 - mid]),
-// 16 probes per memory round trip (a scattered access costs the memory pipeline per LANE: four rounds of 16 are cheaper
-// than three of 64)
-constexpr uint32_t SPLIT_PROBES = 16;
-template <int RA, int RB>
-__device__ __forceinline__ uint32_t merge_split(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
-    uint32_t lo = d > B.n ? d - B.n : 0u, hi = d < A.n ? d : A.n;
-    while (lo < hi) {
-        const uint32_t span = hi - lo, step = (span + SPLIT_PROBES - 1u) / SPLIT_PROBES;
-        const uint32_t p = lo + (uint32_t)lane * step;
-        bool less = false;
-        if ((uint32_t)lane < SPLIT_PROBES && p < hi) less = ka_load(sb, A, p) < ka_load(sb, B, d - 1u - p);
-        const uint32_t c = (uint32_t)__popcll(__ballot(less));       // the predicate is monotone: the first c probes hold
-        const uint32_t nlo = c ? lo + (c - 1u) * step + 1u : lo;
-        const uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
-        lo = nlo; hi = c ? nhi : lo;
-    }
-    return lo;
-}
-
-template <int RA, int RB>
-static __device__ __noinline__ uint32_t merge_runs(gptr_t sb_, KeyArr<RA> A_, KeyArr<RB> B_, uint32_t out_off_, int lane, uint32_t verify_) {
-    const gptr_t sb = uniform_ptr(sb_);
-    uint64_t *const s_tile = s_e;
-    const KeyArr<RA> A = ka_uniform(A_);
-    const KeyArr<RB> B = ka_uniform(B_);
-    const uint32_t out_off = uniform32(out_off_), verify = uniform32(verify_);
-    const uint32_t n = A.n + B.n;
-    uint32_t a0 = 0, b0 = 0;
-    uint64_t prev_last = 0;          // (keys are > 0: idx and length fields aside, start >= 1)
-    bool bad = false;
-    for (uint32_t o0 = 0; o0 < n; o0 += MERGE_TILE) {
-        const uint32_t d1 = o0 + MERGE_TILE < n ? o0 + MERGE_TILE : n;
-        const uint32_t a1 = d1 == n ? A.n : merge_split(sb, A, B, d1, lane);
-        const uint32_t b1 = d1 - a1;
-        const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
-        // stage the tile: every load is requested before the first key goes into LDS (one memory round trip, not twelve)
-        {
-            uint64_t v[MERGE_C];
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                v[c] = 0;
-                if (i < na) v[c] = ka_load(sb, A, a0 + i);
-                else if (i < tn) v[c] = ka_load(sb, B, b0 + (i - na));
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                if (i < tn) s_tile[mslot(i)] = v[c];
-            }
-        }
-        wave_sync();
-        // this lane's outputs [d, d + cnt)
-        const uint32_t d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
-        const uint32_t cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
-        uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
-        while (__any(lo < hi)) {
-            if (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_tile[mslot(mid)] < s_tile[mslot(na + d - 1u - mid)]) lo = mid + 1u; else hi = mid;
-            }
-        }
-        uint32_t ia = lo, ib = d - lo;
-        uint64_t va = ia < na ? s_tile[mslot(ia)] : ~0ull, vb = ib < nb ? s_tile[mslot(na + ib)] : ~0ull;
-        uint64_t o[MERGE_C];
-#pragma unroll
-        for (uint32_t c = 0; c < MERGE_C; ++c) {
-            const bool ta = va < vb;
-            o[c] = ta ? va : vb;
-            if (ta) ++ia; else ++ib;
-            const uint32_t idx = ta ? ia : na + ib;
-            const bool ok = ta ? ia < na : ib < nb;
-            uint64_t x = ~0ull;
-            if (ok && c + 1u < cnt) x = s_tile[mslot(idx)];
-            if (ta) va = x; else vb = x;
-        }
-        // out through the tile buffer, so that each store instruction writes 512 consecutive bytes: a lane storing its own twelve
-        // keys (lanes 96 bytes apart) costs the CU's memory pipeline ten times as much (tools/dev/ubench_vmem.hip)
-        wave_sync();
-#pragma unroll
-        for (uint32_t c = 0; c < MERGE_C; ++c)
-            if (c < cnt) s_tile[mslot(d + c)] = o[c];
-        wave_sync();
-#pragma unroll
-        for (uint32_t c = 0; c < MERGE_C; ++c) {
-            const uint32_t i = (uint32_t)lane + c * WAVE;
-            if (i < tn) gst(sb, out_off + ((o0 + i) << 3), s_tile[mslot(i)]);
-        }
-        if (verify) {
-            uint64_t last = o[0];
-            bool w = false;
-#pragma unroll
-            for (uint32_t c = 1; c < MERGE_C; ++c)
-                if (c < cnt) { w = w || !(o[c] > last); last = o[c]; }
-            uint64_t pl = (uint64_t)__shfl_up((unsigned long long)last, 1);
-            if (lane == 0) pl = prev_last;
-            if (cnt > 0 && !(o[0] > pl)) w = true;
-            if (__any(w)) bad = true;
-            const uint32_t ll = (tn - 1u) / MERGE_C;        // the last lane with outputs (tn > 0)
-            prev_last = bcast64(last, (int)ll);
-        }
-        a0 = a1; b0 = b1;
-        wave_sync();
-    }
-    return bad ? 0u : 1u;
-}
-
-// The moves of one base (run r of the streams) are ascending by START; two of them with equal starts can be out of order
-// when their parents were nested ranges (the outer parent comes first and its child can be the longer range).  A key that
-// is smaller than one before it is moved to the unsorted run: what is left is ascending.  Nearly every 64-key chunk has
-// no such key (one compare with the neighbour lane says so); a chunk that has one takes the exact running maximum.
-static __device__ __noinline__ uint32_t repair_run(gptr_t sb_, uint32_t run_off_, uint32_t n_, uint32_t x_off_, uint32_t nx_, int lane) {
-    const gptr_t sb = uniform_ptr(sb_);
-    const uint32_t run_off = uniform32(run_off_), n = uniform32(n_), x_off = uniform32(x_off_);
-    uint32_t nx = uniform32(nx_), shift = 0;
-    uint64_t carry = 0;              // the largest key so far (keys are > 0)
-    uint64_t knext = (uint32_t)lane < n ? gld<uint64_t>(sb, run_off + ((uint32_t)lane << 3)) : 0ull;
-    for (uint32_t c0 = 0; c0 < n; c0 += WAVE) {
-        const uint32_t i = c0 + (uint32_t)lane;
-        const bool have = i < n;
-        const uint64_t k = knext;
-        // the next chunk is requested before this one is worked on (what this pass stores lies below what the next one reads)
-        knext = i + WAVE < n ? gld<uint64_t>(sb, run_off + ((i + WAVE) << 3)) : 0ull;
-        uint64_t pk = (uint64_t)__shfl_up((unsigned long long)k, 1);
-        if (lane == 0) pk = carry;
-        bool viol = have && k < pk;
-        const uint32_t nvalid = n - c0 < (uint32_t)WAVE ? n - c0 : (uint32_t)WAVE;
-        if (__any(viol)) {
-            const uint64_t inc = seg_incl_max64(k, lane == 0);
-            uint64_t ex = (uint64_t)__shfl_up((unsigned long long)inc, 1);
-            if (lane == 0) ex = 0;
-            if (ex < carry) ex = carry;
-            viol = have && k < ex;
-            const uint64_t top = bcast64(inc, WAVE - 1);
-            if (top > carry) carry = top;
-        } else carry = bcast64(k, (int)nvalid - 1);
-        const uint64_t vm = __ballot(viol);
-        if (vm == 0 && shift == 0) continue;
-        if constexpr (!MERGE_REPAIR) { shift += (uint32_t)__popcll(vm); continue; }      // (test build: count, leave in place)
-        wave_sync();
-        const uint32_t before = (uint32_t)prefix_popc(vm);
-        if (have) {
-            if (viol) gst(sb, x_off + ((nx + before) << 3), k);
-            else gst(sb, run_off + ((i - shift - before) << 3), k);
-        }
-        const uint32_t nv = (uint32_t)__popcll(vm);
-        shift += nv; nx += nv;
-        wave_sync();
-    }
-    return shift;
-}
 
 __device__ __forceinline__ uint32_t float_orderable(float f) {
     uint32_t u = __float_as_uint(f);
