@@ -48,11 +48,11 @@ def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shif
 
 
 def test_chunked_variants(sim_lib, oracle_lib, example, goldens):
-    pc.case_chunked_variants(sim_lib, oracle_lib, example, goldens, n_channels=2, n_reads=4)     # 6 reads on the GPU
+    pc.case_chunked_variants(sim_lib, oracle_lib, example, goldens, n_channels=2, n_reads=3)     # 6 reads on the GPU
 
 
 def test_parameter_variants(sim_lib, oracle_lib, example, goldens):
-    pc.case_parameter_variants(sim_lib, oracle_lib, example, goldens, n=4)       # 6 reads per set on the GPU
+    pc.case_parameter_variants(sim_lib, oracle_lib, example, goldens, n=3)       # 6 reads per set on the GPU
 
 
 def test_cluster_overflow_remap(sim_lib, oracle_lib, example, goldens):
@@ -70,7 +70,7 @@ def test_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slic
 
 @pytest.mark.parametrize("pool_chunks,n_waves", [(1, 1)])
 def test_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
-    pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=5)
+    pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=4)
 
 
 def test_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
