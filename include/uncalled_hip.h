@@ -249,6 +249,19 @@ int unc_rt_process_chunks(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t 
 int unc_rt_process_chunks_f32(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chunks, const float *signal, int on_device,
                               void *stream, unc_rt_result_t *results);
 int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *ms_map);
+/* stage tap (parity tests): what a channel's Mapper carries between chunks below the PAF -- EventDetector counters
+ * (event_detector.hpp:106-128), the EventProfiler's window and queue (event_profiler.hpp:35-48) and the rolling Normalizer
+ * (normalizer.hpp:74-79) with its ring.  ring (host, 6000 floats) receives the channel's ring, slots [0, norm_n) are in use. */
+typedef struct {
+    uint32_t det_t, det_total_events;
+    float det_len_sum;
+    uint32_t norm_n, norm_wr;
+    uint32_t prof_n, prof_to_mask, prof_queued;
+    double norm_mean, norm_varsum;
+    double prof_mean, prof_varsum;
+    float prof_queue[28];               /* the queued event means, oldest first (at most 26) */
+} unc_rt_tap_t;
+int unc_rt_tap_channel(unc_rt_t *rt, uint32_t channel, unc_rt_tap_t *out, float *ring);
 
 /* ---- measurement aid: `reps` launches that write, then `reps` that read, n_records (made odd) scattered 64-byte records with
  * one lane per record and four 16-byte accesses per lane -- k_map's access shape with an exactly known byte count, for

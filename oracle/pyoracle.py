@@ -33,6 +33,10 @@ class Params(C.Structure):
                 ("bp_per_sec", C.c_float), ("sample_rate", C.c_float)]
 
 
+RT_TAP = np.dtype([("det_t", "<u4"), ("det_total_events", "<u4"), ("det_len_sum", "<f4"), ("norm_n", "<u4"), ("norm_wr", "<u4"),
+                   ("prof_n", "<u4"), ("prof_to_mask", "<u4"), ("prof_queued", "<u4"), ("norm_mean", "<f8"), ("norm_varsum", "<f8"),
+                   ("prof_mean", "<f8"), ("prof_varsum", "<f8"), ("prof_queue", "<f4", (28,))], align=True)
+
 _lib = None
 
 
@@ -200,6 +204,16 @@ class Mapper:
 
     def set_max_chunks(self, n):
         lib().unc_o_set_max_chunks(self.h, n)
+
+    def rt_tap(self):
+        """(tap record, ring of 6000 floats): the state the chunked path carries between chunks below the PAF"""
+        tap = np.zeros(1, dtype=RT_TAP)
+        ring = np.zeros(6000, dtype=np.float32)
+        f = lib().unc_o_rt_tap
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(self.h, tap.ctypes.data, ring.ctypes.data)
+        return tap[0], ring
 
     def stats(self):
         a, b, d = C.c_uint64(), C.c_uint64(), C.c_uint64()

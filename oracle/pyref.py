@@ -135,6 +135,16 @@ class Mapper:
         lib().ref_chunk_read(self.h, sig.ctypes.data, sig.size, chunk_len, number, C.byref(hit), C.byref(used))
         return hit, used.value
 
+    def rt_tap(self):
+        from oracle.pyoracle import RT_TAP
+        tap = np.zeros(1, dtype=RT_TAP)
+        ring = np.zeros(6000, dtype=np.float32)
+        f = lib().ref_rt_tap
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        f.restype = None
+        f(self.h, tap.ctypes.data, ring.ctypes.data, 6000)
+        return tap[0], ring
+
     def trace(self, signal_f32, max_paths=10000, max_clusters=1 << 16):
         """Generator: after each map_next() yields (done, event_i, paths, clusters, max_map, len_sum, n_lens)."""
         sig = np.ascontiguousarray(signal_f32, dtype=np.float32)

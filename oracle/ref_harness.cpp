@@ -235,6 +235,19 @@ int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len
 
 void ref_set_max_chunks(uint32_t max_chunks) { ReadBuffer::PRMS.max_chunks = max_chunks; }
 
+void ref_rt_tap(void *mp, ref_rt_tap_t *out, float *ring, uint32_t ring_cap) {
+    Mapper *m = static_cast<Mapper *>(mp);
+    std::memset(out, 0, sizeof *out);
+    out->det_t = m->evdt_.t; out->det_total_events = m->evdt_.total_events_; out->det_len_sum = m->evdt_.len_sum_;
+    const Normalizer &n = m->norm_, &w = m->evt_prof_.window_;
+    out->norm_n = n.n_; out->norm_wr = n.wr_; out->norm_mean = n.mean_; out->norm_varsum = n.varsum_;
+    for (uint32_t i = 0; i < ring_cap && i < n.signal_.size(); ++i) ring[i] = n.signal_[i];
+    out->prof_n = w.n_; out->prof_to_mask = m->evt_prof_.to_mask_; out->prof_queued = (uint32_t)m->evt_prof_.events_.size();
+    out->prof_mean = w.mean_; out->prof_varsum = w.varsum_;
+    uint32_t i = 0;
+    for (const Event &e : m->evt_prof_.events_) { if (i < 28) out->prof_queue[i] = e.mean; ++i; }
+}
+
 // self_align (self_align_ref.cpp:34-91), the FM walk behind `uncalled index`: flattened into CSR form
 uint64_t ref_self_align(const char *bwa_prefix, uint32_t sample_dist, uint64_t *lens, uint64_t lens_cap, uint64_t *offsets,
                         uint64_t offsets_cap, uint64_t *n_paths) {

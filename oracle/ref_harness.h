@@ -66,6 +66,17 @@ double ref_map_batch_pool(int n_threads, uint32_t n_reads, const float *signals,
 int ref_chunk_read(void *m, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,
                    uint32_t *chunks_used);
 void ref_set_max_chunks(uint32_t max_chunks);
+/* stage tap of the chunked path (same layout as unc_o_rt_tap_t): Mapper::evdt_ / evt_prof_ / norm_ after ref_chunk_read */
+typedef struct {
+    uint32_t det_t, det_total_events;
+    float det_len_sum;
+    uint32_t norm_n, norm_wr;
+    uint32_t prof_n, prof_to_mask, prof_queued;
+    double norm_mean, norm_varsum;
+    double prof_mean, prof_varsum;
+    float prof_queue[28];
+} ref_rt_tap_t;
+void ref_rt_tap(void *mapper, ref_rt_tap_t *out, float *ring, uint32_t ring_cap);
 
 /* `uncalled index`: FM-range-size trajectories of sampled reference positions (self_align_ref.cpp:34-91) */
 uint64_t ref_self_align(const char *bwa_prefix, uint32_t sample_dist, uint64_t *lens, uint64_t lens_cap, uint64_t *offsets,

@@ -1188,6 +1188,18 @@ static int rt_map_chunk(unc_o_mapper_t *m) {
     return 0;
 }
 
+void unc_o_rt_tap(const unc_o_mapper_t *m, unc_o_rt_tap_t *out, float *ring) {
+    memset(out, 0, sizeof *out);
+    out->det_t = m->evdt.t; out->det_total_events = m->evdt.total_events; out->det_len_sum = m->evdt.len_sum;
+    if (!m->rt.inited) return;
+    const rnorm_t *n = &m->rt.norm, *w = &m->rt.prof.window;
+    out->norm_n = n->n; out->norm_wr = n->wr; out->norm_mean = n->mean; out->norm_varsum = n->varsum;
+    memcpy(ring, n->signal, (size_t)NORM_LEN * sizeof(float));
+    out->prof_n = w->n; out->prof_to_mask = m->rt.prof.to_mask; out->prof_queued = m->rt.prof.q_len;
+    out->prof_mean = w->mean; out->prof_varsum = w->varsum;
+    for (uint32_t i = 0; i < m->rt.prof.q_len && i < 28; ++i) out->prof_queue[i] = m->rt.prof.evq[(m->rt.prof.q_head + i) % (PROF_WIN + 1)];
+}
+
 void unc_o_set_max_chunks(unc_o_mapper_t *m, uint32_t max_chunks) { m->max_chunks = max_chunks; }
 
 /* One read on this mapper (= one channel), chunk by chunk.  chunks_used: chunks handed to the mapper. */

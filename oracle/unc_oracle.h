@@ -103,6 +103,18 @@ void unc_o_set_max_chunks(unc_o_mapper_t *m, uint32_t max_chunks);
 int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_t chunk_len, unc_o_hit_t *out,
                      uint32_t *chunks_used);
 
+/* stage tap of the chunked path: the state this mapper (= channel) carries between chunks below the PAF; ring: NORM_LEN floats */
+typedef struct {
+    uint32_t det_t, det_total_events;
+    float det_len_sum;
+    uint32_t norm_n, norm_wr;
+    uint32_t prof_n, prof_to_mask, prof_queued;
+    double norm_mean, norm_varsum;
+    double prof_mean, prof_varsum;
+    float prof_queue[28];
+} unc_o_rt_tap_t;
+void unc_o_rt_tap(const unc_o_mapper_t *m, unc_o_rt_tap_t *out, float *ring);
+
 /* step-wise trace */
 void unc_o_trace_begin(unc_o_mapper_t *m, const float *signal, uint32_t n);
 int unc_o_trace_step(unc_o_mapper_t *m);

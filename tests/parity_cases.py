@@ -248,6 +248,49 @@ def case_chunked_variants(lib, oracle_lib, example, goldens, n_channels=2, n_rea
             assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), (ov, chunk_len, i)
 
 
+def assert_rt_taps_equal(a, ring_a, b, ring_b, what):
+    """stage tap of the chunked path (unc_rt_tap_t layout): detector counters, profiler window + queue, rolling normaliser + ring"""
+    for f in ("det_t", "det_total_events", "det_len_sum", "norm_n", "norm_wr", "prof_n", "prof_to_mask", "prof_queued"):
+        assert a[f] == b[f], (what, f, a[f], b[f])
+    for f in ("norm_mean", "norm_varsum", "prof_mean", "prof_varsum"):
+        assert np.float64(a[f]).tobytes() == np.float64(b[f]).tobytes(), (what, f, a[f], b[f])
+    q = int(a["prof_queued"])
+    assert np.array_equal(a["prof_queue"][:q].view(np.uint32), b["prof_queue"][:q].view(np.uint32)), (what, "prof_queue")
+    n = int(a["norm_n"])
+    assert np.array_equal(ring_a[:n].view(np.uint32), ring_b[:n].view(np.uint32)), (what, "ring")
+
+
+def case_chunked_stage_tap(lib, oracle_lib, example, goldens, n_reads=8):
+    """Below the PAF of the chunked path: after every read of a channel the EventDetector's counters, the EventProfiler's
+    25-event window (mean / varsum / mask countdown / queued events) and the rolling 6000-event Normalizer (mean / varsum /
+    write position / ring contents) of the device equal the oracle's bit for bit -- a masking or normalisation slip that
+    cancelled out in the coordinates would show here.  (tests/test_oracle.py pins the oracle's tap against the reference's.)"""
+    from uncalled_amd.realtime import MapPoolOrd
+    po = oracle_lib
+    dev_index = _index(lib, example)
+    oix = po.Index(example["prefix"])
+    pool = MapPoolOrd(dev_index, n_channels=1)
+    om = po.Mapper(oix)
+    off = goldens["sim_offsets"]
+    reads = [(example["signal"], (example["range"], example["offset"], example["digitisation"]))]
+    for i in range(n_reads - 1):
+        reads.append((goldens["sim_signal"][int(off[i]):int(off[i + 1])], (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)))
+    for i, (raw, cal) in enumerate(reads):
+        pool.add_read(0, i, raw, cal, key=i)
+    done = 0
+    rounds = 0
+    while pool.running():
+        for key, r in pool.update():
+            raw, cal = reads[key]
+            om.chunk_read(po.calibrate(raw, *cal), 4000)
+            (ta, ra), (tb, rb) = pool.rt.tap_channel(0), om.rt_tap()
+            assert_rt_taps_equal(ta, ra, tb, rb, "read %d" % key)
+            done += 1
+        rounds += 1
+        assert rounds < 1000
+    assert done == n_reads and int(tb["norm_n"]) == 6000       # (the ring has wrapped by then)
+
+
 def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, n_reads=9, max_chunks=None, long_read=False):
     """Config 5's path: reads replayed chunk by chunk over a few channels (MapPoolOrd semantics) through
     unc_rt_process_chunks; per-channel state persists across chunks AND reads.  Checked against the oracle fed the

@@ -47,6 +47,10 @@ def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shif
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
 
+def test_chunked_stage_tap(sim_lib, oracle_lib, example, goldens):
+    pc.case_chunked_stage_tap(sim_lib, oracle_lib, example, goldens, n_reads=6)
+
+
 def test_chunked_variants(sim_lib, oracle_lib, example, goldens):
     pc.case_chunked_variants(sim_lib, oracle_lib, example, goldens, n_channels=2, n_reads=3)     # 6 reads on the GPU
 

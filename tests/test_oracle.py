@@ -256,6 +256,22 @@ def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, golden
     pr.lib().ref_set_max_chunks(1000000)
 
 
+def test_chunked_stage_tap_equals_live_reference(oracle_lib, ref_lib, example, goldens):
+    """Below the PAF: Mapper::evdt_ / evt_prof_ / norm_ of the reference after every read of a channel (EventDetector counters,
+    the EventProfiler's window and queue, the rolling Normalizer's mean / varsum / ring) against the oracle's, bit for bit."""
+    from tests.parity_cases import assert_rt_taps_equal
+    po, pr = oracle_lib, ref_lib
+    pr.init(example["prefix"])
+    ix = po.Index(example["prefix"])
+    om, rm = po.Mapper(ix), pr.Mapper()
+    for i, sig in enumerate(_chunk_signals(po, goldens)[:12]):
+        om.chunk_read(sig, 4000)
+        rm.chunk_read(sig, 4000, i)
+        (a, ra), (b, rb) = om.rt_tap(), rm.rt_tap()
+        assert_rt_taps_equal(a, ra, b, rb, "read %d" % i)
+    assert int(a["norm_n"]) == 6000
+
+
 def test_chunked_path_variants_equal_live_reference(oracle_lib, ref_lib, example, goldens):
     """The chunked path of the oracle against the reference's (Mapper::new_read(Chunk&) / add_chunk / process_chunk / map_chunk)
     on the parameter sets and chunk lengths of tests/parity_cases.py CHUNK_VARIANTS, reads one after the other on ONE Mapper."""

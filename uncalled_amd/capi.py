@@ -133,6 +133,8 @@ def load(path=None):
     L.unc_rt_process_chunks.argtypes = [vp, u32, vp, vp, C.c_int, vp, vp]
     L.unc_rt_process_chunks_f32.argtypes = [vp, u32, vp, vp, C.c_int, vp, vp]
     L.unc_rt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if hasattr(L, "unc_rt_tap_channel"):
+        L.unc_rt_tap_channel.argtypes = [vp, u32, vp, vp]
     L.unc_trace_begin.argtypes = [vp, vp, u32, vp]
     L.unc_trace_step.argtypes = [vp, u32, C.POINTER(C.c_int)]
     L.unc_trace_paths.argtypes = [vp, vp, u32, C.POINTER(u32)]
@@ -361,6 +363,11 @@ class Mapper:
         return hit[0]
 
 
+RT_TAP = np.dtype([("det_t", "<u4"), ("det_total_events", "<u4"), ("det_len_sum", "<f4"), ("norm_n", "<u4"), ("norm_wr", "<u4"),
+                   ("prof_n", "<u4"), ("prof_to_mask", "<u4"), ("prof_queued", "<u4"), ("norm_mean", "<f8"), ("norm_varsum", "<f8"),
+                   ("prof_mean", "<f8"), ("prof_varsum", "<f8"), ("prof_queue", "<f4", (28,))], align=True)
+
+
 class Realtime:
     """Chunked path: RealtimePool + one Mapper per channel with MapPoolOrd's deterministic semantics
     (realtime_pool.cpp:74-142,349-358; map_pool_ord.cpp:61-112)."""
@@ -383,6 +390,13 @@ class Realtime:
 
     def device_bytes(self):
         return self.L.unc_rt_device_bytes(self.h)
+
+    def tap_channel(self, channel):
+        """unc_rt_tap_channel: (tap record, ring of 6000 floats) of one channel (parity tests)"""
+        tap = np.zeros(1, dtype=RT_TAP)
+        ring = np.zeros(6000, dtype=np.float32)
+        _check(self.L, self.L.unc_rt_tap_channel(self.h, int(channel), tap.ctypes.data, ring.ctypes.data))
+        return tap[0], ring
 
     def process_chunks(self, chunks, raw_i16=None, raw_ptr=None, stream=None):
         """chunks: RT_CHUNK array (at most one per channel); raw: host int16 array or a device address."""

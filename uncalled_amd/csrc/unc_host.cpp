@@ -1261,6 +1261,20 @@ extern "C" int unc_rt_last_timing(const unc_rt_t *rt, float *ms_events, float *m
     return UNC_OK;
 }
 
+extern "C" int unc_rt_tap_channel(unc_rt_t *rt, uint32_t channel, unc_rt_tap_t *out, float *ring) {
+    if (!rt || !out || !ring || channel >= rt->n_channels) return fail(UNC_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(rt->ix->device));
+    RtChan c;
+    HIPCHK(hipMemcpy(&c, rt->d_chans + channel, sizeof c, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ring, rt->d_ring + (size_t)channel * NORM_LEN, (size_t)NORM_LEN * 4, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->det_t = c.t; out->det_total_events = c.total_events; out->det_len_sum = c.len_sum;
+    out->norm_n = c.n_n; out->norm_wr = c.n_wr; out->norm_mean = c.n_mean; out->norm_varsum = c.n_varsum;
+    out->prof_n = c.pw_n; out->prof_to_mask = c.to_mask; out->prof_queued = c.q_len; out->prof_mean = c.pw_mean; out->prof_varsum = c.pw_varsum;
+    for (uint32_t i = 0; i < c.q_len && i < 28; ++i) out->prof_queue[i] = c.evq[(c.q_head + i) % (PROF_WIN + 1)];
+    return UNC_OK;
+}
+
 static void rt_unmapped(const unc_rt *rt, const RtHostChan &hc, const SlotState &s, const unc_evt_info_t *inf, unc_hit_t *h) {
     DevResult res;
     memset(&res, 0, sizeof res);
