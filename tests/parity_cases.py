@@ -1,6 +1,7 @@
 """Parity cases shared by the lanesim (CPU emulator, container) and gpu (real MI355X) test modules: the HIP path
 -- through the C ABI -- against the oracle restatement and the committed reference goldens."""
 import numpy as np
+import pytest
 
 from tests.helpers import assert_hits_equal, oracle_hits, to_oracle_params
 from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
@@ -201,6 +202,43 @@ def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4)
     cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     hits = capi.Mapper(ix, n_slots=3).map_batch(raw, off, cal)
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "narrow buckets")
+
+
+def case_loud_overflows(lib, oracle_lib, example, goldens):
+    """Device scratch that is too small is REPORTED per read (unc_hit_t.status) and by the call's return code -- never a silent
+    wrong answer: a per-event seed list of one entry (UNC_READ_SEED_OVERFLOW), and on the chunked path a chunk of more than 6000
+    events (UNC_READ_NORM_FULL: the reference's #SKIP branch, mapper.cpp:336-351, needs chunks of 8 s and more and is not
+    reproduced).  Reads that did not overflow still answer as the oracle does."""
+    dev_index = _index(lib, example)
+    oix = oracle_lib.Index(example["prefix"])
+    n = 4
+    off = goldens["sim_offsets"][:n + 1].copy()
+    raw = goldens["sim_signal"][:int(off[n])]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    m = capi.Mapper(dev_index, n_slots=3, max_seed_paths=1)
+    with pytest.raises(RuntimeError):
+        m.map_batch(raw, off, cal)                       # the call itself fails ...
+    hits = m.map_batch(raw, off, cal, allow_overflow=True)
+    want = oracle_hits(oix, raw, off, cal)
+    bad = (hits["status"] & 2) != 0
+    assert bad.any() and not (hits["status"] & ~np.uint32(2)).any()      # ... and says which reads, and why
+    assert not hits["mapped"][bad].any()
+    ok = np.flatnonzero(~bad)
+    assert_hits_equal(hits[ok], [want[i] for i in ok], "reads without seed overflow")
+    # chunked path: one 15 s chunk of an off-target read = more than 6000 events before anything is popped
+    from tools.simulate_reads import simulate_reads
+    sim = simulate_reads(np.zeros(20000, np.uint8), [20000], 1, seed=9, read_bases=5200, off_target=1.0)
+    p = capi.default_params(lib)
+    p.chunk_time = 15.0
+    rt = capi.Realtime(dev_index, 1, p)
+    sig = np.ascontiguousarray(sim["signal"], dtype=np.int16)
+    assert 40000 < sig.size <= 60000
+    ch = np.zeros(1, dtype=capi.RT_CHUNK)
+    ch[0]["channel"], ch[0]["read_number"], ch[0]["flags"], ch[0]["n_samples"], ch[0]["offset"] = 0, 0, capi.RT_FIRST | capi.RT_LAST, sig.size, 0
+    ch[0]["calib"]["range"], ch[0]["calib"]["offset"], ch[0]["calib"]["digitisation"] = CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION
+    res = rt.process_chunks(ch, sig, allow_overflow=True)      # (without allow_overflow the call raises, as map_batch above)
+    assert res[0]["state"] == capi.RT_FAILED and (int(res[0]["hit"]["status"]) & 4) and not res[0]["hit"]["mapped"]
+    rt.close()
 
 
 # chunked-path sets: (parameter overrides, chunk length in samples)

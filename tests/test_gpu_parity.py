@@ -58,6 +58,10 @@ def test_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shif
     pc.case_narrow_buckets(hip_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
 
+def test_loud_overflows(hip_lib, oracle_lib, example, goldens):
+    pc.case_loud_overflows(hip_lib, oracle_lib, example, goldens)
+
+
 def test_chunked_stage_tap(hip_lib, oracle_lib, example, goldens):
     pc.case_chunked_stage_tap(hip_lib, oracle_lib, example, goldens)
 

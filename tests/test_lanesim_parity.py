@@ -47,6 +47,10 @@ def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shif
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
 
+def test_loud_overflows(sim_lib, oracle_lib, example, goldens):
+    pc.case_loud_overflows(sim_lib, oracle_lib, example, goldens)
+
+
 def test_chunked_stage_tap(sim_lib, oracle_lib, example, goldens):
     pc.case_chunked_stage_tap(sim_lib, oracle_lib, example, goldens, n_reads=6)
 

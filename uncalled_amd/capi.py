@@ -398,7 +398,7 @@ class Realtime:
         _check(self.L, self.L.unc_rt_tap_channel(self.h, int(channel), tap.ctypes.data, ring.ctypes.data))
         return tap[0], ring
 
-    def process_chunks(self, chunks, raw_i16=None, raw_ptr=None, stream=None):
+    def process_chunks(self, chunks, raw_i16=None, raw_ptr=None, stream=None, allow_overflow=False):
         """chunks: RT_CHUNK array (at most one per channel); raw: host int16 array or a device address."""
         ch = np.ascontiguousarray(chunks, dtype=RT_CHUNK)
         res = np.zeros(ch.size, dtype=RT_RESULT)
@@ -408,7 +408,7 @@ class Realtime:
             raw = np.ascontiguousarray(raw_i16, dtype=np.int16)
             ptr, on_dev = C.c_void_p(raw.ctypes.data), 0
         _check(self.L, self.L.unc_rt_process_chunks(self.h, ch.size, ch.ctypes.data, ptr, on_dev, C.c_void_p(stream or 0),
-                                                    res.ctypes.data))
+                                                    res.ctypes.data), allow=(UNC_ERR_OVERFLOW,) if allow_overflow else ())
         return res
 
     def process_chunks_f32(self, chunks, signal_f32):
