@@ -119,18 +119,39 @@ __shared__ uint64_t s_cyc[12];   // PROF: shader-clock cycles per phase (lane 0)
 __device__ __forceinline__ uint32_t ctx_get(const uint32_t &f) { return uniform32(f); }
 #define CTX_SET(field, v) do { if (lane == 0) s_w.field = (v); } while (0)
 
+// UNC_PROF_SORT (dev build, tools/dev/build_variants.py sortprof="-DUNC_PROF_SORT=1"): the four counters that normally split
+// phase E (8..11) split phase S instead -- 8 repair of the move streams, 9 sort of the unsorted stream, 10 merge of moves and
+// unsorted, 11 last merge (with its walk, or through memory) -- and phase E's parts go to counter 1.  Read the profiling pass of
+// tools/dev/ab_libs.py with that in mind (the names it prints for 8..11 are phase E's); counter 2 then holds the rest of S.
+#ifndef UNC_PROF_SORT
+#define UNC_PROF_SORT 0
+#endif
 template <bool PROF> struct PhaseClock {
     uint64_t tk;
     __device__ __forceinline__ PhaseClock() : tk(PROF ? (uint64_t)clock64() : 0ull) {}
     __device__ __forceinline__ void reset() { if constexpr (PROF) tk = (uint64_t)clock64(); }
     __device__ __forceinline__ void end(int i, int lane) {
         if constexpr (PROF) {
+            if (UNC_PROF_SORT && i >= 8) i = 1;
             const uint64_t tn = (uint64_t)clock64();
             if (lane == 0) s_cyc[i] += tn - tk;
             tk = tn;
         }
     }
 };
+#if UNC_PROF_SORT
+struct SortClock {          // (counts in both instantiations of the dev build; only the profiling pass reads s_cyc)
+    uint64_t tk;
+    __device__ __forceinline__ SortClock() : tk((uint64_t)clock64()) {}
+    __device__ __forceinline__ void end(int i, int lane) {
+        const uint64_t tn = (uint64_t)clock64();
+        if (lane == 0) { s_cyc[i] += tn - tk; s_cyc[2] -= tn - tk; }       // (the caller adds the whole of S to counter 2 afterwards)
+        tk = tn;
+    }
+};
+#else
+struct SortClock { __device__ __forceinline__ void end(int, int) {} };
+#endif
 
 __device__ __forceinline__ TrackerMem tracker_mem(kargs_t A, gptr_t sb) {
     TrackerMem M;
@@ -505,11 +526,13 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
             // then the unsorted run is sorted and merged with the moves, and the result with the stays while it is walked
             const uint32_t x_off = str_off + 5u * run_bytes;
             uint32_t nviol = 0;
+            SortClock sclk;
             if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt1 -= v; nx += v; } }
             if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt2 -= v; nx += v; } }
             if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt3 -= v; nx += v; } }
             if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt4 -= v; nx += v; } }
             wave_sync();
+            sclk.end(8, lane);
             if (MERGE_REPAIR || nviol == 0) {       // (test build without the repair: an event with such a pair takes the network below)
                 if (nx > 1) {
                     KeyArr<6> KX;
@@ -519,6 +542,7 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
                     sort_any64(sb, KX, x_off, lane);          // in place
                     wave_sync();
                 }
+                sclk.end(9, lane);
                 KeyArr<4> KM;       // the moves, base by base
                 KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
                 KM.n = KM.cum[3] + scnt4;
@@ -534,17 +558,20 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
                     KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
                     KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
                 }
+                sclk.end(10, lane);
                 if (!ctx_get(s_w.bchild)) {
                     merge_walk(A, sb, ka_single(str_off, scnt0), KB, lane);
                     CTX_SET(kl, kl);
                     CTX_SET(walked, 1u);
                     wave_sync();
+                    sclk.end(11, lane);
                     return;
                 }
                 // (an event with a single-row child on a k-mer's boundary row may need the 128-bit keys, which is decided on the
                 // sorted keys below: its keys go through memory)
                 sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, lane, 1u) != 0u;
                 wave_sync();
+                sclk.end(11, lane);
             }
         }
         if (!sorted_ok) {
