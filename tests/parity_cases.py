@@ -396,14 +396,13 @@ def case_cluster_overflow_remap(lib, oracle_lib, example, goldens):
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal), "remap")
 
 
-def case_wide_sort_keys(lib, oracle_lib, example, goldens, monkeypatch):
+def case_wide_sort_keys(lib, oracle_lib, example, goldens, monkeypatch, n=10):
     """References too large for the packed 64-bit sort key (GRCh38-sized: seq_len x k-mer range x 2^16 > 2^64) take
     the 128-bit key path; forced here through UNC_WIDE_KEYS on the small index."""
     monkeypatch.setenv("UNC_WIDE_KEYS", "1")
     ix = capi.Index(example["prefix"], lib=lib)
     monkeypatch.delenv("UNC_WIDE_KEYS", raising=False)
     oix = oracle_lib.Index(example["prefix"])
-    n = 10
     off = goldens["sim_offsets"][:n + 1].copy()
     raw = goldens["sim_signal"][:int(off[n])]
     cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)

@@ -27,7 +27,7 @@ def _worker(rank, world, port, out_dir):
     from uncalled_amd import capi
     lib = capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
     gold = np.load(ROOT / "tests" / "golden" / "ref_goldens.npz")
-    n = 8
+    n = 6
     off = gold["sim_offsets"][:n + 1]
     a, b = _split(n, rank, world)
     ix = capi.Index(ROOT / "tests" / "golden" / "example_index" / "example_ref", lib=lib)   # index replicated per rank
@@ -50,7 +50,7 @@ def test_two_rank_sharded_mapping_matches_single_rank(sim_lib, goldens, tmp_path
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
     from uncalled_amd import capi
-    n = 8
+    n = 6
     off = goldens["sim_offsets"][:n + 1].copy()
     ix = capi.Index(ROOT / "tests" / "golden" / "example_index" / "example_ref", lib=sim_lib)
     single = capi.Mapper(ix, n_slots=2).map_batch(goldens["sim_signal"][:int(off[n])], off,
