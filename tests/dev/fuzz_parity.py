@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Dev checker (CPU): randomised parity of the kernel sources under the lanesim emulator against the oracle -- random reads
+(length, noise, dwell, off-target share) on the example index and on a small synthetic reference, random parameter sets drawn
+around the defaults, random mapper geometry (slots, slice length, wavefronts, tiny pools).  Everything is seeded: a failure
+prints the seed that reproduces it.
+
+    python tests/dev/fuzz_parity.py [n_rounds] [first_seed]"""
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle import pyoracle as po  # noqa: E402
+from tests.helpers import assert_hits_equal, oracle_hits, to_oracle_params  # noqa: E402
+from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE, simulate_reads  # noqa: E402
+from uncalled_amd import capi  # noqa: E402
+from uncalled_amd.build_index import build_from_codes, encode_contigs, read_fasta, synthetic_genome  # noqa: E402
+
+L = capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
+G = ROOT / "tests" / "golden"
+
+
+def refs(tmp):
+    ex = G / "example_index" / "example_ref"
+    names, _, seqs = read_fasta(str(ex) + ".fa")
+    out = [(ex, encode_contigs(seqs)[0], [len(s) for s in seqs])]
+    n2, l2, c2 = synthetic_genome(3, 60000, seed=77)
+    pre = Path(tmp) / "fz"
+    build_from_codes(pre, n2, [""] * 3, l2, c2)
+    Path(str(pre) + ".uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
+    out.append((pre, c2, l2))
+    return out
+
+
+def draw_params(rng):
+    p = capi.default_params(L)
+    if rng.random() < 0.7:
+        p.max_paths = int(rng.choice([60, 150, 400, 1000, 10000]))
+        p.max_consec_stay = int(rng.integers(2, 12))
+        p.max_rep_copy = int(rng.integers(1, 65))
+        p.min_rep_len = int(rng.integers(0, 15))
+        p.max_stay_frac = float(rng.uniform(0.2, 0.7))
+        p.min_seed_prob = float(rng.uniform(-4.2, -3.0))
+        p.max_events = int(rng.choice([200, 600, 2000, 30000]))
+        p.min_map_len = int(rng.integers(12, 40))
+        p.min_mean_conf = float(rng.uniform(2.0, 8.0))
+        p.min_top_conf = float(rng.uniform(1.1, 2.5))
+        p.threshold1 = float(rng.uniform(1.2, 1.8))
+        p.threshold2 = float(rng.uniform(7.0, 10.0))
+        p.peak_height = float(rng.uniform(0.1, 0.4))
+    return p
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(prefix="unc_fuzz_") as tmp:
+        R = refs(tmp)
+        idx = [(capi.Index(pre, lib=L), po.Index(pre), codes, lens) for pre, codes, lens in R]
+        n_reads_total = 0
+        for k in range(rounds):
+            seed = seed0 + k
+            rng = np.random.default_rng(seed)
+            dix, oix, codes, lens = idx[int(rng.integers(0, len(idx)))]
+            n = int(rng.integers(2, 6))
+            sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1800)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
+                                 dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))
+            p = draw_params(rng)
+            n_waves = int(rng.integers(1, 3))
+            kw = dict(n_waves=n_waves, n_slots=n_waves * int(rng.integers(1, 4)), slice_events=int(rng.choice([0, 13, 64, 1024])))
+            if rng.random() < 0.3:
+                kw["pool_chunks"] = int(rng.integers(1, 4))
+            if rng.random() < 0.2:
+                kw["max_clusters"] = int(rng.choice([8, 64]))
+            cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+            try:
+                hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal)
+                want = oracle_hits(oix, sim["signal"], sim["offsets"], cal, to_oracle_params(p), fresh_mapper_per_read=True)
+                assert_hits_equal(hits, want, f"seed {seed}")
+            except Exception as e:
+                print(f"FAILED at seed {seed}: {kw} max_paths={p.max_paths} max_events={p.max_events}: {e!r}"[:600], flush=True)
+                return 1
+            n_reads_total += n
+            print(f"seed {seed}: {n} reads ok ({kw}, max_paths {p.max_paths}, mapped {int(hits['mapped'].sum())}) [{time.time() - t0:.0f} s]", flush=True)
+    print(f"{rounds} rounds, {n_reads_total} reads: device == oracle")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
