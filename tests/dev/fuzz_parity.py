@@ -4,7 +4,7 @@
 around the defaults, random mapper geometry (slots, slice length, wavefronts, tiny pools).  Everything is seeded: a failure
 prints the seed that reproduces it.
 
-    python tests/dev/fuzz_parity.py [n_rounds] [first_seed]"""
+    python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path)"""
 import sys
 import tempfile
 import time
@@ -55,9 +55,50 @@ def draw_params(rng):
     return p
 
 
+def rt_round(seed, dix, oix, codes, lens):
+    """chunked path: random reads over 1-3 channels, random chunk length / max_chunks / parameters, per channel in order"""
+    from uncalled_amd.realtime import MapPoolOrd
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 6))
+    sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1500)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
+                         dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))
+    p = draw_params(rng)
+    chunk_len = int(rng.choice([1000, 2000, 4000, 8000]))
+    p.chunk_time = chunk_len / p.sample_rate
+    max_chunks = int(rng.choice([1, 2, 3, 1000000]))
+    p.max_chunks = max_chunks
+    n_ch = int(rng.integers(1, 4))
+    pool = MapPoolOrd(dix, n_channels=n_ch, params=p)
+    oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_ch)]
+    for om in oms:
+        om.set_max_chunks(max_chunks)
+    want, got = {}, {}
+    off = sim["offsets"]
+    cal = (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    for i in range(n):
+        raw = sim["signal"][int(off[i]):int(off[i + 1])]
+        pool.add_read(i % n_ch, i, raw, cal, key=i)
+        want[i] = oms[i % n_ch].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+    rounds = 0
+    while pool.running():
+        for key, r in pool.update():
+            got[key] = r
+        rounds += 1
+        assert rounds < 5000
+    names = dix.seq_names()
+    for i in range(n):
+        h, o = got[i]["hit"], want[i]
+        assert int(h["status"]) == 0, (i, int(h["status"]))
+        assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), (i, capi.hit_paf_cols(h, names), po.hit_paf_cols(o, oix.ref_names()))
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+            assert int(h[f]) == int(o[f]), (i, f, int(h[f]), int(o[f]))
+    return n, f"{n_ch} channels, chunks of {chunk_len}, max_chunks {max_chunks}, max_paths {p.max_paths}"
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    rt = len(sys.argv) > 3 and sys.argv[3] == "rt"
     t0 = time.time()
     with tempfile.TemporaryDirectory(prefix="unc_fuzz_") as tmp:
         R = refs(tmp)
@@ -67,6 +108,15 @@ def main():
             seed = seed0 + k
             rng = np.random.default_rng(seed)
             dix, oix, codes, lens = idx[int(rng.integers(0, len(idx)))]
+            if rt:
+                try:
+                    n, what = rt_round(seed, dix, oix, codes, lens)
+                except Exception as e:
+                    print(f"FAILED (chunked path) at seed {seed}: {e!r}"[:700], flush=True)
+                    return 1
+                n_reads_total += n
+                print(f"seed {seed}: {n} reads ok ({what}) [{time.time() - t0:.0f} s]", flush=True)
+                continue
             n = int(rng.integers(2, 6))
             sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1800)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
                                  dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))

@@ -329,6 +329,63 @@ def case_chunked_stage_tap(lib, oracle_lib, example, goldens, n_reads=8):
     assert done == n_reads and int(tb["norm_n"]) == 6000       # (the ring has wrapped by then)
 
 
+CARRY_OVER_PARAMS = dict(max_paths=60, max_rep_copy=2, max_chunks=2)      # with chunks of 8000 samples
+
+
+def carry_over_data(tmp_path):
+    """the reference and reads of tests/dev/fuzz_parity.py's seed 5007 (chunked mode): (index prefix, simulated reads, n)"""
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
+    from tools.simulate_reads import simulate_reads
+    names, lens, codes = synthetic_genome(3, 60000, seed=77)
+    prefix = tmp_path / "fz"
+    build_from_codes(prefix, names, [""] * 3, lens, codes)
+    (tmp_path / "fz.uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
+    rng = np.random.default_rng(5007)
+    n = int(rng.integers(2, 6))
+    sim = simulate_reads(codes, lens, n, seed=5007, read_bases=int(rng.integers(300, 1500)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
+                         dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))
+    assert n == 4
+    return prefix, sim, n
+
+
+def case_chunked_flags_carry_over(lib, oracle_lib, tmp_path):
+    """A channel is one Mapper, and Mapper::new_read does not clear sources_added_ (mapper.cpp:88,612-623: the flags are only
+    cleared in a branch a full path buffer never reaches).  With a small max_paths a read therefore sees the flags its
+    predecessor on the channel left behind; the chunked path reproduces that (found by tests/dev/fuzz_parity.py, seed 5007: the
+    fourth read of a channel did two get_neighbor calls more when the flags were cleared).  Reads of the fuzz case, one channel;
+    the scenario is checked to be one where the carry-over matters (a fresh Mapper per read answers differently)."""
+    from uncalled_amd.realtime import MapPoolOrd
+    po = oracle_lib
+    prefix, sim, n = carry_over_data(tmp_path)
+    ix = capi.Index(prefix, lib=lib)
+    oix = po.Index(prefix)
+    p = capi.default_params(lib)
+    p.max_paths, p.max_rep_copy, p.max_chunks, p.chunk_time = 60, 2, 2, 8000 / p.sample_rate
+    pool = MapPoolOrd(ix, n_channels=1, params=p)
+    om = po.Mapper(oix, to_oracle_params(p))
+    om.set_max_chunks(2)
+    off = sim["offsets"]
+    cal = (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    want, alone = [], []
+    for i in range(n):
+        raw = sim["signal"][int(off[i]):int(off[i + 1])]
+        pool.add_read(0, i, raw, cal, key=i)
+        want.append(om.chunk_read(po.calibrate(raw, *cal), 8000)[0])
+        fresh = po.Mapper(oix, to_oracle_params(p))
+        fresh.set_max_chunks(2)
+        alone.append(fresh.chunk_read(po.calibrate(raw, *cal), 8000)[0])
+    got = {}
+    while pool.running():
+        for key, r in pool.update():
+            got[key] = r["hit"]
+    names_dev = ix.seq_names()
+    for i in range(n):
+        assert capi.hit_paf_cols(got[i], names_dev) == po.hit_paf_cols(want[i], oix.ref_names()), i
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+            assert int(got[i][f]) == int(want[i][f]), (i, f)
+    assert any(int(want[i]["n_nbr"]) != int(alone[i]["n_nbr"]) or int(want[i]["event_i"]) != int(alone[i]["event_i"]) for i in range(1, n))
+
+
 def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, n_reads=9, max_chunks=None, long_read=False):
     """Config 5's path: reads replayed chunk by chunk over a few channels (MapPoolOrd semantics) through
     unc_rt_process_chunks; per-channel state persists across chunks AND reads.  Checked against the oracle fed the

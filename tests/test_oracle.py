@@ -272,6 +272,36 @@ def test_chunked_stage_tap_equals_live_reference(oracle_lib, ref_lib, example, g
     assert int(a["norm_n"]) == 6000
 
 
+def test_chunked_flags_carry_over_equals_live_reference(oracle_lib, tmp_path):
+    """sources_added_ survives Mapper::new_read: with a small max_paths the reads of one channel influence each other.  The
+    oracle against the reference on the scenario where that changes the work counters (tests/parity_cases.py carry_over_data).
+    In a process of its own: the reference keeps its index in statics, and this case needs another one than the other tests."""
+    import subprocess
+    import sys
+    from oracle import pyref
+    if not pyref.available():
+        pytest.skip("oracle/_ref not built")
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from pathlib import Path\n"
+        "from oracle import pyoracle as po, pyref as pr\n"
+        "from tests.parity_cases import carry_over_data, CARRY_OVER_PARAMS, variant_params\n"
+        "from tools.simulate_reads import CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION\n"
+        "prefix, sim, n = carry_over_data(Path(%r))\n"
+        "p = variant_params(po.default_params(), {k: v for k, v in CARRY_OVER_PARAMS.items() if k != 'max_chunks'})\n"
+        "pr.init(prefix); pr.set_params(p); pr.lib().ref_set_max_chunks(2)\n"
+        "ix = po.Index(prefix); om = po.Mapper(ix, p); om.set_max_chunks(2); rm = pr.Mapper()\n"
+        "off = sim['offsets']\n"
+        "for i in range(n):\n"
+        "    sig = po.calibrate(sim['signal'][int(off[i]):int(off[i + 1])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)\n"
+        "    (h, hu), (r, ru) = om.chunk_read(sig, 8000), rm.chunk_read(sig, 8000, i)\n"
+        "    assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), i\n"
+        "    assert (hu, int(h['event_i']), int(h['n_nbr']), int(h['n_sa']), int(h['n_lf'])) == (ru, r.event_i, r.n_nbr, r.n_sa, r.n_lf), i\n"
+        "print('CARRY_OVER_OK')\n") % (str(Path(__file__).resolve().parents[1]), str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "CARRY_OVER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
 def test_chunked_path_variants_equal_live_reference(oracle_lib, ref_lib, example, goldens):
     """The chunked path of the oracle against the reference's (Mapper::new_read(Chunk&) / add_chunk / process_chunk / map_chunk)
     on the parameter sets and chunk lengths of tests/parity_cases.py CHUNK_VARIANTS, reads one after the other on ONE Mapper."""

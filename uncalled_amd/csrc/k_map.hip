@@ -1168,7 +1168,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;
-            if (lane < NKMER / 32) s_flags[lane] = 0;
+            // sources_added_ is NOT cleared by Mapper::new_read / reset (mapper.cpp:88,219-246,612-623): a channel is one Mapper, and the
+            // flags a read leaves behind when its path buffer was full (the else-branch that clears them was not reached) are seen by
+            // the channel's next read.  Deterministic per channel, so the chunked path reproduces it (the slot starts zeroed).
+            if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
         } else {
             if (!sliced) {
                 uint32_t t = 0;
