@@ -171,9 +171,9 @@ def cpu_baseline(prefix, raw_host, offsets, calib, hits_gpu, budget_s=80.0, swee
         out["paf_mismatch_reads"] = mism[:16]
     out["tie_order_note"] = ("children tying on (fm_range, seed_prob) are ordered by creation in oracle and kernels alike; "
                              "upstream's unstable pdqsort (mapper.cpp:531) is not available here, oracle/shim uses std::stable_sort")
-    out["sources_added_note"] = ("sources_added_ starts clear for every read on the device; the reference leaks it from one read to the next "
-                                 "on the same thread (mapper.cpp:88,547,612-623), which only matters after a read that filled max_paths and is "
-                                 "order-dependent with -t > 1")
+    out["sources_added_note"] = ("sources_added_ starts clear for every read on the batch path; the reference leaks it from one read to the "
+                                 "next on the same thread (mapper.cpp:88,547,612-623), which only matters after a read that filled max_paths and "
+                                 "is order-dependent with -t > 1 (the chunked path, where a channel is one Mapper, reproduces the carry-over)")
     return out
 
 
