@@ -20,7 +20,8 @@ from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE, simula
 from uncalled_amd import capi  # noqa: E402
 from uncalled_amd.build_index import build_from_codes, encode_contigs, read_fasta, synthetic_genome  # noqa: E402
 
-L = capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
+import os
+L = capi.load(os.environ.get("UNC_FUZZ_LIB") or (ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so"))
 G = ROOT / "tests" / "golden"
 
 

@@ -329,17 +329,45 @@ def case_chunked_stage_tap(lib, oracle_lib, example, goldens, n_reads=8):
     assert done == n_reads and int(tb["norm_n"]) == 6000       # (the ring has wrapped by then)
 
 
+def fuzz_reference(tmp_path):
+    """the second reference of tests/dev/fuzz_parity.py: three contigs of 60 kb, loose thresholds (many children per event)"""
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
+    names, lens, codes = synthetic_genome(3, 60000, seed=77)
+    prefix = tmp_path / "fz"
+    if not (tmp_path / "fz.sa").exists():
+        build_from_codes(prefix, names, [""] * 3, lens, codes)
+        (tmp_path / "fz.uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
+    return prefix, codes, lens
+
+
+def case_unsorted_stream_past_one_block(lib, oracle_lib, tmp_path):
+    """max_paths = 1000 with events of many children of sources: the unsorted key stream holds more than 512 keys and is sorted IN
+    PLACE in room for exactly max_paths keys.  Round 3's first form of that sort stored whole 512-key blocks, padding included, i.e.
+    past the stream's end into the children's info words (found by tests/dev/fuzz_parity.py, seed 2085: a read unmapped that the
+    reference maps; the emulator's bounds checks, UNC_SIM_CHECK, now fail on such a store).  The fuzz case, against the oracle."""
+    from tools.simulate_reads import simulate_reads
+    prefix, codes, lens = fuzz_reference(tmp_path)
+    sim = simulate_reads(codes, lens, 4, seed=2085, read_bases=490, off_target=0.0, dwell_mean=11.29495188046118, noise_sd=1.030862943416349)
+    p = capi.default_params(lib)
+    for k, v in dict(min_rep_len=1, max_rep_copy=28, max_paths=1000, max_consec_stay=2, max_events=2000, max_stay_frac=0.4174584150314331,
+                     min_seed_prob=-4.121715545654297, threshold1=1.4309371709823608, threshold2=9.04516315460205,
+                     peak_height=0.31874945759773254, min_map_len=27, min_mean_conf=7.31113862991333, min_top_conf=1.9158369302749634).items():
+        setattr(p, k, v)
+    cal = capi.make_calib(4, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    ix = capi.Index(prefix, lib=lib)
+    hits = capi.Mapper(ix, params=p, n_slots=2, n_waves=2).map_batch(sim["signal"], sim["offsets"], cal)
+    want = oracle_hits(oracle_lib.Index(prefix), sim["signal"], sim["offsets"], cal, to_oracle_params(p), fresh_mapper_per_read=True)
+    assert_hits_equal(hits, want, "unsorted stream of more than one block")
+    assert int(hits["mapped"].sum()) == 2 and (hits["n_nbr"] / np.maximum(hits["event_i"], 1)).min() > 400
+
+
 CARRY_OVER_PARAMS = dict(max_paths=60, max_rep_copy=2, max_chunks=2)      # with chunks of 8000 samples
 
 
 def carry_over_data(tmp_path):
     """the reference and reads of tests/dev/fuzz_parity.py's seed 5007 (chunked mode): (index prefix, simulated reads, n)"""
-    from uncalled_amd.build_index import build_from_codes, synthetic_genome
     from tools.simulate_reads import simulate_reads
-    names, lens, codes = synthetic_genome(3, 60000, seed=77)
-    prefix = tmp_path / "fz"
-    build_from_codes(prefix, names, [""] * 3, lens, codes)
-    (tmp_path / "fz.uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
+    prefix, codes, lens = fuzz_reference(tmp_path)
     rng = np.random.default_rng(5007)
     n = int(rng.integers(2, 6))
     sim = simulate_reads(codes, lens, n, seed=5007, read_bases=int(rng.integers(300, 1500)), off_target=float(rng.choice([0.0, 0.3, 1.0])),

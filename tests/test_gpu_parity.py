@@ -62,6 +62,10 @@ def test_loud_overflows(hip_lib, oracle_lib, example, goldens):
     pc.case_loud_overflows(hip_lib, oracle_lib, example, goldens)
 
 
+def test_unsorted_stream_past_one_block(hip_lib, oracle_lib, tmp_path):
+    pc.case_unsorted_stream_past_one_block(hip_lib, oracle_lib, tmp_path)
+
+
 def test_chunked_flags_carry_over(hip_lib, oracle_lib, tmp_path):
     pc.case_chunked_flags_carry_over(hip_lib, oracle_lib, tmp_path)
 

@@ -521,6 +521,18 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
         uint32_t scnt0 = ctx_get(s_w.scnt[0]), scnt1 = ctx_get(s_w.scnt[1]), scnt2 = ctx_get(s_w.scnt[2]), scnt3 = ctx_get(s_w.scnt[3]),
                  scnt4 = ctx_get(s_w.scnt[4]), nx = ctx_get(s_w.scnt[5]);
         bool sorted_ok = false;
+#ifdef LANESIM
+        {   // emulator only: every key phase E filed names a child of this event, and the runs hold all of them
+            const uint32_t cnt[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
+            uint32_t tot = 0;
+            for (uint32_t r = 0; r < 6; ++r) {
+                tot += cnt[r];
+                for (uint32_t i = (uint32_t)lane; i < cnt[r]; i += WAVE)
+                    UNC_SIM_CHECK((gld<uint64_t>(sb, str_off + r * run_bytes + (i << 3)) & 0xFFFFu) < n);
+            }
+            UNC_SIM_CHECK(tot == n);
+        }
+#endif
         if (n > MERGE_MIN && !ctx_get(s_w.par_unsorted)) {
             // moves of one base: ascending but for the odd pair of nested parents (repair_run moves those to the unsorted run);
             // then the unsorted run is sorted and merged with the moves, and the result with the stays while it is walked
@@ -691,6 +703,7 @@ __device__ __forceinline__ void walk_core(const WalkConst<NARROW> &C, WalkState<
     using Row = typename WalkState<NARROW>::Row;
     const uint32_t n = C.n, room = C.room;
     const uint32_t idx = (uint32_t)(sb_ >> 16) & 0xFFFFu;
+    UNC_SIM_CHECK(!(have && !dup) || idx < n);
     uint32_t pk = (uint32_t)__shfl_up((int)kmer, 1);
     if (lane == 0) pk = S.carry_kmer;
     const bool first = have && kmer != pk;              // source_kmer != prev_kmer, :543
@@ -909,6 +922,14 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
             if (c < cnt) s_tile[mslot(1u + d + c)] = o[c];
         if (lane == 0 && have_pend) s_tile[mslot(0)] = pend_key;
         wave_sync();
+#ifdef LANESIM
+        for (uint32_t q = 1u + (uint32_t)lane; q <= tn; q += WAVE) {       // emulator only: the tile holds keys of this event's children
+            const uint64_t kq = s_tile[mslot(q)];
+            UNC_SIM_CHECK((kq & 0xFFFFu) < n);
+            UNC_SIM_CHECK(((infow[kq & 0xFFFFu] >> 16) & 0xFFFFu) == (kq & 0xFFFFu));
+        }
+        wave_sync();
+#endif
         // ---- the walk over logical positions [p0, p1): a key's successor sits one position on (none after the last key of all)
         const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
         uint64_t bq0 = 0, bq1 = 0;

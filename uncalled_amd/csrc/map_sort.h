@@ -269,8 +269,13 @@ static __device__ __noinline__ void sort_hybrid64(gptr_t sb_, KeyArr<6> K_, uint
         }
         block_sort64<E>(a, lane);
         wave_sync();                                          // (in place: the block is loaded before any of it is stored)
+        // only positions < n are ever stored or loaded: the output may be a run of exactly n keys' room (the unsorted stream sorted
+        // in place), and the padding of a sorted block sits behind its real keys
 #pragma unroll
-        for (int e = 0; e < E; ++e) out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+            if (i < n) out[i] = a[e];
+        }
     }
     wave_sync();
     for (uint32_t k = 2 * B; k <= N; k <<= 1) {
@@ -317,15 +322,17 @@ static __device__ __noinline__ void sort_hybrid64(gptr_t sb_, KeyArr<6> K_, uint
             uint64_t b2[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                a[e] = out[base + (uint32_t)lane * E + (uint32_t)e];
-                b2[e] = two ? out[base + B + (uint32_t)lane * E + (uint32_t)e] : ~0ull;
+                const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+                a[e] = i < n ? out[i] : ~0ull;
+                b2[e] = i + B < n ? out[i + B] : ~0ull;
             }
             asc_stages64<E>(a, B >> 1, lane);
             if (two) asc_stages64<E>(b2, B >> 1, lane);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                out[base + (uint32_t)lane * E + (uint32_t)e] = a[e];
-                if (two) out[base + B + (uint32_t)lane * E + (uint32_t)e] = b2[e];
+                const uint32_t i = base + (uint32_t)lane * E + (uint32_t)e;
+                if (i < n) out[i] = a[e];
+                if (i + B < n) out[i + B] = b2[e];
             }
         }
         wave_sync();

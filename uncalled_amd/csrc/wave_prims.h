@@ -4,6 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Invariants that only the CPU emulator of the tests checks (tests/lanesim defines LANESIM): an index about to be used for a store
+// lies inside the buffer it addresses.  Compiled out of the gfx950 build.
+#ifdef LANESIM
+#include <cassert>
+#define UNC_SIM_CHECK(c) assert(c)
+#else
+#define UNC_SIM_CHECK(c) ((void)0)
+#endif
+
 namespace unc {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
