@@ -4,7 +4,7 @@
 around the defaults, random mapper geometry (slots, slice length, wavefronts, tiny pools).  Everything is seeded: a failure
 prints the seed that reproduces it.
 
-    python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path)"""
+    python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path; wide: the batch path with 128-bit sort keys)"""
 import sys
 import tempfile
 import time
@@ -104,6 +104,10 @@ def main():
     with tempfile.TemporaryDirectory(prefix="unc_fuzz_") as tmp:
         R = refs(tmp)
         idx = [(capi.Index(pre, lib=L), po.Index(pre), codes, lens) for pre, codes, lens in R]
+        if len(sys.argv) > 3 and sys.argv[3] == "wide":      # the 128-bit-key instantiation (human-sized references) on the small ones
+            os.environ["UNC_WIDE_KEYS"] = "1"
+            idx = [(capi.Index(pre, lib=L), oix, codes, lens) for (pre, codes, lens), (_, oix, _, _) in zip(R, idx)]
+            del os.environ["UNC_WIDE_KEYS"]
         n_reads_total = 0
         for k in range(rounds):
             seed = seed0 + k
