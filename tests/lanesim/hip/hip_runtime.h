@@ -172,6 +172,7 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     return __lanesim_shfl_abs(v, __lanesim_lane() ^ mask);
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __lanesim_shfl_abs(v, 0); }
+static inline int __builtin_amdgcn_readlane(int v, int src) { return __lanesim_shfl_abs(v, src); }   // (src: wave-uniform)
 // v_mov_b32_dpp as the kernels use it (row_shr:n, row_shl:n, row_bcast:15, row_bcast:31, wave_shr:1, wave_shl:1).  A lane whose
 // source does not exist (or whose row / bank is masked off) keeps an undefined destination on the hardware when
 // bound_ctrl is clear: the emulator hands such lanes a poison value, so that a kernel relying on it fails its parity test.

@@ -1076,14 +1076,12 @@ static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane
         }
         wave_sync();
         clk.end(5, lane);
-        // SeedTracker::add_seed in the reference's order = task order (seed paths in list order, their rows ascending)
+        // SeedTracker::add_seed with the reference's outcome: task order = seed paths in list order, their rows ascending; one lane
+        // per seed, seeds that cannot see each other together (map_tracker.h)
         for (uint32_t t0 = 0; t0 < ttot && !T.status; t0 += WAVE) {
             const uint32_t nt = ttot - t0 < WAVE ? ttot - t0 : WAVE;
             const uint64_t mine = (uint32_t)lane < nt ? gld<uint64_t>(sb, tasks_off + ((t0 + (uint32_t)lane) << 3)) : 0ull;
-            for (uint32_t j = 0; j < nt; ++j) {
-                const uint64_t v = uniform64(bcast64(mine, (int)j));     // scalar, as every argument of add_seed must be
-                add_seed(T, TM, p_min_map_len, v & ((1ull << 40) - 1ull), (uint32_t)(v >> 56), (uint32_t)(v >> 40) & 0xFFFFu, lane);
-            }
+            add_seeds(T, TM, p_min_map_len, mine, nt, lane);
         }
         clk.end(6, lane);
     }

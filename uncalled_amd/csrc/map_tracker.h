@@ -15,16 +15,16 @@ struct Tracker {
 // at the first cluster that lies more than `event` rows back (seed_tracker.cpp:169-191: in_range needs r2 - r1 <= e2 - e1 <=
 // e2, a cluster further back is never a candidate and ends the scan).  Inside that window the scan's outcome does not depend
 // on any order but the set's own tie-break (among equally long candidates the first in set order), so a bucket is an UNORDERED
-// array: nodes of NODE_K = 5 clusters (hot key 16 B + cold part 32 B each, 256 B) chained from a per-read table of bucket heads.  A seed
-// costs the heads of its window's buckets (one coalesced load), their nodes (one load, one lane per cluster) and a store;
+// array: nodes of NODE_K = 5 clusters (hot key 16 B + cold part 32 B each, 256 B) chained from a per-read table of bucket heads.
 // insert = append, erase = move the node's last cluster into the hole.  No directory, nothing to shift, nothing to split.
-// The bucket width (DevIndex::bucket_shift) is set per index: at least 2^12 rows (a window of the default max_events spans at
-// most 9 buckets; 12 are gathered at once) and at most 2^15 buckets per read (a bucket costs a node of 256 bytes once it is used).  (Rounds 1-2: a sorted array, then a two-level B+-tree whose
-// directory search, leaf load and leaf shift were three to five dependent memory round trips per seed.)
+// Round 4: the seeds of an event are added ONE LANE PER SEED (add_seeds below) -- a lane walks its seed's window by itself, and
+// seeds whose windows share no bucket are added in the same round -- where round 3 added them one after the other, the whole
+// wavefront gathering one seed's window (lane = bucket x slot) with three to five dependent round trips per seed.
+// The bucket width (DevIndex::bucket_shift) is set per index: at least 2^BUCKET_SHIFT_MIN rows and at most 2^15 buckets per
+// read (a bucket costs a node of 256 bytes once it is used).  (Rounds 1-2: a sorted array, then a two-level B+-tree.)
 constexpr uint32_t NODE_HOT_OFF = 16, NODE_COLD_OFF = 16 + NODE_K * 16;      // (NODE_K = 5 clusters in 256 bytes: unc_dev_types.h)
-constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 struct alignas(16) NodeHdr { uint32_t count, next, pad0, pad1; };            // next: node id + 1 (0: end of the chain)
-static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES && WIN_BUCKETS * NODE_K <= WAVE, "node layout");
+static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES, "node layout");
 static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32, "seed-cluster record layout");
 struct PoolView {          // DevPool with its arrays typed as global memory
     gptr_t nodes;
@@ -40,27 +40,6 @@ struct TrackerMem {
     uint32_t n_buckets, shift;
     PoolView pool;         // nodes
 };
-
-// A fresh node for this read: the next one of its newest chunk, or the first of a chunk popped off the pool's ring.
-// NODE_NONE when the read has used up its allowance or the pool has run dry (the read then overflows and is mapped again later).
-__device__ __forceinline__ uint32_t tracker_new_node(Tracker &T, const TrackerMem &M, int lane) {
-    const uint32_t a = T.n_alloc;
-    if (a >= M.max_nodes) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return NODE_NONE; }
-    uint32_t chunk;
-    if (a % CHUNK_NODES == 0) {
-        uint32_t c = SCHED_EMPTY;
-        if (lane == 0) {
-            c = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
-            if (c != SCHED_EMPTY) gst(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2), c);
-        }
-        chunk = bcast32(c, 0);
-        if (chunk == SCHED_EMPTY) { T.status |= UNC_READ_CLUSTER_OVERFLOW | UNC_READ_POOL_DRY; return NODE_NONE; }
-    } else {
-        chunk = uniform32(gld<uint32_t>(M.sb, M.off_chunks + ((a / CHUNK_NODES) << 2)));
-    }
-    T.n_alloc = a + 1;
-    return chunk * CHUNK_NODES + a % CHUNK_NODES;
-}
 
 // the read is over: its chunks go back to the pool
 __device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
@@ -90,26 +69,6 @@ __device__ __forceinline__ void lens_replace(Tracker &T, uint32_t p, uint32_t q)
     else { if (q > T.max1) { T.max2 = T.max1; T.max1 = q; } else if (q > T.max2) T.max2 = q; }
 }
 
-__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, d); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
-    return v;
-}
-
-// one cluster as add_seed carries it between the gather and the commit (all fields uniform)
-struct ClusterRef { uint32_t found, node, slot, cnt, next, tl, e; uint64_t r; };
-// the lane `src` holds the cluster: its fields to every lane
-__device__ __forceinline__ ClusterRef cluster_ref(uint32_t node, uint32_t slot, const NodeHdr &h, const ClusterKey &k, int src) {
-    ClusterRef c;
-    c.found = 1; c.node = bcast32(node, src); c.slot = bcast32(slot, src); c.cnt = bcast32(h.count, src); c.next = bcast32(h.next, src);
-    c.tl = bcast32(k.total_len, src); c.e = bcast32(k.evt_en, src); c.r = bcast64(k.rstart, src);
-    return c;
-}
 __device__ __forceinline__ gptr_t node_ptr(const TrackerMem &M, uint32_t node) { return M.pool.nodes + (size_t)node * NODE_BYTES; }
 __device__ __forceinline__ void node_store(const TrackerMem &M, uint32_t node, uint32_t slot, const ClusterKey &k, const ClusterCold &c) {
     const gptr_t p = node_ptr(M, node);
@@ -121,173 +80,240 @@ __device__ __forceinline__ void node_hdr_store(const TrackerMem &M, uint32_t nod
     gst(node_ptr(M, node), 0u, h);
 }
 
-// SeedTracker::add_seed, seed_tracker.cpp:157-232 (wave-cooperative; all arguments uniform; stores by lane 0)
-static __device__ void add_seed(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t ref_en, uint32_t ref_len, uint32_t evt, int lane) {
-    if (T.status) return;
-    const uint64_t r2 = ref_en - ref_len + 1;   // new_seed.ref_en_.start_ (= ref_st_)
-    const uint32_t e2 = evt;
+// What one lane has found out about its seed's window: the candidates of seed_tracker.cpp:169-191 reduced to the few the outcome
+// depends on.  A cluster of the window is ranked by re = (0xFFFF - (r2 - r1)) << 16 | e1: larger = earlier in set order
+// (ref_en_.start descending, evt_en_ descending; both differences fit 16 bits because max_events <= 65535).
+struct SeedScan {
+    uint32_t best_found, best_tl, best_re, best_node, best_sc, best_next;   // best-supported near candidate (sc = slot | node count << 8)
+    uint32_t f0_found, f0_tl, f0_node, f0_sc, f0_next;                      // the cluster exactly e2 rows back with evt_en 0, if there is one
+    uint32_t f_other;                                                       // another cluster sits exactly e2 rows back (it ends the scan first)
+    uint32_t exists;                                                        // an equivalent key (r2, e2) is in the set
+    uint32_t lb_have, lb_re;                                                // key at lower_bound(seed): the first in set order not before the seed
+    uint32_t ins_node, ins_cnt, ins_next;                                   // a node of the seed's own bucket with room (id + 1)
+    uint32_t head0;                                                         // head of the seed's own bucket
+};
 
-    // ---- gather: the buckets that hold starts in [r2 - e2, r2], highest first; lane = (bucket j, slot s) of the bucket's current node
+// the window of one seed, walked by ONE lane: buckets from the seed's own downwards, every node of their chains (header + NODE_K
+// hot keys = one contiguous piece of the node), all comparisons in the lane's own registers.  The next bucket's head is
+// requested before the current chain is walked.
+__device__ __forceinline__ void seed_scan(const TrackerMem &M, uint64_t r2, uint32_t e2, uint32_t b_hi, uint32_t b_lo, SeedScan &S) {
+    S.best_found = S.best_tl = S.best_re = S.best_node = S.best_sc = S.best_next = 0;
+    S.f0_found = S.f0_tl = S.f0_node = S.f0_sc = S.f0_next = 0;
+    S.f_other = S.exists = S.lb_have = S.lb_re = 0;
+    S.ins_node = S.ins_cnt = S.ins_next = 0;
+    uint32_t node1 = gld<uint32_t>(M.sb, M.off_heads + (b_hi << 2));      // node id + 1
+    S.head0 = node1;
+    for (uint32_t b = b_hi;;) {
+        const uint32_t head_nxt = b > b_lo ? gld<uint32_t>(M.sb, M.off_heads + ((b - 1u) << 2)) : 0u;
+        while (node1) {
+            const cgptr_t p = node_ptr(M, node1 - 1u);
+            const NodeHdr h = gld<NodeHdr>(p, 0u);
+            ClusterKey k[NODE_K];
+#pragma unroll
+            for (uint32_t s = 0; s < NODE_K; ++s) k[s] = gld<ClusterKey>(p, NODE_HOT_OFF + (s << 4));
+#pragma unroll
+            for (uint32_t s = 0; s < NODE_K; ++s) {
+                const uint64_t r1 = k[s].rstart;
+                const uint32_t e1 = k[s].evt_en, tl = k[s].total_len;
+                // not before the seed in set order, and not further back than e2 rows
+                if (s < h.count && r1 <= r2 && !(r1 == r2 && e1 > e2) && (r2 - r1) <= (uint64_t)e2) {
+                    const uint32_t dr = (uint32_t)(r2 - r1);
+                    const uint32_t re = ((0xFFFFu - dr) << 16) | e1;
+                    if (dr == 0u && e1 == e2) S.exists = 1u;
+                    if (!S.lb_have || re > S.lb_re) S.lb_re = re;
+                    S.lb_have = 1u;
+                    const uint32_t sc = s | (h.count << 8);
+                    if (dr == e2) {                                                  // r2 - r1 >= e2: a non-candidate here ends the scan
+                        if (e1 > 0u) S.f_other = 1u;
+                        else { S.f0_found = 1u; S.f0_tl = tl; S.f0_node = node1 - 1u; S.f0_sc = sc; S.f0_next = h.next; }
+                    } else if (e1 <= e2) {
+                        const uint32_t de = e2 - e1;
+                        // near candidates (:178-181): the longest wins, among equally long ones the first in set order
+                        if (dr <= de && dr >= de / 12u &&
+                            (!S.best_found || tl > S.best_tl || (tl == S.best_tl && re > S.best_re))) {
+                            S.best_found = 1u; S.best_tl = tl; S.best_re = re; S.best_node = node1 - 1u; S.best_sc = sc; S.best_next = h.next;
+                        }
+                    }
+                }
+            }
+            if (b == b_hi && !S.ins_node && h.count < NODE_K) { S.ins_node = node1; S.ins_cnt = h.count; S.ins_next = h.next; }
+            node1 = h.next;          // on along the chain
+        }
+        if (b == b_lo) break;
+        --b;
+        node1 = head_nxt;
+    }
+}
+
+// take a cluster out of its node (one lane): the node's last cluster moves into the hole
+__device__ __forceinline__ void node_erase(const TrackerMem &M, uint32_t node, uint32_t sc, uint32_t next) {
+    const uint32_t slot = sc & 0xFFu, last = (sc >> 8) - 1u;
+    if (slot != last) {
+        const cgptr_t p = node_ptr(M, node);
+        const ClusterKey lk = gld<ClusterKey>(p, NODE_HOT_OFF + (last << 4));
+        const ClusterCold lc = gld<ClusterCold>(p, NODE_COLD_OFF + (last << 5));
+        node_store(M, node, slot, lk, lc);
+    }
+    node_hdr_store(M, node, last, next);
+}
+
+__device__ __forceinline__ uint32_t lane_get32(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+__device__ __forceinline__ uint64_t lane_get64(uint64_t v, uint32_t src) {
+    return ((uint64_t)lane_get32((uint32_t)(v >> 32), src) << 32) | lane_get32((uint32_t)v, src);
+}
+
+// SeedTracker::add_seed (seed_tracker.cpp:157-232) for up to 64 seeds of one event, ONE LANE PER SEED.  A seed reads and changes only the
+// clusters whose start lies in its window [r2 - e2, r2], i.e. the buckets b_lo..b_hi: seeds whose bucket intervals are
+// disjoint do not see each other, whatever the order they are added in.  So the seeds are added in ROUNDS: a round takes every
+// pending seed whose interval no EARLIER pending seed touches (such seeds are pairwise disjoint), each lane scans its
+// window, decides and commits on its own -- the dependent memory round trips of a seed are paid once per round, not once
+// per seed -- and the seeds that had to wait take the next round, seeing what the earlier ones left: the reference's order
+// wherever order matters.  What IS order-dependent across all seeds -- the float sum of the lengths, the two largest lengths and
+// the first cluster to reach the record length -- is replayed in seed order from per-lane outcomes afterwards (registers only).
+// task = sa_end (40 bits) | event << 40 | length << 56 of lane's seed (lanes >= nt: none).  All of T stays uniform.
+static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_map_len, uint64_t task, uint32_t nt, int lane) {
+    if (T.status) return;
+    const bool have = (uint32_t)lane < nt;
+    const uint64_t ref_en = task & ((1ull << 40) - 1ull);
+    const uint32_t ref_len = (uint32_t)(task >> 56), e2 = (uint32_t)(task >> 40) & 0xFFFFu;
+    const uint64_t r2 = ref_en - ref_len + 1;                     // new_seed.ref_en_.start_ (= ref_st_)
     const uint64_t r_lo = r2 > (uint64_t)e2 ? r2 - (uint64_t)e2 : 0ull;
     const uint32_t b_hi = (uint32_t)(r2 >> M.shift), b_lo = (uint32_t)(r_lo >> M.shift);
-    const uint32_t nb = b_hi - b_lo + 1u;                         // <= WIN_BUCKETS for max_events < 2^15 (the default is 30 000)
-    const uint32_t j = (uint32_t)lane / NODE_K, s = (uint32_t)lane % NODE_K;
-    uint32_t head0 = 0;                                           // head of the seed's own bucket
+    // what the seed did, for the replay: 0 nothing (not reached), 1 joined a cluster, 2 new cluster; the cluster's length before
+    // and the cluster after
+    uint32_t o_kind = 0, o_prev = 0;
+    ClusterVal o_a;
+    o_a.ref_st = o_a.rstart = o_a.rend = 0; o_a.evt_st = o_a.evt_en = o_a.total_len = 0;
 
-    ClusterRef best; best.found = 0; best.node = best.slot = best.cnt = best.next = best.tl = best.e = 0; best.r = 0;   // best-supported candidate among the near ones
-    ClusterRef f0 = best;                                         // the cluster exactly e2 rows back with evt_en 0, if there is one
-    bool f_other = false;                                         // ... and whether another cluster sits exactly e2 rows back (it ends the scan first)
-    bool exists = false;                                          // an equivalent key (r2, e2) is in the set
-    uint64_t lb_r = 0; uint32_t lb_e = 0; bool lb_have = false;   // key at lower_bound(seed): the first in set order not before the seed
-    uint32_t ins_node = 0, ins_cnt = 0, ins_next = 0;             // a node of the seed's own bucket with room (id + 1)
-    for (uint32_t jb = 0; jb < nb; jb += WIN_BUCKETS) {
-    const bool active = j < WIN_BUCKETS && jb + j < nb;
-    uint32_t node1 = active ? gld<uint32_t>(M.sb, M.off_heads + ((b_hi - jb - j) << 2)) : 0u;      // node id + 1
-    if (jb == 0) head0 = bcast32(node1, 0);
-    while (__any(node1 != 0u)) {
-        NodeHdr h; h.count = 0; h.next = 0; h.pad0 = h.pad1 = 0;
-        ClusterKey k; k.rstart = 0; k.evt_en = 0; k.total_len = 0;
-        if (node1) {
-            const cgptr_t p = node_ptr(M, node1 - 1u);
-            h = gld<NodeHdr>(p, 0u);
-            k = gld<ClusterKey>(p, NODE_HOT_OFF + (s << 4));
+    uint64_t pend = __ballot(have);
+    while (pend) {
+        // ---- this round's seeds: pending, and no earlier pending seed's buckets overlap theirs
+        bool blocked = false;
+        for (uint64_t m = pend; m & (m - 1ull); m &= m - 1ull) {              // (the last pending seed blocks nobody)
+            const uint32_t i = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+            const uint32_t lo_i = lane_get32(b_lo, i), hi_i = lane_get32(b_hi, i);
+            if ((uint32_t)lane > i && b_lo <= hi_i && lo_i <= b_hi) blocked = true;
         }
-        const bool valid = node1 != 0u && s < h.count;
-        const uint64_t r1 = k.rstart;
-        const uint32_t e1 = k.evt_en, tl = k.total_len;
-        // not before the seed in set order, and not further back than e2 rows
-        const bool in_win = valid && r1 <= r2 && !(r1 == r2 && e1 > e2) && (r2 - r1) <= (uint64_t)e2;
-        const uint64_t dr = r2 - r1, de = (uint64_t)e2 - (uint64_t)e1;
-        const bool in_range = in_win && e1 <= e2 && dr <= de && dr >= de / 12;       // :178-181
-        const bool farE = in_win && dr == (uint64_t)e2;                              // r2 - r1 >= e2: a non-candidate here ends the scan
-        if (__any(valid && r1 == r2 && e1 == e2)) exists = true;
-        // a node of the seed's own bucket with a free slot
-        if (!ins_node) {
-            const uint64_t m = __ballot(jb == 0 && j == 0 && s == 0 && node1 != 0u && h.count < NODE_K);
-            if (m) { ins_node = bcast32(node1, 0); ins_cnt = bcast32(h.count, 0); ins_next = bcast32(h.next, 0); }
-        }
-        // lower bound: the largest (r1, e1) in the window
-        {
-            const uint64_t mr = wave_max64(in_win ? r1 + 1ull : 0ull);               // (+1: a start of 0 still counts)
-            if (mr) {
-                const uint32_t me = wave_max32(in_win && r1 + 1ull == mr ? e1 + 1u : 0u);
-                if (!lb_have || mr - 1ull > lb_r || (mr - 1ull == lb_r && me - 1u > lb_e)) { lb_r = mr - 1ull; lb_e = me - 1u; }
-                lb_have = true;
+        const bool ready = ((pend >> lane) & 1ull) != 0ull && !blocked;
+
+        // ---- scan, decide, commit (per lane; a new node is taken below, together)
+        bool need_node = false;
+        int dn = 0;                                                // change of the set's size
+        ClusterKey nk; nk.rstart = 0; nk.evt_en = 0; nk.total_len = 0;
+        ClusterCold nc; nc.ref_st = 0; nc.rend = 0; nc.evt_st = 0; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
+        uint32_t head0 = 0;
+        if (ready) {
+            SeedScan S;
+            seed_scan(M, r2, e2, b_hi, b_lo, S);
+            head0 = S.head0;
+            // the scan reaches the clusters e2 rows back after all nearer ones, in order of descending evt_en: any of them with
+            // evt_en > 0 is out of range and ends it; the one with evt_en 0 is in range (r2 - r1 = e2 - e1) and is taken when it is longer
+            uint32_t mt_found = S.best_found, mt_tl = S.best_tl, mt_re = S.best_re, mt_node = S.best_node, mt_sc = S.best_sc, mt_next = S.best_next;
+            if (S.f0_found && !S.f_other && (!S.best_found || S.f0_tl > S.best_tl)) {
+                mt_found = 1u; mt_tl = S.f0_tl; mt_re = (0xFFFFu - e2) << 16; mt_node = S.f0_node; mt_sc = S.f0_sc; mt_next = S.f0_next;
+            }
+            bool want_insert = false;
+            if (mt_found) {
+                const uint64_t mt_r = r2 - (uint64_t)(0xFFFFu - (mt_re >> 16));
+                const ClusterCold mp = gld<ClusterCold>(node_ptr(M, mt_node), NODE_COLD_OFF + ((mt_sc & 0xFFu) << 5));
+                ClusterVal a;
+                a.ref_st = mp.ref_st; a.rstart = mt_r; a.rend = mp.rend;
+                a.evt_st = mp.evt_st; a.evt_en = mt_re & 0xFFFFu; a.total_len = mt_tl;
+                // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
+                uint8_t growth = 0;
+                if (r2 < a.rend) {
+                    if (ref_en > a.rend) { growth = (uint8_t)(ref_en - a.rend); a.rend = ref_en; }
+                    a.rstart = r2;
+                } else {
+                    growth = (uint8_t)ref_len;
+                    a.rstart = r2;
+                    a.rend = ref_en;
+                }
+                a.evt_en = e2;
+                a.total_len += growth;
+                o_kind = 1u; o_prev = mt_tl; o_a = a;
+                // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2).  The insert collides -- and the cluster is
+                // dropped -- when that key is already in the set and is not the matched cluster itself (which then sits at the lower bound)
+                nk.rstart = r2; nk.evt_en = e2; nk.total_len = a.total_len;
+                nc.ref_st = a.ref_st; nc.rend = a.rend; nc.evt_st = a.evt_st;
+                const bool is_lb = S.lb_have && mt_re == S.lb_re;
+                if (!is_lb && S.exists) {
+                    node_erase(M, mt_node, mt_sc, mt_next);
+                    dn = -1;
+                } else if ((uint32_t)(mt_r >> M.shift) == b_hi) {
+                    node_store(M, mt_node, mt_sc & 0xFFu, nk, nc);          // same bucket: the cluster stays where it is
+                } else {
+                    node_erase(M, mt_node, mt_sc, mt_next);                 // its start moved into the seed's bucket
+                    want_insert = true;      // (the node found for inserting is not the one just shrunk: that one belongs to another bucket)
+                }
+            } else {
+                // new cluster (:218-228): the bookkeeping happens even when the set insert collides
+                o_kind = 2u; o_prev = 0u;
+                o_a.ref_st = r2; o_a.rstart = r2; o_a.rend = ref_en; o_a.evt_st = e2; o_a.evt_en = e2; o_a.total_len = ref_len;
+                if (!S.exists) {
+                    nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
+                    nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2;
+                    want_insert = true;
+                    dn = 1;
+                }
+            }
+            // where a new key goes: a free slot of the seed's own bucket, or a fresh node at its head
+            if (want_insert) {
+                if (S.ins_node) { node_store(M, S.ins_node - 1u, S.ins_cnt, nk, nc); node_hdr_store(M, S.ins_node - 1u, S.ins_cnt + 1u, S.ins_next); }
+                else need_node = true;
             }
         }
-        // near candidates: the longest wins, among equally long ones the first in set order = the largest (r1, e1)
-        {
-            const bool cand = in_range && !farE;
-            const uint64_t cm = __ballot(cand);
-            if (cm) {
-                const uint32_t m_tl = wave_max32(cand ? tl + 1u : 0u) - 1u;
-                const bool s1 = cand && tl == m_tl;
-                const uint64_t m_r = wave_max64(s1 ? r1 + 1ull : 0ull) - 1ull;
-                const bool s2 = s1 && r1 == m_r;
-                const uint32_t m_e = wave_max32(s2 ? e1 + 1u : 0u) - 1u;
-                const uint64_t wm = __ballot(s2 && e1 == m_e);
-                const int src = __ffsll((unsigned long long)wm) - 1;
-                const bool better = !best.found || m_tl > best.tl || (m_tl == best.tl && (m_r > best.r || (m_r == best.r && m_e > best.e)));
-                if (better) best = cluster_ref(node1 - 1u, s, h, k, src);
-            }
-        }
-        // clusters exactly e2 rows back
-        {
-            if (__any(farE && e1 > 0u)) f_other = true;
-            const uint64_t fm = __ballot(farE && e1 == 0u);
-            if (fm) f0 = cluster_ref(node1 - 1u, s, h, k, __ffsll((unsigned long long)fm) - 1);
-        }
-        node1 = node1 ? h.next : 0u;          // on along the chains
-    }
-    }
-    // the scan reaches the clusters e2 rows back after all nearer ones, in order of descending evt_en: any of them with evt_en > 0
-    // is out of range and ends it; the one with evt_en 0 is in range (r2 - r1 = e2 - e1) and is taken when it is longer
-    ClusterRef mt = best;
-    if (f0.found && !f_other && (!best.found || f0.tl > best.tl)) mt = f0;
-
-    // where a new key goes: a free slot of the seed's own bucket, or a fresh node at its head
-    auto insert_key = [&](const ClusterKey &nk, const ClusterCold &nc) -> bool {
-        if (ins_node) {
-            if (lane == 0) { node_store(M, ins_node - 1u, ins_cnt, nk, nc); node_hdr_store(M, ins_node - 1u, ins_cnt + 1u, ins_next); }
-        } else {
-            const uint32_t id = tracker_new_node(T, M, lane);
-            if (id == NODE_NONE) return false;
+        // ---- fresh nodes for the lanes that need one: the next ones of the read's newest chunk, then of a chunk popped off the pool's
+        // ring (at most one chunk boundary is crossed: 64 < CHUNK_NODES).  Out of allowance or pool dry: the read overflows and is
+        // mapped again later, whatever has been committed so far is void.
+        const uint64_t nm = __ballot(need_node);
+        if (nm) {
+            const uint32_t k = (uint32_t)__popcll(nm), a0 = T.n_alloc;
+            if (a0 + k > M.max_nodes) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
+            const uint32_t c0 = a0 / CHUNK_NODES, c1 = (a0 + k - 1u) / CHUNK_NODES;
+            uint32_t ch0 = SCHED_EMPTY, ch1 = SCHED_EMPTY;
             if (lane == 0) {
+                if (a0 % CHUNK_NODES == 0u) {
+                    ch0 = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
+                    if (ch0 != SCHED_EMPTY) gst(M.sb, M.off_chunks + (c0 << 2), ch0);
+                } else ch0 = gld<uint32_t>(M.sb, M.off_chunks + (c0 << 2));
+                if (c1 == c0) ch1 = ch0;
+                else if (ch0 != SCHED_EMPTY) {
+                    ch1 = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
+                    if (ch1 != SCHED_EMPTY) gst(M.sb, M.off_chunks + (c1 << 2), ch1);
+                }
+            }
+            ch0 = lane_get32(ch0, 0u); ch1 = lane_get32(ch1, 0u);
+            if (ch0 == SCHED_EMPTY || ch1 == SCHED_EMPTY) {
+                // (a chunk that WAS popped is the read's: n_alloc covers it, so that tracker_release hands it back)
+                if (ch0 != SCHED_EMPTY) T.n_alloc = c1 * CHUNK_NODES;
+                T.status |= UNC_READ_CLUSTER_OVERFLOW | UNC_READ_POOL_DRY;
+                return;
+            }
+            if (need_node) {
+                const uint32_t my = a0 + prefix_popc(nm);
+                const uint32_t id = (my / CHUNK_NODES == c0 ? ch0 : ch1) * CHUNK_NODES + my % CHUNK_NODES;
                 node_store(M, id, 0u, nk, nc); node_hdr_store(M, id, 1u, head0);
                 gst(M.sb, M.off_heads + (b_hi << 2), id + 1u);
             }
+            T.n_alloc = a0 + k;
         }
-        return true;
-    };
-    // take the cluster c out of its node: the node's last cluster moves into the hole
-    auto erase_ref = [&](const ClusterRef &c) {
-        const uint32_t last = c.cnt - 1u;
-        if (c.slot != last) {
-            const cgptr_t p = node_ptr(M, c.node);
-            const ClusterKey lk = gld<ClusterKey>(p, NODE_HOT_OFF + (last << 4));
-            const ClusterCold lc = gld<ClusterCold>(p, NODE_COLD_OFF + (last << 5));
-            wave_sync();
-            if (lane == 0) node_store(M, c.node, c.slot, lk, lc);
-        }
-        if (lane == 0) node_hdr_store(M, c.node, last, c.next);
-    };
+        T.n += (uint32_t)__popcll(__ballot(dn > 0)) - (uint32_t)__popcll(__ballot(dn < 0));
+        pend &= ~__ballot(ready);
+        wave_sync();          // this round's stores before the next round's loads
+    }
 
-    if (mt.found) {
-        const ClusterCold mp = gld<ClusterCold>(node_ptr(M, mt.node), NODE_COLD_OFF + (mt.slot << 5));
-        ClusterVal a;
-        a.ref_st = mp.ref_st; a.rstart = mt.r; a.rend = mp.rend;
-        a.evt_st = mp.evt_st; a.evt_en = mt.e; a.total_len = mt.tl;
-        const uint32_t prev_len = a.total_len;
-        // SeedCluster::update, seed_tracker.cpp:56-73 (growth is a u8)
-        uint8_t growth = 0;
-        if (r2 < a.rend) {
-            if (ref_en > a.rend) { growth = (uint8_t)(ref_en - a.rend); a.rend = ref_en; }
-            a.rstart = r2;
-        } else {
-            growth = (uint8_t)ref_len;
-            a.rstart = r2;
-            a.rend = ref_en;
-        }
-        a.evt_en = e2;
-        a.total_len += growth;
-        if (a.total_len != prev_len) {
-            T.len_sum = __fadd_rn(T.len_sum, (float)(a.total_len - prev_len));
-            lens_replace(T, prev_len, a.total_len);
-            if (a.total_len >= min_map_len && a.total_len > T.mm.total_len) T.mm = a;
-        }
-        // erase(loc_match) then insert(hint, a): a's key is now exactly (r2, e2).  The insert collides -- and the cluster is
-        // dropped -- when that key is already in the set and is not the matched cluster itself (which then sits at the lower bound)
-        ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = a.total_len;
-        ClusterCold nc; nc.ref_st = a.ref_st; nc.rend = a.rend; nc.evt_st = a.evt_st; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
-        const bool is_lb = lb_have && mt.r == lb_r && mt.e == lb_e;
-        wave_sync();
-        if (!is_lb && exists) {
-            erase_ref(mt);
-            T.n--;
-        } else if ((uint32_t)(mt.r >> M.shift) == b_hi) {
-            if (lane == 0) node_store(M, mt.node, mt.slot, nk, nc);      // same bucket: the cluster stays where it is
-        } else {
-            erase_ref(mt);                                               // its start moved into the seed's bucket
-            wave_sync();
-            // (the node found for inserting is not the one just shrunk: that one belongs to another bucket)
-            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
-        }
-        wave_sync();
-    } else {
-        // new cluster (:218-228): the bookkeeping happens even when the set insert collides
-        lens_insert(T, ref_len);
-        T.len_sum = __fadd_rn(T.len_sum, (float)ref_len);
-        if (ref_len >= min_map_len && ref_len > T.mm.total_len) {
-            T.mm.ref_st = r2; T.mm.rstart = r2; T.mm.rend = ref_en;
-            T.mm.evt_st = e2; T.mm.evt_en = e2; T.mm.total_len = ref_len;
-        }
-        if (!exists) {
-            ClusterKey nk; nk.rstart = r2; nk.evt_en = e2; nk.total_len = ref_len;
-            ClusterCold nc; nc.ref_st = r2; nc.rend = ref_en; nc.evt_st = e2; nc.pad[0] = nc.pad[1] = nc.pad[2] = 0;
-            wave_sync();
-            if (!insert_key(nk, nc)) return;        // (status set by tracker_new_node)
-            T.n++;
-            wave_sync();
+    // ---- replay in seed order what depends on it (:193-206, :218-224)
+    for (uint32_t j = 0; j < nt; ++j) {
+        const uint32_t kind = lane_get32(o_kind, j), prev = lane_get32(o_prev, j), tl = lane_get32(o_a.total_len, j);
+        if (kind == 2u) lens_insert(T, tl);
+        else if (tl != prev) lens_replace(T, prev, tl);
+        if (kind == 2u || tl != prev) {
+            T.len_sum = __fadd_rn(T.len_sum, (float)(tl - prev));
+            if (tl >= min_map_len && tl > T.mm.total_len) {
+                T.mm.ref_st = lane_get64(o_a.ref_st, j); T.mm.rstart = lane_get64(o_a.rstart, j); T.mm.rend = lane_get64(o_a.rend, j);
+                T.mm.evt_st = lane_get32(o_a.evt_st, j); T.mm.evt_en = lane_get32(o_a.evt_en, j); T.mm.total_len = tl;
+            }
         }
     }
 }
