@@ -3,7 +3,7 @@
 
 Headline = BASELINE config 2 (E. coli 4.6 Mb, 50 k synthetic r9.4.1 reads, 1 GPU).  One step = one pass of the whole hot
 path (event detection -> normalisation -> match -> FM path forest -> seed clustering -> PAF coordinates) over one batch
-of reads that is already resident in HBM.  `--gpus N` is launched by the driver as N ranks (torch.distributed.run);
+of reads that is already resident in HBM.  `--gpus N` runs as N ranks (started by the driver's torch.distributed.run, or by this script);
 reads shard across ranks (index replicated per GPU, no data-path collective), per-GPU work fixed => weak scaling.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -11,8 +11,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline  the reference's own object code (oracle/_ref) on this box's host cores: thread-count sweep, best N,
                 mean / median ms per read, the as-shipped MapPool hand-shake ("B2"), PAF mismatches against the GPU
   verify        sha256 of the hits of every timed step (all equal), reads checked against the CPU reference
-  secondary     (N = 1 only) the same measurement on `grch38_syn` (BASELINE config 4's reference, one GPU's share) and
-                `chr20_syn` (config 3, 200 k reads), each with roofline, sampled cpu_baseline and PAF check
+  secondary     N = 1: the same measurement on `grch38_syn` (BASELINE config 4's reference, one GPU's share), `chr20_syn`
+                (config 3, 200 k reads), each with roofline, sampled cpu_baseline and PAF check, and the realtime rounds
+                (config 5); N > 1: config 4 itself (every rank 250 k reads on its own copy of the GRCh38 index)
+`python bench.py --gpus N` without a launcher starts the N ranks itself (launch_ranks).
 See DESIGN.md "Measurement" for how the numbers are derived.
 """
 import argparse
@@ -538,6 +540,23 @@ def realtime_workload(a, ix, prefix, codes, lens, local_rank, ref_label, steps, 
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU; torch.distributed.run on this
+    node, rendezvous on 127.0.0.1) with the same arguments, pass their output through, return their exit code.  The reference's
+    parallelism is N independent workers over one read queue (src/map_pool.cpp:31-42); here a worker is a rank with its own GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py")] + sys.argv[1:]
+    log(f"--gpus {n}: launching {n} ranks: {' '.join(cmd[2:9])} ...")
+    rc = subprocess.run(cmd).returncode
+    if rc:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -550,8 +569,9 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed passes (PCIe-inclusive rate, phase cycle shares)")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "grch38", "realtime", "example"], default="ecoli",
                     help="headline workload (the driver runs the default: BASELINE config 2)")
-    ap.add_argument("--secondary", default=os.environ.get("UNC_BENCH_SECONDARY", "realtime:ecoli,chr20,realtime:chr20,grch38"),
-                    help="comma list of further workloads measured after the headline at N=1 ('' = none)")
+    ap.add_argument("--secondary", default=os.environ.get("UNC_BENCH_SECONDARY"),
+                    help="comma list of further workloads measured after the headline ('' = none; default: realtime:ecoli, chr20, "
+                         "realtime:chr20, grch38 at N = 1, grch38 -- BASELINE config 4, every rank its 250 k reads -- at N > 1)")
     ap.add_argument("--grch38-reads", type=int, default=250000, help="reads of the grch38 block (config 4: 2 M reads over 8 GPUs = 250 k per GPU)")
     ap.add_argument("--chr20-reads", type=int, default=200000, help="reads of the chr20 block (config 3)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("UNC_BENCH_BUDGET_S", 1500)),
@@ -569,10 +589,13 @@ def main():
         a.reads = a_reads(argparse.Namespace(reads=int(os.environ.get("UNC_BENCH_READS", 50000)), chr20_reads=a.chr20_reads,
                                              grch38_reads=a.grch38_reads), a.workload)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a.gpus)         # plain `python bench.py --gpus N`: one rank per GPU, this process only relays
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but the launcher started {world} rank(s): the line would state the wrong n_gpus"
     # UNC_BENCH_LIB: tests point this at the lanesim build of the same sources to run the world > 1 plumbing on CPU ranks
     lib_path = os.environ.get("UNC_BENCH_LIB")
     have_gpu = lib_path is None
@@ -627,12 +650,22 @@ def main():
             out["cpu_baseline"] = head["cpu_baseline"]
         if placement:
             out["config"]["host_placement_rank0"] = placement
-    # secondary blocks: N = 1 only (BASELINE config 4 shards 2 M reads over 8 GPUs = 250 k per GPU: one GPU's share is
-    # what a single box can measure; the same code path runs on every rank)
-    if world == 1 and a.workload == "ecoli" and have_gpu:
+    # secondary blocks.  N = 1: config 5 (realtime), config 3 (chr20) and one GPU's share of config 4 (GRCh38, 250 k reads).
+    # N > 1: config 4 as BASELINE.json states it -- the GRCh38 index replicated on every GPU, every rank its own 250 k reads
+    # (2 M reads over 8 GPUs), no collective on the data path; timed like the headline (barriers, MAX over ranks)
+    if a.secondary is None:
+        a.secondary = "" if not (have_gpu and a.workload == "ecoli") else \
+            ("realtime:ecoli,chr20,realtime:chr20,grch38" if world == 1 else "grch38")
+    if a.secondary:
         sec = {}
         for w in [x for x in a.secondary.split(",") if x]:
+            if w.startswith("realtime") and world > 1:
+                continue                    # (per-chunk latency of one flow cell: a single-GPU measurement)
             spent = time.time() - T_START
+            if dist is not None:            # every rank takes the same decision (the blocks contain barriers)
+                t = torch.tensor([spent], dtype=torch.float64, device=dev_name if have_gpu else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                spent = float(t.item())
             if spent > a.budget_s:
                 sec[w] = {"skipped": f"time budget: {spent:.0f} s of {a.budget_s:.0f} s gone"}
                 continue
@@ -654,14 +687,16 @@ def main():
                                  dev_name, extras, 0.0 if a.no_cpu_baseline else 60.0, warmup_reads=8192)
                 r = {k: v for k, v in r.items() if k != "dt"}
                 r["unit"] = "reads/s"
+                r["n_gpus"] = world
                 r["wall_s_incl_index_build"] = time.time() - t0
                 sec[w] = r
-                log(f"secondary {w}: {r['value']:.0f} reads/s")
+                if rank == 0:
+                    log(f"secondary {w}: {r['value']:.0f} reads/s on {world} GPU(s)")
             except Exception as e:      # a secondary block never takes the headline down with it
                 import traceback
                 traceback.print_exc()
                 sec[w] = {"error": repr(e)[:400]}
-        if sec:
+        if sec and rank == 0:
             out["secondary"] = sec
     if rank == 0:
         out["bench_wall_s"] = time.time() - T_START

@@ -88,6 +88,32 @@ def test_bench_py_two_ranks_gloo(sim_lib, tmp_path):
     assert "cpu_baseline" not in b and "secondary" not in b                               # N > 1: neither is run
 
 
+def test_bench_py_launches_its_own_ranks(sim_lib, tmp_path):
+    """plain `python bench.py --gpus 2` (no launcher): the script starts the two ranks itself, the line says n_gpus 2, and the
+    secondary block runs on both ranks as well (the N > 1 form of BASELINE config 4; here on the example index)."""
+    import json
+    import subprocess
+    env = dict(os.environ, UNC_DIST_BACKEND="gloo", UNC_BENCH_LIB=str(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so"),
+               UNC_BENCH_CACHE=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "example",
+                        "--reads", "2", "--secondary", "example"], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["reads_per_gpu_per_step"] == 2
+    sec = b["secondary"]["example"]
+    assert sec["n_gpus"] == 2 and sec["value"] > 0 and sec["verify"]["all_steps_identical"]
+    assert abs(sec["value"] - 2 * 2 / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 1e-6
+    # a launcher that started a different number of ranks than --gpus says is refused
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "example", "--reads", "2"], env=env1,
+                       capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode != 0 and "n_gpus" in r.stderr
+
+
 def test_numa_placement_plan(tmp_path):
     """uncalled_amd/numa.py: a rank's host threads go to the NUMA node of its GPU (sysfs), to an equal share of the allowed
     cores when the platform names no node, and stay put on one GPU -- worked out against a fake sysfs tree."""

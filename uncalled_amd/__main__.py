@@ -192,49 +192,92 @@ def map_cmd(args):
     mapper.stop()
 
 
+class _Channel:
+    """What the decision session remembers about one channel."""
+    __slots__ = ("last_chunk_at", "ejected_read")
+
+    def __init__(self, now):
+        self.last_chunk_at = now        # when the channel's newest chunk was handed to the pool (decision latency is taken from it)
+        self.ejected_read = None        # number of the read this channel was told to eject: its late chunks are dropped
+
+
+class RealtimeSession:
+    """ReadUntil decisions over a RealtimePool and a chunk source with the ClientSim surface: the behaviour of the reference's
+    `uncalled realtime / sim` main loop (scripts/uncalled:216-256 -- the caller of this repo's boundary, not part of it),
+    written as a table of verdicts instead of a branch ladder.
+
+    verdict of a result  | PAF tag (seconds since the channel's last chunk) | told to the chunk source
+    ---------------------+--------------------------------------------------+--------------------------------
+    "ended"              | Paf.ENDED                                        | stop_receiving_read
+    "eject"              | Paf.EJECT (+ Paf.DELAY = the source's answer)    | unblock_read, later chunks of that read dropped
+    "keep"               | Paf.KEEP                                         | stop_receiving_read
+    A mapped read is ejected when depleting, an unmapped one when enriching; everything else is kept."""
+
+    def __init__(self, unc, conf, client, pool, emit=None, clock=time.time):
+        self.unc, self.client, self.pool, self.clock = unc, client, pool, clock
+        self.emit = emit or (lambda paf: paf.print_paf())
+        self.eject_mapped = conf.realtime_mode == int(unc.RealtimePool.DEPLETE)
+        self.skip_odd = conf.active_chs == int(unc.RealtimePool.EVEN)
+        self.deadline = conf.duration * 3600 if conf.duration else None
+        now = clock()
+        self.chan = {c: _Channel(now) for c in range(1, conf.num_channels + 1)}
+        self.act = {"ended": self._ended, "eject": self._eject, "keep": self._keep}
+
+    def verdict(self, paf):
+        if paf.is_ended():
+            return "ended"
+        return "eject" if bool(paf.is_mapped()) == self.eject_mapped else "keep"
+
+    def _ended(self, ch, number, paf, waited):
+        paf.set_float(self.unc.Paf.ENDED, waited)
+        self.client.stop_receiving_read(ch, number)
+
+    def _keep(self, ch, number, paf, waited):
+        paf.set_float(self.unc.Paf.KEEP, waited)
+        self.client.stop_receiving_read(ch, number)
+
+    def _eject(self, ch, number, paf, waited):
+        paf.set_float(self.unc.Paf.EJECT, waited)
+        paf.set_int(self.unc.Paf.DELAY, self.client.unblock_read(ch, number))
+        self.chan[ch].ejected_read = number
+
+    def decide(self):
+        """every result the pool has ready -> verdict -> PAF line"""
+        for ch, number, paf in self.pool.update():
+            self.act[self.verdict(paf)](ch, number, paf, self.clock() - self.chan[ch].last_chunk_at)
+            self.emit(paf)
+
+    def feed(self):
+        """the source's new chunks -> the pool (channels that are switched off and ejected reads aside)"""
+        for ch, chunk in self.client.get_read_chunks():
+            if self.skip_odd and ch % 2:
+                self.client.stop_receiving_read(ch, chunk.number)
+            elif self.chan[ch].ejected_read == chunk.number:
+                sys.stdout.write("# chunk of %s arrived after its ejection: dropped\n" % chunk.id)
+            else:
+                self.chan[ch].last_chunk_at = self.clock()
+                self.pool.add_chunk(chunk)
+
+    def run(self, sleep=time.sleep):
+        """decide / feed in ticks of MAX_SLEEP until the source has stopped and nothing is left in the pool, or the
+        run's duration is over"""
+        while self.client.is_running or not self.pool.all_finished():
+            tick = self.clock()
+            self.decide()
+            if not self.client.is_running:
+                return          # the source ran dry: what is still undecided stays so
+            self.feed()
+            if self.deadline is not None and self.client.get_runtime() >= self.deadline:
+                return
+            spare = MAX_SLEEP - (self.clock() - tick)
+            if spare > 0:
+                sleep(spare)
+
+
 def realtime_loop(unc, conf, client, pool, sim=True, emit=None, sleep=time.sleep):
-    """The enrich / deplete decision loop of scripts/uncalled:216-256 (realtime_cmd), statement for statement, over a
-    RealtimePool and a chunk source with the ClientSim surface.  Per result: the read ended -> stop receiving it; it
-    mapped and we deplete (or did not map and we enrich) -> eject it; otherwise keep it."""
-    emit = emit or (lambda paf: paf.print_paf())
-    deplete = conf.realtime_mode == int(unc.RealtimePool.DEPLETE)
-    even = conf.active_chs == int(unc.RealtimePool.EVEN)
-    chunk_times = [time.time() for _ in range(conf.num_channels)]
-    unblocked = [None for _ in range(conf.num_channels)]
-    end_time = float("inf") if not conf.duration else conf.duration * 60 * 60
-    while client.is_running or not pool.all_finished():
-        t0 = time.time()
-        for ch, nm, paf in pool.update():
-            t = time.time() - chunk_times[ch - 1]
-            if paf.is_ended():
-                paf.set_float(unc.Paf.ENDED, t)
-                client.stop_receiving_read(ch, nm)
-            elif (paf.is_mapped() and deplete) or not (paf.is_mapped() or deplete):
-                paf.set_float(unc.Paf.EJECT, t)
-                u = client.unblock_read(ch, nm)
-                if sim:
-                    paf.set_int(unc.Paf.DELAY, u)
-                unblocked[ch - 1] = nm
-            else:
-                paf.set_float(unc.Paf.KEEP, t)
-                client.stop_receiving_read(ch, nm)
-            emit(paf)
-        if not client.is_running:
-            break            # the source ran dry: what is still undecided stays so, as in the reference
-        for channel, read in client.get_read_chunks():
-            if even and channel % 2 == 1:
-                client.stop_receiving_read(channel, read.number)
-            else:
-                if unblocked[channel - 1] == read.number:
-                    sys.stdout.write("# recieved chunk from %s after unblocking\n" % read.id)
-                    continue
-                chunk_times[channel - 1] = time.time()
-                pool.add_chunk(read)
-        if client.get_runtime() >= end_time:
-            break
-        dt = time.time() - t0
-        if dt < MAX_SLEEP:
-            sleep(MAX_SLEEP - dt)
+    """`uncalled sim`'s main loop: a RealtimeSession run to its end (`sim` is accepted for the reference's call shape; the
+    MinKNOW client, the only other chunk source, is out of scope)."""
+    RealtimeSession(unc, conf, client, pool, emit=emit).run(sleep=sleep)
 
 
 def sim_cmd(args):
