@@ -170,3 +170,8 @@ def test_realtime_add_chunk_and_decision_loop_gpu(unc, oracle_lib, tmp_path, gol
 def test_map_pool_pipeline_gpu(unc, oracle_lib, tmp_path, goldens):
     from tests.test_realtime_host import case_map_pool_pipeline
     case_map_pool_pipeline(unc, oracle_lib, tmp_path, goldens)
+
+
+def test_map_pool_short_of_staging_memory_gpu(unc, oracle_lib, tmp_path, goldens, monkeypatch):
+    from tests.test_realtime_host import case_map_pool_short_of_staging_memory
+    case_map_pool_short_of_staging_memory(unc, oracle_lib, tmp_path, goldens, monkeypatch)

@@ -211,6 +211,44 @@ def case_map_pool_pipeline(unc, po, tmp_path, goldens):
         assert "ch:i:%d" % r["channel"] in c and "st:i:%d" % r["start"] in c
 
 
+def case_map_pool_short_of_staging_memory(unc, po, tmp_path, goldens, monkeypatch):
+    """The loader with a staging buffer that cannot grow (round-3 advice: a read dropped without a PAF line, and a failed first
+    read ending the run).  UNC_STAGING_MAX_KB caps a buffer at 40 KB = 20 000 samples: a batch that is full is handed over and the
+    read that did not fit OPENS THE NEXT ONE; a read larger than the cap gets its unmapped line (length column as the reference
+    prints it) and the run goes on.  Every read comes out exactly once, the staged ones with the oracle's columns."""
+    import time
+    monkeypatch.setenv("UNC_STAGING_MAX_KB", "40")
+    off = goldens["sim_offsets"]
+    n = 6
+    reads = [dict(id="sim-%d" % i, channel=1 + i, number=i, start=100 * i, range=CAL_RANGE, offset=CAL_OFFSET, digitisation=CAL_DIGITISATION,
+                  signal=goldens["sim_signal"][int(off[i]):int(off[i + 1])].tolist()[:9000]) for i in range(n)]
+    big = dict(reads[2], id="too-big", signal=(reads[2]["signal"] * 4)[:30000])      # 60 KB: no buffer will ever hold it
+    order = [big] + reads[:3] + [dict(big, id="too-big-2")] + reads[3:]                # ... also as the very first read of the run
+    assert unc.write_fast5(str(tmp_path / "a.fast5"), order, True, 4000.0)
+    pool = unc.MapPool(_conf(unc, 512, batch_reads=8))
+    pool.add_fast5(str(tmp_path / "a.fast5"))
+    lines, t0 = [], time.time()
+    while pool.running():
+        lines += [str(p) for p in pool.update()]
+        time.sleep(0.01)
+        assert time.time() - t0 < 600
+    pool.stop()
+    got = {l.split("\t")[0]: l.split("\t") for l in lines}
+    assert len(lines) == len(order) and sorted(got) == sorted(r["id"] for r in order)
+    for name in ("too-big", "too-big-2"):
+        assert got[name][2] == "*" and int(got[name][1]) == int(np.float32(30000) * (np.float32(450.0) / np.float32(4000.0)))
+    oix = po.Index(G / "example_index" / "example_ref")
+    om = po.Mapper(oix)
+    for r in reads:
+        o = om.map_read(po.calibrate(np.array(r["signal"], dtype=np.int16), CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION))
+        want = po.hit_paf_cols(o, oix.ref_names())
+        c = got[r["id"]]
+        if o["mapped"]:
+            assert (int(c[1]), int(c[2]), int(c[3]), c[4], c[5], int(c[6]), int(c[7]), int(c[8]), int(c[9]), int(c[10]), int(c[11])) == want
+        else:
+            assert int(c[1]) == want[0] and c[2] == "*"
+
+
 # ---- the cases above on the lanesim build of the host module (tests/test_gpu_host.py runs them on the real one)
 @pytest.mark.lanesim
 def test_chunk_class(sim_host):
@@ -240,3 +278,8 @@ def test_client_sim_feeds_the_decision_loop(sim_host, tmp_path, goldens):
 @pytest.mark.lanesim
 def test_map_pool_pipeline_matches_oracle(sim_host, oracle_lib, tmp_path, goldens):
     case_map_pool_pipeline(sim_host, oracle_lib, tmp_path, goldens)
+
+
+@pytest.mark.lanesim
+def test_map_pool_short_of_staging_memory(sim_host, oracle_lib, tmp_path, goldens, monkeypatch):
+    case_map_pool_short_of_staging_memory(sim_host, oracle_lib, tmp_path, goldens, monkeypatch)

@@ -290,6 +290,7 @@ MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(conf) {
     p.max_chunks = conf.max_chunks;
     p.chunk_time = conf.chunk_time;
     p.sample_rate = conf.sample_rate;
+    bp_per_samp_ = p.bp_per_sec / p.sample_rate;
     if (unc_index_load(conf.bwa_prefix.c_str(), conf.idx_preset.c_str(), conf.device, &ix_) != UNC_OK ||
         unc_mapper_create(ix_, &p, nullptr, &mapper_) != UNC_OK) {
         std::cerr << "Error: " << unc_last_error() << "\n";   // Mapper::load_static aborts on a bad index, mapper.cpp:118-127
@@ -334,6 +335,14 @@ bool MapPool::grow(Batch &b, uint64_t need) {
     uint64_t cap = b.cap ? 2 * b.cap : (32ull << 20);            // at least double, at least what is asked for (in 32 M-sample steps)
     if (cap < need) cap = (need + (32ull << 20) - 1) / (32ull << 20) * (32ull << 20);
     if (cap > kBatchBytes / 2 && need <= kBatchBytes / 2) cap = kBatchBytes / 2;      // never past the byte cap of a batch
+    // UNC_STAGING_MAX_KB: a ceiling on one staging buffer for hosts short of (lockable) memory -- and how the tests reach the
+    // out-of-memory paths of the loader
+    const char *lim_env = getenv("UNC_STAGING_MAX_KB");
+    const uint64_t limit = lim_env ? (uint64_t)atoll(lim_env) * 512ull : 0ull;       // in samples
+    if (limit) {
+        if (need > limit) return false;
+        if (cap > limit) cap = limit;
+    }
     bool pinned = true;
     int16_t *p = static_cast<int16_t *>(unc_host_alloc(cap * 2));
     if (!p) {
@@ -367,7 +376,7 @@ void MapPool::loader_main() {
         Batch &b = bufs_[bi];
         b.used = 0; b.off.assign(1, 0); b.cal.clear(); b.meta.clear();
         const uint32_t target = batches_staged_ == 0 ? first_batch_reads_ : batch_reads_;
-        bool failed = false;
+        std::vector<Paf> unstaged;      // reads no staging buffer could be had for: reported unmapped, like every read the reference is given
         while (b.meta.size() < target) {
             // the GPU has nothing to do and one load of its slots is staged: hand that over now.  Batches thus grow from one
             // load towards four as long as reading keeps ahead of mapping, and the GPU never waits for a full batch.
@@ -375,10 +384,13 @@ void MapPool::loader_main() {
                 std::lock_guard<std::mutex> lk(mtx_);
                 if (!mapper_busy_ && staged_.empty()) break;
             }
-            if (reader_.buffered() == 0 && (reader_.empty() || reader_.fill_buffer() == 0)) break;
+            if (!carry_valid_ && reader_.buffered() == 0 && (reader_.empty() || reader_.fill_buffer() == 0)) break;
             // (a batch is also closed by bytes: whole reads with -c 1000000 are tens of MB each)
-            if (!b.meta.empty() && (b.used + reader_.front_size() + 1) * 2 > kBatchBytes) break;
-            RawRead r = reader_.pop_read();
+            const uint64_t next_size = carry_valid_ ? carry_.signal.size() : reader_.front_size();
+            if (!b.meta.empty() && (b.used + next_size + 1) * 2 > kBatchBytes) break;
+            RawRead r;
+            if (carry_valid_) { r = std::move(carry_); carry_valid_ = false; }      // the read the last batch had no room for
+            else r = reader_.pop_read();
             // a buffer that must grow goes straight to what a FULL batch will need, also while the short first batch is being
             // read: page-locking is slow (seconds for the 4-5 GB of a batch) and holds up the HIP calls of the mapping thread
             // meanwhile, so both buffers reach their final size during the first two batches and never grow again
@@ -388,10 +400,20 @@ void MapPool::loader_main() {
                 if (est > need) need = est < kBatchBytes / 2 ? est : kBatchBytes / 2;
                 if (need < b.used + r.signal.size() + 1) need = b.used + r.signal.size() + 1;
             }
-            if (!grow(b, need)) {
-                std::cerr << "Error: out of host memory for a staging buffer (" << ((b.used + r.signal.size()) * 2 >> 20) << " MB); read " << r.id << " is dropped\n";
-                failed = true;
-                break;
+            if (!grow(b, need) && !grow(b, b.used + r.signal.size() + 1)) {
+                // no memory for the buffer to grow.  A batch that holds reads is handed over as it is and this read opens the next
+                // one (whose buffer is then empty); a read that does not even fit an empty buffer gets its unmapped PAF line
+                // (every read gets a line, map_pool.cpp:130-158) and the loader goes on with the next read
+                if (!b.meta.empty()) {
+                    carry_ = std::move(r); carry_valid_ = true;
+                    break;
+                }
+                std::cerr << "Error: out of host memory for a staging buffer of " << ((r.signal.size() + 1) * 2 >> 20) << " MB; read " << r.id
+                          << " is reported unmapped\n";
+                Paf pf(r.id, (uint16_t)(r.channel_idx + 1), r.start_sample);
+                pf.set_read_len((uint64_t)((float)r.signal.size() * bp_per_samp_));     // (an unmapped read's length: read_buffer.cpp:133-155)
+                unstaged.push_back(std::move(pf));
+                continue;
             }
             if (!r.signal.empty()) memcpy(b.raw + b.used, r.signal.data(), r.signal.size() * 2);
             b.used += r.signal.size();
@@ -400,6 +422,7 @@ void MapPool::loader_main() {
             b.meta.push_back(ReadMeta{r.id, r.channel_idx, r.start_sample});
         }
         std::unique_lock<std::mutex> lk(mtx_);
+        for (Paf &pf : unstaged) done_.push_back(std::move(pf));
         if (b.meta.empty()) {          // the files ran dry: idle until another one is added
             free_.push_front(bi);
             loader_idle_ = true;
@@ -409,7 +432,6 @@ void MapPool::loader_main() {
             if (stopped_) break;
             continue;
         }
-        (void)failed;
         ++batches_staged_;
         staged_.push_back(bi);
         cv_.notify_all();

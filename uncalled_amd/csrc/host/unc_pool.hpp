@@ -140,6 +140,9 @@ private:
     uint32_t batch_reads_ = 0, first_batch_reads_ = 0;
     uint64_t batches_staged_ = 0;
     bool warned_pageable_ = false;
+    RawRead carry_;                  // loader thread only: the read a closed batch had no room for; it opens the next batch
+    bool carry_valid_ = false;
+    float bp_per_samp_ = 0.0f;
     Batch bufs_[2];
     std::deque<int> free_, staged_;       // indices into bufs_
     std::deque<std::string> new_files_;   // add_fast5 -> loader thread
