@@ -173,6 +173,24 @@ def cpu_baseline(prefix, raw_host, offsets, calib, hits_gpu, budget_s=80.0, swee
         out["paf_mismatch_reads"] = mism[:16]
     out["tie_order_note"] = ("children tying on (fm_range, seed_prob) are ordered by creation in oracle and kernels alike; "
                              "upstream's unstable pdqsort (mapper.cpp:531) is not available here, oracle/shim uses std::stable_sort")
+    if kind == "reference":
+        # how much rides on that convention: the same reads under the two other tie orders of oracle/shim/pdqsort.h -- pattern-defeating
+        # quicksort restated from its published algorithm, and creation order REVERSED -- with the ties counted by the shim
+        n_t = int(max(8, min(n_avail, best_rate * 5.0)))
+        legs = {}
+        for name, mode in (("stable", pyref.SORT_STABLE), ("pdqsort_restated", pyref.SORT_PDQ_RESTATED), ("reversed_ties", pyref.SORT_REVERSED_TIES)):
+            pyref.set_sort_mode(mode)
+            pyref.sort_stats(reset=True)
+            _, _, cols_m, _ = run(n_t, best_n)
+            legs[name] = (cols_m, pyref.sort_stats())
+        pyref.set_sort_mode(pyref.SORT_STABLE)
+        base_cols, (n_sorts, n_tie_ev, n_tie_pairs) = legs["stable"]
+        out["tie_order"] = {
+            "reads": n_t, "events_with_children": n_sorts, "events_with_a_tie": n_tie_ev, "tied_adjacent_pairs": n_tie_pairs,
+            "paf_lines_differing_from_stable": {k: sum(1 for a, b in zip(base_cols, v[0]) if a != b) for k, v in legs.items() if k != "stable"},
+            "ties_seen": {k: {"events_with_a_tie": v[1][1], "tied_adjacent_pairs": v[1][2]} for k, v in legs.items()},
+            "note": "oracle/_ref with the tie order of mapper.cpp:531 switched at run time (ref_set_sort_mode); the restated pdqsort is "
+                    "not pinned against upstream's object code"}
     out["sources_added_note"] = ("sources_added_ starts clear for every read on the batch path; the reference leaks it from one read to the "
                                  "next on the same thread (mapper.cpp:88,547,612-623), which only matters after a read that filled max_paths and "
                                  "is order-dependent with -t > 1 (the chunked path, where a channel is one Mapper, reproduces the carry-over)")
@@ -428,7 +446,12 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                          "whole_path_bytes_per_step": ev_bytes + map_bytes,
                          "k_events": {"algorithmic_bytes_per_launch": ev_bytes, "launch_ms": ev_ms,
                                       "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else None}},
-            "verify": {"steps_hashed": len(digests), "all_steps_identical": True, "hits_sha256": digests[0]},
+            "verify": {"steps_hashed": len(digests), "all_steps_identical": True, "hits_sha256": digests[0],
+                       # the only state the reference's Mapper carries from one read into the next (sources_added_, mapper.cpp:88,612-623)
+                       # exists only after a read that filled its path buffer: counted per read by the kernel (unc_hit_t::notes)
+                       "reads_that_filled_max_paths": int(((hits["notes"] & capi.NOTE_PATHS_FULL) != 0).sum()),
+                       "reads_ending_with_sources_added_set": int(((hits["notes"] & capi.NOTE_FLAGS_LEFT) != 0).sum()),
+                       "carry_over_note": "both 0: every read of the batch is mapped exactly as `uncalled map -t 1` maps it in any order"},
         })
         if world == 1 and cpu_budget > 0:
             # the CPU leg and the PAF check run on reads SAMPLED ACROSS the batch (seeded), not on its first reads

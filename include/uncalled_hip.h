@@ -65,6 +65,13 @@ typedef struct { float range, offset, digitisation; } unc_calib_t;
 #define UNC_READ_SORT_FAULT 8u        /* internal: the runs of child keys handed to the merge were not ascending (never expected; result invalid) */
 #define UNC_READ_NORM_FULL 4u          /* chunked path: >= 6000 unread events (the reference's #SKIP branch, mapper.cpp:336-351) */
 
+/* per-read notes (unc_hit_t::notes): conditions under which the reference's Mapper carries state from one read into the NEXT read
+ * mapped by the same thread -- which the batch path, where every read starts from a fresh Mapper, does not reproduce (with
+ * `-t N > 1` the reference's own outcome then depends on which thread gets which read).  A batch whose reads carry neither
+ * note is mapped exactly as `uncalled map -t 1` maps it, whatever the order. */
+#define UNC_NOTE_PATHS_FULL 1u         /* after some event the path buffer held max_paths paths (mapper.cpp:480,507,521,543,577,607) */
+#define UNC_NOTE_FLAGS_LEFT 2u         /* sources_added_ flags were still set when the read ended (mapper.cpp:88,612-623) */
+
 /* One PAF record's worth of coordinates (Paf, read_buffer.hpp:42-126; set by Mapper::set_ref_loc,
  * mapper.cpp:708-728) plus the work counters of SURVEY.md section 8(d). */
 typedef struct {
@@ -83,6 +90,8 @@ typedef struct {
     float map_ms;                       /* batch path: time the read spent on the device, first event taken up -> result written
                                          * (device wall clock; the PAF `mt` tag, mapper.cpp:197).  Reads share wavefronts in time
                                          * slices, so this is residence, not service time.  0 on the chunked / trace paths */
+    uint32_t notes;                     /* UNC_NOTE_* bits: not errors, the result is valid */
+    uint32_t pad_;
 } unc_hit_t;
 
 /* stage tap: per-read result of the event/normalisation kernel */

@@ -18,7 +18,7 @@ O_CLUSTER = np.dtype([("ref_st", "<u8"), ("ref_en_start", "<u8"), ("ref_en_end",
 O_HIT = np.dtype([("mapped", "<i4"), ("fwd", "<i4"), ("rid", "<i4"), ("matches", "<u4"),
                   ("rd_st", "<u8"), ("rd_en", "<u8"), ("rd_len", "<u8"),
                   ("rf_st", "<u8"), ("rf_en", "<u8"), ("rf_len", "<u8"),
-                  ("n_events", "<u4"), ("event_i", "<u4"), ("mean_event_len", "<f4"), ("pad", "<u4"),
+                  ("n_events", "<u4"), ("event_i", "<u4"), ("mean_event_len", "<f4"), ("notes", "<u4"),
                   ("n_nbr", "<u8"), ("n_sa", "<u8"), ("n_lf", "<u8"), ("cluster", O_CLUSTER)])
 
 

@@ -57,6 +57,9 @@ def lib():
         L.ref_map_batch.restype = C.c_double
         L.ref_chunk_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RefHit), C.POINTER(C.c_uint32)]
         L.ref_set_max_chunks.argtypes = [C.c_uint32]
+        L.ref_set_sort_mode.argtypes = [C.c_int]
+        L.ref_sort_stats.argtypes = [C.c_void_p, C.c_int]
+        L.ref_sort_selftest.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.ref_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.ref_events.restype = C.c_uint32
         L.ref_norm_levels.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -97,6 +100,25 @@ def init(prefix, preset="default", max_events=0):
 def set_max_paths(n):
     lib().ref_set_max_paths.argtypes = [C.c_uint32]
     lib().ref_set_max_paths(n)
+
+
+SORT_STABLE, SORT_PDQ_RESTATED, SORT_REVERSED_TIES = 0, 1, 2
+
+
+def set_sort_mode(mode):
+    """order of children that tie on (fm_range_, seed_prob_) at mapper.cpp:531 (oracle/shim/pdqsort.h), for every sort from now on"""
+    lib().ref_set_sort_mode(int(mode))
+
+
+def sort_stats(reset=False):
+    """(sorts = events with children, sorts that had a tied adjacent pair, tied adjacent pairs) since the last reset"""
+    out = np.zeros(3, dtype=np.uint64)
+    lib().ref_sort_stats(out.ctypes.data, 1 if reset else 0)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def sort_selftest(n, seed, key_range, shape=0):
+    return int(lib().ref_sort_selftest(n, seed, key_range, shape))
 
 
 def set_params(p):

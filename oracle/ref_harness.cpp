@@ -235,6 +235,37 @@ int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len
 
 void ref_set_max_chunks(uint32_t max_chunks) { ReadBuffer::PRMS.max_chunks = max_chunks; }
 
+void ref_set_sort_mode(int mode) { unc_shim::sort_mode() = mode; }
+/* the restated pattern-defeating quicksort on n pseudo-random keys drawn from [0, key_range) (many duplicates when the range is
+ * small; ascending / descending / organ-pipe inputs for shape 1 / 2 / 3): 0 when the output is ascending and a permutation of
+ * the input, else the first failing check */
+int ref_sort_selftest(uint32_t n, uint32_t seed, uint32_t key_range, int shape) {
+    struct E { uint32_t key, id; bool operator<(const E &o) const { return key < o.key; } };
+    std::vector<E> v(n);
+    uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1u);
+    for (uint32_t i = 0; i < n; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        uint32_t k = (uint32_t)(x >> 33) % (key_range ? key_range : 1u);
+        if (shape == 1) k = (uint32_t)((uint64_t)i * key_range / (n ? n : 1u));
+        else if (shape == 2) k = (uint32_t)((uint64_t)(n - 1u - i) * key_range / (n ? n : 1u));
+        else if (shape == 3) k = (uint32_t)((uint64_t)(i < n / 2 ? i : n - 1u - i) * key_range / (n ? n : 1u));
+        v[i].key = k; v[i].id = i;
+    }
+    std::vector<E> in = v;
+    unc_shim::pdq::sort(v.begin(), v.end(), std::less<E>());
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i && v[i].key < v[i - 1].key) return 1;
+        if (v[i].id >= n || seen[v[i].id] || in[v[i].id].key != v[i].key) return 2;
+        seen[v[i].id] = 1;
+    }
+    return 0;
+}
+void ref_sort_stats(uint64_t *out3, int reset) {
+    out3[0] = unc_shim::sorts().load(); out3[1] = unc_shim::tie_events().load(); out3[2] = unc_shim::tie_pairs().load();
+    if (reset) { unc_shim::sorts().store(0); unc_shim::tie_events().store(0); unc_shim::tie_pairs().store(0); }
+}
+
 void ref_rt_tap(void *mp, ref_rt_tap_t *out, float *ring, uint32_t ring_cap) {
     Mapper *m = static_cast<Mapper *>(mp);
     std::memset(out, 0, sizeof *out);

@@ -49,6 +49,13 @@ void ref_set_max_paths(uint32_t max_paths);
 void ref_set_params(uint32_t min_rep_len, uint32_t max_rep_copy, uint32_t max_paths, uint32_t max_consec_stay, uint32_t max_events,
                     float max_stay_frac, float min_seed_prob, float threshold1, float threshold2, float peak_height,
                     float min_mean, float max_mean, uint32_t min_map_len, float min_mean_conf, float min_top_conf);
+/* How oracle/shim/pdqsort.h orders children that TIE on (fm_range_, seed_prob_) at mapper.cpp:531 -- 0 creation order (stable; the
+ * project's convention), 1 pattern-defeating quicksort as restated there, 2 reversed creation order -- for every sort from now
+ * on, and what the sorts have seen since the last reset: out[0] sorts (events with children), out[1] sorts with at least one
+ * tied adjacent pair, out[2] tied adjacent pairs. */
+void ref_set_sort_mode(int mode);
+void ref_sort_stats(uint64_t *out3, int reset);
+int ref_sort_selftest(uint32_t n, uint32_t seed, uint32_t key_range, int shape);   /* the restated sort itself; 0 = ok */
 void *ref_mapper_new(void);
 void ref_mapper_free(void *m);
 

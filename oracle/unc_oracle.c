@@ -987,6 +987,7 @@ static int map_next(unc_o_mapper_t *m) {
         }
     }
 
+    if (nn == max_paths) m->hit.notes |= UNC_O_NOTE_PATHS_FULL;   /* next_path == next_paths_.end(): a child or a source may have been left out */
     m->prev_size = nn;
     path_t *tmp = m->prev_paths; m->prev_paths = m->next_paths; m->next_paths = tmp;
 
@@ -1038,6 +1039,9 @@ void unc_o_trace_finish(unc_o_mapper_t *m, unc_o_hit_t *out) {
     h->n_events = m->n_means;
     h->event_i = m->event_i;
     h->mean_event_len = m->evdt.total_events ? evdt_mean_event_len(&m->evdt) : 0.0f;
+    /* sources_added_ is not cleared between reads (mapper.cpp:88,612-623): what is set now is seen by the Mapper's next read */
+    for (uint32_t k = 0; k < UNC_O_NKMER; ++k)
+        if (m->sources_added[k]) { h->notes |= UNC_O_NOTE_FLAGS_LEFT; break; }
     minibwa_counters_t c1;
     minibwa_counters_get(&c1);
     h->n_nbr = c1.n_2occ - m->c0.n_2occ;

@@ -62,10 +62,16 @@ typedef struct {
     uint64_t rf_st, rf_en, rf_len;
     uint32_t n_events, event_i;
     float mean_event_len;
-    uint32_t pad;
+    uint32_t notes;                     /* UNC_O_NOTE_* */
     uint64_t n_nbr, n_sa, n_lf;         /* SURVEY 8(d) work counters */
     unc_o_cluster_t cluster;            /* the winning SeedTracker::max_map_ (zero if unmapped) */
 } unc_o_hit_t;
+
+/* what a read ran into that the reference does not report but that decides whether Mapper state leaks into the NEXT read of the
+ * same Mapper: the path buffer was full after some event (next_path == next_paths_.end(), mapper.cpp:480,507,521,543,577,607), and
+ * sources_added_ flags were still set when the read ended (mapper.cpp:612-623 clears them only on the way to the buffer's end) */
+#define UNC_O_NOTE_PATHS_FULL 1u
+#define UNC_O_NOTE_FLAGS_LEFT 2u
 
 typedef struct unc_o_index unc_o_index_t;
 typedef struct unc_o_mapper unc_o_mapper_t;

@@ -5,7 +5,7 @@ from oracle import pyoracle as po
 from uncalled_amd import capi
 
 HIT_INT_FIELDS = ("mapped", "fwd", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "rf_len", "matches",
-                  "n_events", "event_i", "n_nbr", "n_sa", "n_lf")
+                  "n_events", "event_i", "n_nbr", "n_sa", "n_lf", "notes")
 
 
 def oracle_hits(oix, raw, offsets, calib, params=None, fresh_mapper_per_read=False):

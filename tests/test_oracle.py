@@ -357,3 +357,37 @@ def test_edge_case_reads_equal_live_reference(oracle_lib, ref_lib, example):
         assert (int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (q.event_i, q.n_nbr, q.n_sa, q.n_lf), i
         mapped_some += 1
     assert mapped_some > 20
+
+
+def test_tie_order_of_the_unstable_sort_is_counted_not_assumed(ref_lib, example, goldens):
+    """mapper.cpp:531 sorts the children with orlp/pdqsort (unstable, un-vendored).  oracle/shim/pdqsort.h offers three tie orders at
+    run time -- creation order (the project's convention), pattern-defeating quicksort restated from its published algorithm, and
+    creation order reversed -- and counts the ties.  Pinned here: the restated sort sorts (duplicates, sorted / reversed /
+    organ-pipe inputs, sizes around its thresholds 24 and 128); ties DO occur on the golden reads (one event in ten has one); and no
+    PAF line of the 48 reads depends on their order.  (Work counters of a few reads do: a tie can decide which of two lineages with
+    the same range and seed probability lives on.  bench.py reports the same counts on its own reads.)"""
+    pr = ref_lib
+    bad = [(n, s, k, sh) for n in (0, 1, 2, 23, 24, 25, 127, 128, 129, 130, 1000, 20000) for s in range(3)
+           for k in (1, 2, 7, 1000, 1 << 30) for sh in range(4) if pr.sort_selftest(n, s, k, sh)]
+    assert not bad, bad
+    pr.init(example["prefix"])
+    from oracle import pyoracle as po
+    off = goldens["sim_offsets"]
+    n = off.size - 1
+    sig = po.calibrate(goldens["sim_signal"][:int(off[n])], CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    seen = {}
+    try:
+        for mode in (pr.SORT_STABLE, pr.SORT_PDQ_RESTATED, pr.SORT_REVERSED_TIES):
+            pr.set_sort_mode(mode)
+            pr.sort_stats(reset=True)
+            hits, _ = pr.map_batch(sig, off[:n + 1], 4)
+            seen[mode] = ([h.paf_cols() for h in hits], [(h.event_i, h.n_nbr, h.n_sa) for h in hits], pr.sort_stats())
+    finally:
+        pr.set_sort_mode(pr.SORT_STABLE)
+    sorts, tie_events, tie_pairs = seen[pr.SORT_STABLE][2]
+    assert sorts > 10000 and tie_events > sorts // 20 and tie_pairs >= tie_events
+    for mode in (pr.SORT_PDQ_RESTATED, pr.SORT_REVERSED_TIES):
+        assert seen[mode][0] == seen[pr.SORT_STABLE][0], mode
+        assert seen[mode][2][0] == sorts
+    # the order is not without effect: some read's work counters move under the reversed order
+    assert seen[pr.SORT_REVERSED_TIES][1] != seen[pr.SORT_STABLE][1]

@@ -43,7 +43,9 @@ HIT = np.dtype([("mapped", "<i4"), ("fwd", "<i4"), ("rid", "<i4"), ("status", "<
                 ("matches", "<u4"), ("n_events", "<u4"), ("event_i", "<u4"), ("mean_event_len", "<f4"),
                 ("n_nbr", "<u8"), ("n_sa", "<u8"), ("n_lf", "<u8"),
                 ("cl_ref_st", "<u8"), ("cl_ref_en_start", "<u8"), ("cl_ref_en_end", "<u8"),
-                ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("map_ms", "<f4")])
+                ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("map_ms", "<f4"),
+                ("notes", "<u4"), ("pad_", "<u4")])
+NOTE_PATHS_FULL, NOTE_FLAGS_LEFT = 1, 2      # unc_hit_t::notes (include/uncalled_hip.h)
 # every field of a hit but the timing one: what two runs over the same reads must agree on
 RESULT_FIELDS = tuple(n for n in HIT.names if n != "map_ms")
 

@@ -111,6 +111,7 @@ struct WaveCtx {
     uint32_t conf;                                   // the confidence test passed
     uint32_t par_unsorted;                           // narrow keys: the surviving parents were not in ascending range order (never expected)
     uint32_t walked;                                 // phase S walked the keys as it merged them: no separate walk
+    uint32_t notes;                                  // UNC_NOTE_* of the read so far
 };
 __shared__ WaveCtx s_w;
 __shared__ Tracker s_T;       // SeedTracker's scalars between the events that touch them
@@ -1021,7 +1022,10 @@ static __device__ __noinline__ void phase_F(kargs_t A_, gptr_t sb_, int lane) {
     wave_sync();
     const uint32_t nsrc_total = ent - n;
     for (uint32_t q = (uint32_t)lane; q < nsrc_total; q += WAVE) gst(sb, nord_off + ((n_surv + q) << 2), n + q);
-    if (lane == 0) { s_w.n_parents = n_surv + nsrc_total; s_w.n_surv_par = n_surv; s_w.cur = cur ^ 1u; }
+    if (lane == 0) {
+        s_w.n_parents = n_surv + nsrc_total; s_w.n_surv_par = n_surv; s_w.cur = cur ^ 1u;
+        if (ent >= max_paths) s_w.notes |= UNC_NOTE_PATHS_FULL;      // next_path == next_paths_.end(): something may have been left out
+    }
     wave_sync();
 }
 
@@ -1118,6 +1122,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         uint32_t r = 0, event_i, n_parents, cur;
         uint32_t n_surv_par = 0;                     // the first n_surv_par parents are the last walk's survivors (sorted)
         uint32_t tstatus = 0;                        // UNC_READ_* bits (mirror of the tracker's status)
+        uint32_t notes = 0;                          // UNC_NOTE_* bits
         Tracker T;
         uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters
         uint64_t t_start = (uint64_t)wall_clock64();  // when the read was taken up (a parked read brings its own)
@@ -1166,6 +1171,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         if ((resume && !fresh) || restore) {
             r = restore ? uniform32(st->read_idx) : blockIdx.x; event_i = st->event_i; n_parents = st->n_parents; cur = st->cur;
             n_surv_par = uniform32(st->n_surv);
+            notes = uniform32(st->notes);
             T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
             T.status = st->status; T.len_sum = st->len_sum; T.n_alloc = st->n_alloc;
             T.mm.ref_st = st->max_map.ref_st; T.mm.rstart = st->max_map.rstart; T.mm.rend = st->max_map.rend;
@@ -1210,6 +1216,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         if (lane == 0) {
             s_T = T;
             s_w.event_i = event_i; s_w.n_parents = n_parents; s_w.cur = cur; s_w.n_surv_par = n_surv_par; s_w.tstatus = tstatus;
+            s_w.notes = notes;
         }
         wave_sync();
         const uint32_t n_events = A->rd.info[r].n_events;
@@ -1262,6 +1269,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             clk.end(7, lane);
         }
         n_parents = ctx_get(s_w.n_parents); cur = ctx_get(s_w.cur); n_surv_par = ctx_get(s_w.n_surv_par);
+        notes = ctx_get(s_w.notes);
+        // sources_added_ flags that are still set when the read is decided: the reference's Mapper takes them into its next read
+        if (done && __any(lane < NKMER / 32 && s_flags[lane < NKMER / 32 ? lane : 0] != 0u)) notes |= UNC_NOTE_FLAGS_LEFT;
 
         // ---------------- publish / park ----------------
         const uint64_t t_nbr = wave_sum64(c_nbr), t_sa = wave_sum64(c_sa), t_lf = wave_sum64(c_lf);
@@ -1270,7 +1280,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         T.n_alloc = uniform32(T.n_alloc);
         if (done && lane == 0) {
             DevResult res;
-            res.done = done; res.status = T.status; res.event_i = event_i; res.pad = 0;
+            res.done = done; res.status = T.status; res.event_i = event_i; res.notes = notes;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
             res.ticks = resume ? 0ull : (uint64_t)wall_clock64() - t_start; res.pad2 = 0;
@@ -1289,7 +1299,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
                 st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
-                st->reserved0 = 0; st->n_alloc = T.n_alloc;
+                st->notes = done ? 0u : notes; st->n_alloc = T.n_alloc;
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
                 if constexpr (PROF) {
                     if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; }

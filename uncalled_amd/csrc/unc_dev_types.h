@@ -85,7 +85,7 @@ struct alignas(16) SlotState {
     uint32_t cur;            // which of the two path buffers holds the parents
     uint32_t done;           // 0 = mapping, 1 = SUCCESS, 2 = FAILURE
     uint32_t status;
-    uint32_t n_clusters, n_lens, len_max1, len_max2, reserved0, n_alloc;  // n_alloc: nodes taken from the read's own chunks so far
+    uint32_t n_clusters, n_lens, len_max1, len_max2, notes, n_alloc;  // notes: UNC_NOTE_* so far; n_alloc: nodes taken from the read's own chunks so far
     uint32_t n_surv;         // the first n_surv parents are the last walk's survivors, in sorted order (sources follow)
     uint32_t pad_[1];
     float len_sum;
@@ -215,7 +215,7 @@ struct DevReads {
 
 // what the map kernel hands back per read
 struct alignas(16) DevResult {
-    uint32_t done, status, event_i, pad;
+    uint32_t done, status, event_i, notes;     // notes: UNC_NOTE_* (unc_hit_t::notes)
     ClusterVal cluster;
     uint64_t n_nbr, n_sa, n_lf;
     uint64_t ticks;    // device wall clock ticks from the read's first event to this result

@@ -735,6 +735,7 @@ static void fill_hit(const unc_index *ix, const unc_params_t &P, const DevResult
     h->map_ms = ticks_per_ms > 0.0f ? (float)((double)res.ticks / (double)ticks_per_ms) : 0.0f;
     h->rid = -1;
     h->status = res.status;
+    h->notes = res.notes; h->pad_ = 0;
     h->n_events = inf.n_events;
     h->event_i = res.event_i;
     float mel = inf.len_sum / (float)inf.total_events;   // EventDetector::mean_event_len, event_detector.cpp:151-153
