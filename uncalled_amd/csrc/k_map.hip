@@ -687,9 +687,12 @@ __device__ __forceinline__ void walk_decode_narrow(WalkState<NARROW> &S, uint32_
     uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
     if (lane == 0) pr = S.carry_range;
     const bool rhead = !have || ri != pr;
-    sb_ = seg_incl_max64(bi, rhead);
     const uint64_t rheads = __ballot(rhead);
-    if ((rheads & ((2ull << lane) - 1ull)) == 0 && S.carry_w > sb_) sb_ = S.carry_w;
+    sb_ = bi;
+    if (rheads != ~0ull) {          // (nearly every pass: no two equal ranges, no scan)
+        sb_ = seg_incl_max64(bi, rhead);
+        if ((rheads & ((2ull << lane) - 1ull)) == 0 && S.carry_w > sb_) sb_ = S.carry_w;
+    }
     S.carry_range = bcast64(ri, (int)nv - 1);
     S.carry_w = bcast64(sb_, (int)nv - 1);
 }
