@@ -122,6 +122,10 @@ typedef struct unc_mapper unc_mapper_t;
 
 const char *unc_last_error(void);
 const char *unc_version(void);
+/* PCI address ("0000:c1:00.0") of HIP device `device` as this library numbers the devices (hipDeviceGetPCIBusId): what the
+ * one-process-per-GPU launchers look up under /sys/bus/pci/devices/<address>/numa_node to keep a worker's host threads on its GPU's
+ * NUMA node (the reference has no counterpart: its workers are threads of one process, map_pool.cpp:31-42).  UNC_OK or an error. */
+int unc_device_pci_address(int device, char *out, int cap);
 /* page-locked host memory for batches handed to unc_map_batch with on_device == 0 (the copy to HBM then runs at full
  * PCIe rate and asynchronously); NULL on failure */
 void *unc_host_alloc(uint64_t bytes);

@@ -243,6 +243,7 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+static inline hipError_t hipDeviceGetPCIBusId(char *out, int cap, int dev) { std::snprintf(out, (size_t)cap, "0000:%02X:00.0", 0xC1 + dev); return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { std::free(p); return 0; }

@@ -122,10 +122,17 @@ def case_oversized_chunk_is_refused(unc):
     assert not pool.add_chunk(unc.Chunk("big", 1, 1, 0, noise, 0, 4001))
     assert not pool.try_add_chunk(unc.Chunk("big", 1, 1, 0, noise, 0, 8000))
     assert pool.update() == [] and pool.active_count() == 0 and pool.all_finished()
+    assert pool.refused_chunks() == 2
     assert pool.add_chunk(unc.Chunk("ok", 1, 2, 0, noise, 0, 4000))           # the channel still takes a regular chunk
     assert pool.update() == [] and pool.active_count() == 1
-    assert not pool.add_chunk(unc.Chunk("ok", 1, 2, 4000, noise, 4000, 5000))  # ... and refuses an oversized one mid-read
-    assert pool.active_count() == 1
+    # ... and an oversized one mid-read is refused AND ends the read (unmapped + ended at the next update): the channel is free again
+    assert not pool.add_chunk(unc.Chunk("ok", 1, 2, 4000, noise, 4000, 5000))
+    assert pool.active_count() == 0 and pool.refused_chunks() == 3
+    out = pool.update()
+    assert len(out) == 1 and out[0][0] == 1 and out[0][1] == 2 and out[0][2].is_ended() and not out[0][2].is_mapped()
+    assert str(out[0][2]).split("\t")[0] == "ok" and int(str(out[0][2]).split("\t")[1]) == int(4000 * 450.0 / 4000.0)
+    assert pool.all_finished()
+    assert pool.add_chunk(unc.Chunk("next", 1, 3, 0, noise, 0, 4000)) and pool.active_count() == 1
 
 
 def case_client_sim_feeds_the_decision_loop(unc, tmp_path, goldens):

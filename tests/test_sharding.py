@@ -139,3 +139,11 @@ def test_numa_placement_plan(tmp_path):
     assert cpus == sorted(allowed) and how == "left as is"
     out = numa.pin_to_gpu_node(0, 1, str(sysfs))                                     # never raises, also without a GPU
     assert "how" in out
+
+
+def test_gpu_pci_address_comes_from_the_c_abi(sim_lib):
+    """round-3 advice: the address is asked of libuncalled_hip.so (unc_device_pci_address -> hipDeviceGetPCIBusId, lower-cased as
+    sysfs spells it), not of torch; the emulator's HIP stub answers 0000:C1:00.0 for device 0."""
+    from uncalled_amd import numa
+    assert numa.gpu_pci_address(0, lib=sim_lib) == "0000:c1:00.0"
+    assert numa.gpu_pci_address(1, lib=sim_lib) == "0000:c2:00.0"

@@ -131,7 +131,8 @@ PYBIND11_MODULE(_uncalled_amd, m) {
         .def("all_finished", &RealtimePool::all_finished)
         .def("stop_all", &RealtimePool::stop_all)
         .def("active_count", &RealtimePool::active_count)
-        .def("last_round_ms", &RealtimePool::last_round_ms);
+        .def("last_round_ms", &RealtimePool::last_round_ms)
+        .def("refused_chunks", &RealtimePool::refused_chunks);
     py::enum_<RealtimePool::Mode>(rp, "RealtimeMode" UNC_ML).value("DEPLETE", RealtimePool::DEPLETE).value("ENRICH", RealtimePool::ENRICH).export_values();
     py::enum_<RealtimePool::ActiveChs>(rp, "ActiveChs" UNC_ML)
         .value("FULL", RealtimePool::FULL).value("EVEN", RealtimePool::EVEN).value("ODD", RealtimePool::ODD).export_values();

@@ -88,13 +88,26 @@ static void remember_old(RealtimePool::Chan &c) {
 
 // A chunk longer than chunk_time * sample_rate does not fit the per-channel staging of the device side: it is refused here
 // (add_chunk / try_add_chunk return false, as for a channel that is still busy) instead of failing the whole round later.
+// Refusals are counted (refused_chunks()).  A refused chunk of the read a channel is busy with ENDS that read -- it is reported
+// unmapped + ended by the next update(), as after request_reset -- so that the channel takes the next read instead of waiting for
+// a chunk that will never be accepted (round-3 advice).
 bool RealtimePool::oversized(const Chunk &chunk) {
     const uint64_t cap = (uint64_t)(prms_.chunk_time * prms_.sample_rate);
     if (chunk.size() <= cap) return false;
+    ++refused_chunks_;
     if (!warned_oversized_) {
         std::cerr << "Warning: chunk of " << chunk.size() << " samples on channel " << chunk.get_channel() << " is longer than chunk_time * sample_rate = "
-                  << cap << " and was refused (further ones are refused silently)\n";
+                  << cap << " and was refused; its read is ended (further ones are counted: refused_chunks)\n";
         warned_oversized_ = true;
+    }
+    const uint16_t ch = chunk.get_channel_idx();
+    if (ch < chans_.size()) {
+        Chan &c = chans_[ch];
+        if ((c.active || c.has_pending) && c.number == chunk.get_number()) {
+            remember_old(c);
+            c.active = false; c.has_pending = false; c.pending_first = false;
+            c.pending.clear();
+        }
     }
     return true;
 }

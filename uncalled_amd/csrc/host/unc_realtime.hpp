@@ -60,6 +60,7 @@ public:
     bool is_stopped() const { return stopped_; }
     uint32_t active_count() const;
     float last_round_ms() const { return last_ms_; }
+    uint64_t refused_chunks() const { return refused_chunks_; }     // chunks longer than chunk_time * sample_rate, never staged
 
     struct Chan {
         bool active = false;         // a read is being mapped (Mapper state MAPPING; its last chunk is fully mapped)
@@ -83,6 +84,7 @@ private:
     std::vector<Chan> chans_;
     bool stopped_ = false;
     bool warned_oversized_ = false;
+    uint64_t refused_chunks_ = 0;
     bool oversized(const Chunk &chunk);
     float last_ms_ = 0;
 };

@@ -40,6 +40,12 @@ static int fail(int code, const char *fmt, ...) {
 
 extern "C" const char *unc_last_error(void) { return g_err; }
 extern "C" const char *unc_version(void) { return "uncalled_hip 0.2 (gfx950)"; }
+extern "C" int unc_device_pci_address(int device, char *out, int cap) {
+    if (!out || cap < 13) return fail(UNC_ERR_ARG, "unc_device_pci_address: room for 13 characters is needed");
+    HIPCHK(hipDeviceGetPCIBusId(out, cap, device));
+    for (char *p = out; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells addresses in lower case
+    return UNC_OK;
+}
 extern "C" void *unc_host_alloc(uint64_t bytes) {
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -851,7 +857,12 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                 int rc2 = run_round(sc, slots);
                 if (rc2) return rc2;
                 if (!dry.empty()) {
-                    if (slots <= 1) break;           // one read with the whole pool to itself and still dry: reported (raise pool_chunks)
+                    if (slots <= 1) {
+                        // every read of this round had the whole pool to itself and is still dry: reported with its status (raise
+                        // pool_chunks); the reads waiting in `full` for a larger allowance go on (round-3 advice: they were abandoned)
+                        dry.clear();
+                        continue;
+                    }
                     limit = std::max<size_t>(1, slots / 4);
                 }
                 continue;
@@ -1224,6 +1235,19 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
         // decided; a read that finds the pool dry fails with its status set (there is no second pass in chunked mode).
         size_t per_ch = ix->seq_len >= (1ull << 26) ? 64 : 16;
         size_t n_chunks = S * per_ch;
+        {
+            // never more than 60 % of the HBM that is free now (the batch path's rule): next to a dense SA, or on a smaller GPU,
+            // the pool shrinks -- with a warning, and never below four chunks per channel -- instead of failing the whole create
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            const size_t fit = free_b / 5 * 3 / POOL_CHUNK_BYTES;
+            if (n_chunks > fit) {
+                const size_t floor_chunks = std::max<size_t>(64, (size_t)S * 4);
+                const size_t clamped = std::max(fit, floor_chunks);
+                fprintf(stderr, "Warning: realtime node pool clamped from %zu to %zu chunks (%.1f GB of HBM free)\n", n_chunks, clamped, (double)free_b / 1e9);
+                n_chunks = clamped;
+            }
+        }
         if (const char *e = getenv("UNC_RT_POOL_CHUNKS")) { const long v = atol(e); if (v > 0) n_chunks = (size_t)v; }
         rc = alloc_pool(rt->pool, (uint32_t)std::max<size_t>(64, n_chunks), &bytes);
         if (rc) return rc;

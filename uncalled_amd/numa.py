@@ -22,12 +22,19 @@ def parse_cpulist(text):
     return cpus
 
 
-def gpu_pci_address(local_rank):
-    """'0000:c1:00.0' of the HIP device `local_rank`, or None (no torch / no GPU)"""
+def gpu_pci_address(local_rank, lib=None):
+    """'0000:c1:00.0' of HIP device `local_rank` as libuncalled_hip.so numbers the devices (unc_device_pci_address: the ordinal a
+    worker passes as --device, under whatever HIP_VISIBLE_DEVICES / ROCR filter is in force), or None when the library cannot
+    say (then the caller falls back to equal core shares, and says so)."""
     try:
-        import torch
-        p = torch.cuda.get_device_properties(local_rank)
-        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        import ctypes as C
+        from . import capi
+        L = lib or capi.load()
+        buf = C.create_string_buffer(32)
+        L.unc_device_pci_address.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        if L.unc_device_pci_address(int(local_rank), buf, 32) != 0:
+            return None
+        return buf.value.decode() or None
     except Exception:
         return None
 
@@ -67,6 +74,8 @@ def pin_to_gpu_node(local_rank, world, sysfs="/sys"):
         cpus, how = plan(local_rank, world, allowed, bdf, sysfs)
         if set(cpus) != set(allowed):
             os.sched_setaffinity(0, cpus)
+        if bdf is None:
+            how += " (the GPU's PCI address could not be read)"
         return {"gpu": bdf, "cpus": len(cpus), "first_cpu": cpus[0] if cpus else None, "how": how}
     except Exception as e:      # placement is an optimisation, never a reason to stop
         return {"gpu": None, "cpus": None, "how": f"not pinned: {e!r}"}
