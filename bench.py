@@ -384,7 +384,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     wave_busy = mapper.last_wave_busy()
     remap_n, remap_ms = mapper.last_remap()
     res = {"value": n_reads * world * steps / dt, "ms_per_step": 1e3 * dt / steps, "dt": dt}
-    pcie, phase_share = None, None
+    pcie, phase_share, t1_info = None, None, None
     if extras and rank == 0 and world == 1:
         if have_gpu and workload == "ecoli":
             # the boundary also takes host buffers (unc_map_batch on_device = 0): one extra, untimed step from pageable host
@@ -395,6 +395,23 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
             pcie = n_reads / (time.perf_counter() - t1)
             assert capi.hits_digest(h2) == digests[0], "host-buffer path differs from the device-buffer path"
             del host_raw
+        # `uncalled map -t 1` order: one extra, untimed pass with sources_added_ carried from read to read (UNC_ORDER_T1): what it costs
+        # and how many reads it changes against the independent order of the timed steps
+        if hasattr(mapper.L, "unc_mapper_set_read_order"):
+            mapper.set_read_order(capi.ORDER_T1)
+            t1 = time.perf_counter()
+            ht = one_step()
+            t1 = time.perf_counter() - t1
+            n_again, rounds, ms_again = mapper.last_carry_over()
+            mapper.set_read_order(capi.ORDER_INDEPENDENT)
+            changed = [f for f in capi.RESULT_FIELDS if not np.array_equal(ht[f], hits[f])]
+            t1_info = {"reads_mapped_again": n_again, "rounds": rounds, "ms_spent_on_them": round(ms_again, 1), "step_s": round(t1, 3),
+                       "reads_whose_result_changed": int(np.any([ht[f] != hits[f] for f in capi.RESULT_FIELDS if f != "notes"], axis=0).sum()),
+                       "reads_whose_paf_columns_changed": int(np.any([ht[f] != hits[f] for f in ("mapped", "fwd", "rid", "rd_st", "rd_en", "rd_len", "rf_st", "rf_en", "matches")], axis=0).sum()),
+                       "fields_that_changed": changed,
+                       "note": "UNC_ORDER_T1 = the reads of the batch as ONE Mapper maps them back to back (parity: tests/parity_cases.py:case_read_order_t1, "
+                               "oracle pinned on the reference's Mapper in tests/test_oracle.py); the timed steps use the independent order"}
+            del ht
         # phase shares: one extra, untimed pass with the cycle-counting instantiation of k_map
         prof_reads = min(n_reads, 50000)
         mapper.set_profile(True)
@@ -451,7 +468,8 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        # exists only after a read that filled its path buffer: counted per read by the kernel (unc_hit_t::notes)
                        "reads_that_filled_max_paths": int(((hits["notes"] & capi.NOTE_PATHS_FULL) != 0).sum()),
                        "reads_ending_with_sources_added_set": int(((hits["notes"] & capi.NOTE_FLAGS_LEFT) != 0).sum()),
-                       "carry_over_note": "both 0: every read of the batch is mapped exactly as `uncalled map -t 1` maps it in any order"},
+                       "carry_over_note": "both 0: every read of the batch is mapped exactly as `uncalled map -t 1` maps it in any order",
+                       "t1_order": t1_info},
         })
         if world == 1 and cpu_budget > 0:
             # the CPU leg and the PAF check run on reads SAMPLED ACROSS the batch (seeded), not on its first reads

@@ -217,6 +217,18 @@ void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, float *ms);
 /* mean lifetime of the persistent wavefronts of the last batch's k_map launch / the launch duration (both from the
  * device wall clock): 1.0 = every wavefront worked until the end, lower = idle tail behind the longest reads */
 double unc_mapper_last_wave_busy(const unc_mapper_t *m);
+/* In which order the reads handed to unc_map_batch are to be understood (the reference: N worker threads with one Mapper each,
+ * map_pool.cpp:31-42; the ONE piece of Mapper state that Mapper::new_read does not reset is sources_added_, mapper.cpp:88,612-623):
+ *   UNC_ORDER_INDEPENDENT  every read as a fresh Mapper maps it (the default).  What `uncalled map -t N` gives for every read
+ *                          whose predecessor on its thread left no flag set -- all reads without UNC_NOTE_FLAGS_LEFT neighbours
+ *   UNC_ORDER_T1           `uncalled map -t 1`: one Mapper, the reads of a batch in the order given, batch after batch.  A read
+ *                          whose predecessor left flags set is mapped again starting from them (and so on down the chain);
+ *                          unc_mapper_last_carry_over tells how many reads of the last batch that took, in how many rounds and ms.
+ * Setting the order starts a new run (the carried flags are cleared). */
+#define UNC_ORDER_INDEPENDENT 0
+#define UNC_ORDER_T1 1
+int unc_mapper_set_read_order(unc_mapper_t *m, int order);
+int unc_mapper_last_carry_over(const unc_mapper_t *m, uint32_t *reads, uint32_t *rounds, float *ms);
 /* what the code object says about the k_map instantiation this mapper launches (hipFuncGetAttributes): [0] VGPRs, [1] scratch
  * bytes per lane (spills), [2] static LDS bytes per wavefront, [3] max threads per block, [4] wavefronts per CU the launch
  * bounds are set for, [5] 1 = the 32-bit-row / merged-run instantiation (references below 2^32 rows) */

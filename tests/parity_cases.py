@@ -124,6 +124,41 @@ def case_synthetic_batch(lib, oracle_lib, example, goldens, max_paths, n_reads):
                 assert int(hits[i][name]) == int(goldens["sim_hits"][i][f[name]]), (i, name)
 
 
+def case_read_order_t1(lib, oracle_lib, example, goldens, max_paths, n_reads, split):
+    """UNC_ORDER_T1 = `uncalled map -t 1`: ONE Mapper maps the reads back to back (the oracle with a shared mapper; pinned against the
+    reference's own Mapper in test_oracle.py), sources_added_ travelling from read to read -- within a batch and, here, across the
+    two batches the reads are handed over in.  A small max_paths makes nearly every read leave flags behind; the case also checks
+    that this matters (the independent order gives different answers on the same reads), so that it cannot pass vacuously."""
+    dev_index = _index(lib, example)
+    p = capi.default_params(dev_index.L)
+    p.max_paths = max_paths
+    off_all = goldens["sim_offsets"]
+    raw = goldens["sim_signal"][:int(off_all[n_reads])]
+    off = off_all[:n_reads + 1].copy()
+    cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    oix = oracle_lib.Index(example["prefix"])
+    want = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=False)
+    indep = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True)
+    differ = [i for i in range(n_reads) if any(int(want[i][f]) != int(indep[i][f]) for f in ("event_i", "n_nbr", "n_sa", "mapped", "rf_st"))]
+    assert differ, "the carry-over changes nothing on these reads: the case proves nothing"
+    m = capi.Mapper(dev_index, params=p, n_slots=3)
+    m.set_read_order(capi.ORDER_T1)
+    a = m.map_batch(raw[:int(off[split])], off[:split + 1].copy(), cal[:split])
+    n_a = m.last_carry_over()[0]
+    b_off = (off[split:] - off[split]).astype(np.uint64)
+    b = m.map_batch(raw[int(off[split]):], b_off, cal[split:])
+    n_b = m.last_carry_over()[0]
+    assert_hits_equal(np.concatenate([a, b]), want, f"-t 1 order, max_paths={max_paths}")
+    assert n_a + n_b > 0
+    # a new run starts clear: the first read again as a fresh Mapper maps it
+    m.set_read_order(capi.ORDER_T1)
+    again = m.map_batch(raw[:int(off[1])], off[:2].copy(), cal[:1])
+    assert_hits_equal(again, indep[:1], "first read of a new run")
+    # ... and the default order is untouched by all this
+    m.set_read_order(capi.ORDER_INDEPENDENT)
+    assert_hits_equal(m.map_batch(raw, off, cal), indep, "independent order")
+
+
 def case_trace_matches_oracle_every_event(lib, oracle_lib, example, goldens, dev_index=None):
     """Path buffer (order, ranges, k-mers, prob-sum windows, flags) and the seed-cluster set after every map_next."""
     dev_index = dev_index or _index(lib, example)

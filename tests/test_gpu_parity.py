@@ -39,6 +39,11 @@ def test_synthetic_batch(hip_lib, oracle_lib, example, goldens, max_paths, n_rea
     pc.case_synthetic_batch(hip_lib, oracle_lib, example, goldens, max_paths, n_reads)
 
 
+@pytest.mark.parametrize("max_paths,n_reads,split", [(97, 24, 7), (130, 32, 20), (200, 48, 1)])
+def test_read_order_t1(hip_lib, oracle_lib, example, goldens, max_paths, n_reads, split):
+    pc.case_read_order_t1(hip_lib, oracle_lib, example, goldens, max_paths, n_reads, split)
+
+
 def test_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens):
     pc.case_trace_matches_oracle_every_event(hip_lib, oracle_lib, example, goldens)
 

@@ -33,6 +33,11 @@ def test_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_rea
     pc.case_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads)
 
 
+@pytest.mark.parametrize("max_paths,n_reads,split", [(97, 6, 2), (130, 8, 5)])
+def test_read_order_t1(sim_lib, oracle_lib, example, goldens, max_paths, n_reads, split):
+    pc.case_read_order_t1(sim_lib, oracle_lib, example, goldens, max_paths, n_reads, split)
+
+
 def test_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens):
     pc.case_trace_matches_oracle_every_event(sim_lib, oracle_lib, example, goldens)
 

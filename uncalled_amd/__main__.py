@@ -337,7 +337,8 @@ def get_parser():
     p.add_argument("-r", "--recursive", action="store_true")
     p.add_argument("-l", "--read-list", type=str, default=None, help="Only map reads with these ids")
     p.add_argument("-n", "--max-reads", type=int, default=None, help="Maximum number of reads to map")
-    p.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility and ignored: reads are batched onto the GPU (one loader and one mapper thread feed it)")
+    p.add_argument("-t", "--threads", type=int, default=1, help="1 (default): the reads are mapped exactly as `uncalled map -t 1` maps them, in input order (the few reads whose predecessor left Mapper state behind are mapped twice); "
+                        "N > 1: every read independently, which is what the reference's N threads give up to their scheduling. No host threads are created either way: reads are batched onto the GPU")
     p.add_argument("--num-channels", type=int, default=512)
     p.add_argument("-e", "--max-events", type=int, default=30000, help="Will give up on a read after this many events have been processed")
     p.add_argument("-c", "--max-chunks", type=int, default=1000000, help="Will give up on a read after this many chunks have been processed")

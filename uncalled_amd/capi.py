@@ -46,6 +46,7 @@ HIT = np.dtype([("mapped", "<i4"), ("fwd", "<i4"), ("rid", "<i4"), ("status", "<
                 ("cl_evt_st", "<u4"), ("cl_evt_en", "<u4"), ("cl_total_len", "<u4"), ("map_ms", "<f4"),
                 ("notes", "<u4"), ("pad_", "<u4")])
 NOTE_PATHS_FULL, NOTE_FLAGS_LEFT = 1, 2      # unc_hit_t::notes (include/uncalled_hip.h)
+ORDER_INDEPENDENT, ORDER_T1 = 0, 1           # unc_mapper_set_read_order
 # every field of a hit but the timing one: what two runs over the same reads must agree on
 RESULT_FIELDS = tuple(n for n in HIT.names if n != "map_ms")
 
@@ -120,6 +121,9 @@ def load(path=None):
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.unc_mapper_last_remap.restype = None
+    if hasattr(L, "unc_mapper_set_read_order"):      # (dev tools load older builds of the library for A/B runs)
+        L.unc_mapper_set_read_order.argtypes = [vp, C.c_int]
+        L.unc_mapper_last_carry_over.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
     L.unc_mapper_kernel_info.argtypes = [vp, vp]
     L.unc_mapper_kernel_info.restype = i32
     L.unc_mapper_geometry.argtypes = [vp, vp]
@@ -302,6 +306,17 @@ class Mapper:
         n, ms = C.c_uint32(), C.c_float()
         self.L.unc_mapper_last_remap(self.h, C.byref(n), C.byref(ms))
         return int(n.value), float(ms.value)
+
+    def set_read_order(self, order):
+        """ORDER_INDEPENDENT (default: every read as a fresh Mapper maps it) or ORDER_T1 (`uncalled map -t 1`: one Mapper, reads in
+        the order given, sources_added_ carried from read to read and batch to batch); see include/uncalled_hip.h"""
+        _check(self.L, self.L.unc_mapper_set_read_order(self.h, int(order)))
+
+    def last_carry_over(self):
+        """ORDER_T1: (reads of the last batch mapped again because their predecessor left flags set, rounds, ms)"""
+        n, r, ms = C.c_uint32(), C.c_uint32(), C.c_float()
+        self.L.unc_mapper_last_carry_over(self.h, C.byref(n), C.byref(r), C.byref(ms))
+        return int(n.value), int(r.value), float(ms.value)
 
     def geometry(self):
         out = np.zeros(5, dtype=np.uint32)

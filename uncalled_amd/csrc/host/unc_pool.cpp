@@ -296,6 +296,14 @@ MapPool::MapPool(const Conf &conf) : conf_(conf), reader_(conf) {
         std::cerr << "Error: " << unc_last_error() << "\n";   // Mapper::load_static aborts on a bad index, mapper.cpp:118-127
         abort();
     }
+    // -t 1 (the reference's default): ONE Mapper maps the reads in input order, and what a read leaves set in sources_added_ is seen
+    // by the next (mapper.cpp:88,612-623).  The C ABI reproduces that order exactly (UNC_ORDER_T1: the few reads whose predecessor
+    // left flags set are mapped a second time); -t N > 1, where the reference's own outcome depends on which thread gets which
+    // read, maps every read independently.
+    if (conf.threads <= 1 && unc_mapper_set_read_order(mapper_, UNC_ORDER_T1) != UNC_OK) {
+        std::cerr << "Error: " << unc_last_error() << "\n";
+        abort();
+    }
     // a batch = four times as many reads as the mapper keeps in flight: every unc_map_batch call ends with the few reads that
     // run to max_events on a nearly idle chip, and at one load of the slots that tail is a third of the call (round 3: 11.5 k
     // reads/s end to end against 17 k in HBM); the FIRST batch is one load of the slots, so that the first PAF lines do not

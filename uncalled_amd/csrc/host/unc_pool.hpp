@@ -22,7 +22,7 @@
 namespace unc_host {
 
 struct Conf {
-    uint16_t threads = 1;            // kept for CLI compatibility; the GPU path batches instead
+    uint16_t threads = 1;            // no host threads are made of it (the GPU path batches); 1 = reads in `-t 1` order (UNC_ORDER_T1), > 1 = independent reads
     std::string bwa_prefix, idx_preset = "default", model_path;
     uint32_t max_events = 30000, seed_len = 22, max_chunks = 1000000, max_reads = 0, max_buffer = 100, num_channels = 512;
     float chunk_time = 1.0f, sample_rate = 4000.0f;

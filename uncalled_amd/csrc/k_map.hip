@@ -1212,7 +1212,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             event_i = 0; n_parents = 0; cur = 0;
             T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_alloc = 0;
             T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
-            if (lane < NKMER / 32) s_flags[lane] = 0;   // sources_added_ starts clear for every read
+            // sources_added_: clear -- every read as a fresh Mapper maps it -- unless the caller hands in what the Mapper's previous
+            // read left behind (the `-t 1` order of unc_mapper_set_read_order; mapper.cpp:88,612-623)
+            if (lane < NKMER / 32) s_flags[lane] = A->flags_in ? A->flags_in[(size_t)r * (NKMER / 32) + (uint32_t)lane] : 0u;
         }
         tstatus = uniform32(T.status);
         wave_sync();
@@ -1293,6 +1295,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         // the read is decided: its nodes go back to the pool at once -- in batch mode and in chunked (realtime) mode, where an idle
         // channel would otherwise pin them until its next read arrives; the step-wise trace (resume without a ring) keeps them
         // readable for unc_trace_clusters
+        if (done && !resume && A->flags_out && lane < NKMER / 32) A->flags_out[(size_t)r * (NKMER / 32) + (uint32_t)lane] = s_flags[lane];
         if (done && (!resume || A->rd.ring_mod)) tracker_release(T, tracker_mem(A, sb), lane);
         if (resume || !done) {
             if (lane == 0) {
@@ -1332,8 +1335,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
 namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
-                const DevPool &pool, const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile) {
+                const DevPool &pool, const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile,
+                const uint32_t *flags_in, uint32_t *flags_out) {
     MapArgs a;
+    a.flags_in = flags_in; a.flags_out = flags_out;
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
     a.ix = ix; a.sc = sc; a.rd = rd; a.P = P; a.results = results; a.next_read = next_read;
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;

@@ -29,6 +29,8 @@ struct MapArgs {
     const uint32_t *read_list;  // batch mode: the queue hands out read_list[t] instead of t (re-runs of selected reads)
     const uint32_t *slot_map;   // resume mode: block b works on scratch slot slot_map[b] (null: slot = b), descriptor b
     unsigned long long *wave_ticks;   // optional: sum over waves of (exit - start) in wall_clock64 ticks (queue-tail probe)
+    const uint32_t *flags_in;   // batch mode, optional: sources_added_ a read STARTS with, [read][NKMER / 32] (null: clear)
+    uint32_t *flags_out;        // batch mode, optional: sources_added_ as the read leaves it, same shape
     DevSched sched;             // batch mode with sched.ctl != null: slots are handed out per task, max_steps = slice length
     DevPool pool;               // nodes of the seed-cluster grids
 };

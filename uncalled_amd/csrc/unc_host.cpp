@@ -13,6 +13,7 @@
 #include <string>
 #include <chrono>
 #include <algorithm>
+#include <array>
 #include <map>
 #include <vector>
 
@@ -472,6 +473,12 @@ struct unc_mapper {
     uint32_t *d_list = nullptr; size_t list_cap = 0;     // read ids of a re-map round
     uint32_t remap_reads = 0;      // reads of the last batch that were mapped again with more room, and what that cost
     float remap_ms = 0;
+    // read order UNC_ORDER_T1 (unc_mapper_set_read_order): sources_added_ travels from a read to the next one, across batches
+    int read_order = 0;
+    uint32_t *d_flags_in = nullptr, *d_flags_out = nullptr; size_t flags_cap = 0;
+    uint32_t carry_flags[NKMER / 32] = {0};     // what the last read of the previous batch left set
+    uint32_t carry_reads = 0, carry_rounds = 0; // reads of the last batch mapped again because their predecessor left flags set
+    float carry_ms = 0;
     uint32_t *d_next = nullptr;
     // per-batch buffers (grown on demand)
     int16_t *d_raw = nullptr; size_t raw_cap = 0;
@@ -571,7 +578,7 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     free_scratch(m->sc);
     free_scratch(m->big);
     void *ptrs[] = {m->d_next, m->d_raw, m->d_offsets, m->d_moff, m->d_calib, m->d_info, m->d_results, m->d_means,
-                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells, m->d_list};
+                    m->sched.ctl, m->sched.free_cells, m->sched.park_cells, m->d_list, m->d_flags_in, m->d_flags_out};
     free_pool(m->pool);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
@@ -789,8 +796,24 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     const bool sliced = m->sched.ctl != nullptr && n_reads > m->n_waves;
     if (sliced) launch_sched_init(m->sched, st);
     launch_pool_init(m->pool, st);       // every chunk free: nothing outlives a batch
+    constexpr size_t FW = NKMER / 32;      // words of one read's sources_added_ bitmap
+    const bool t1 = m->read_order == UNC_ORDER_T1;
+    if (t1) {
+        if (n_reads > m->flags_cap) {
+            if (m->d_flags_in) (void)hipFree(m->d_flags_in);
+            if (m->d_flags_out) (void)hipFree(m->d_flags_out);
+            m->d_flags_in = m->d_flags_out = nullptr; m->flags_cap = 0;
+            HIPCHK(hipMalloc((void **)&m->d_flags_in, (size_t)n_reads * FW * 4));
+            HIPCHK(hipMalloc((void **)&m->d_flags_out, (size_t)n_reads * FW * 4));
+            m->flags_cap = n_reads;
+        }
+        HIPCHK(hipMemsetAsync(m->d_flags_in, 0, (size_t)n_reads * FW * 4, st));
+        HIPCHK(hipMemcpyAsync(m->d_flags_in, m->carry_flags, FW * 4, hipMemcpyHostToDevice, st));    // read 0 follows the previous batch's last read
+    }
+    const uint32_t *const fl_in = t1 ? m->d_flags_in : nullptr;
+    uint32_t *const fl_out = t1 ? m->d_flags_out : nullptr;
     launch_map(m->ix->dev, m->sc, rd, m->P, m->d_results, m->d_next, sliced ? m->slice_events : 0xFFFFFFFFu, 0, nullptr, grid, st, m->pool,
-               nullptr, reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile);
+               nullptr, reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile, fl_in, fl_out);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
     m->h_info.resize(n_reads);
@@ -811,16 +834,19 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     // cause: a read that found the pool of nodes DRY runs again on the same scratch with fewer and fewer reads sharing the
     // pool (n_waves, a quarter of that, ... down to one read with the whole pool); a read that used up its own ALLOWANCE
     // (max_clusters / 4 nodes) runs again on scratch with a 16x larger allowance, up to 2^26 clusters.
-    {
+    m->remap_reads = 0;
+    m->remap_ms = 0;
+    // (`subset`: the reads whose results are new -- all of the batch after the first pass, the re-mapped ones of a `-t 1` round)
+    auto resolve_overflows = [&](const std::vector<uint32_t> *subset) -> int {
         std::vector<uint32_t> dry, full, work;
         auto classify = [&](uint32_t i) {
             const uint32_t stt = m->h_results[i].status;
             if (stt & UNC_READ_POOL_DRY) dry.push_back(i);
             else if (stt & UNC_READ_CLUSTER_OVERFLOW) full.push_back(i);
         };
-        for (uint32_t i = 0; i < n_reads; ++i) classify(i);
-        m->remap_reads = (uint32_t)(dry.size() + full.size());
-        m->remap_ms = 0;
+        if (subset) { for (uint32_t i : *subset) classify(i); }
+        else { for (uint32_t i = 0; i < n_reads; ++i) classify(i); }
+        m->remap_reads += (uint32_t)(dry.size() + full.size());
         const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
         size_t limit = m->n_waves;
@@ -837,7 +863,8 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
             launch_pool_init(m->pool, st);
             DevReads rd2 = rd;
             rd2.n_reads = (uint32_t)work.size();
-            launch_map(m->ix->dev, sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, m->pool, m->d_list);
+            launch_map(m->ix->dev, sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr, (uint32_t)slots, st, m->pool, m->d_list,
+                       nullptr, nullptr, false, fl_in, fl_out);
             HIPCHK(hipGetLastError());
             const uint32_t lo = *std::min_element(work.begin(), work.end()), hi = *std::max_element(work.begin(), work.end());
             HIPCHK(hipMemcpyAsync(m->h_results.data() + lo, m->d_results + lo, (size_t)(hi - lo + 1) * sizeof(DevResult), hipMemcpyDeviceToHost, st));
@@ -887,7 +914,83 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
             int rc2 = run_round(m->big, slots);
             if (rc2) return rc2;
         }
-        m->remap_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_redo).count();
+        m->remap_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_redo).count();
+        return UNC_OK;
+    };
+    rc = resolve_overflows(nullptr);
+    if (rc) return rc;
+    m->carry_reads = 0; m->carry_rounds = 0; m->carry_ms = 0;
+    if (t1) {
+        // `uncalled map -t 1`: ONE Mapper maps the reads one after another, and sources_added_ is the one piece of its state that
+        // Mapper::new_read does not reset (mapper.cpp:88,219-246): what a read leaves set (only a read whose path buffer was full
+        // can, :612-623; UNC_NOTE_FLAGS_LEFT) is what its successor starts with.  The batch was mapped with every read but the
+        // first starting clear; a read whose predecessor turned out to leave something else than it assumed is mapped again
+        // with that, and so on down the chain until every read has started from what its predecessor really left.
+        const auto t_c = std::chrono::steady_clock::now();
+        typedef std::array<uint32_t, FW> Flags;
+        const Flags zero{};
+        std::map<uint32_t, Flags> left;        // read -> flags its CURRENT result leaves set (absent: none)
+        std::map<uint32_t, Flags> assumed;     // read -> flags its current result started from (absent: none)
+        Flags f0; memcpy(f0.data(), m->carry_flags, sizeof f0);
+        if (f0 != zero) assumed[0] = f0;
+        auto fetch_left = [&](const std::vector<uint32_t> &reads) -> int {
+            for (uint32_t i : reads) {
+                left.erase(i);
+                if (!(m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT)) continue;
+                Flags f;
+                HIPCHK(hipMemcpyAsync(f.data(), m->d_flags_out + (size_t)i * FW, sizeof f, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                left[i] = f;
+            }
+            return UNC_OK;
+        };
+        {
+            std::vector<uint32_t> flagged;
+            for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT) flagged.push_back(i);
+            rc = fetch_left(flagged);
+            if (rc) return rc;
+        }
+        auto get = [&](const std::map<uint32_t, Flags> &mp, uint32_t i) -> const Flags & { auto it = mp.find(i); return it == mp.end() ? zero : it->second; };
+        std::vector<uint32_t> todo;
+        for (const auto &kv : left) if (kv.first + 1 < n_reads) todo.push_back(kv.first + 1);
+        while (!todo.empty()) {
+            std::vector<uint32_t> work;
+            for (uint32_t j : todo) if (get(left, j - 1) != get(assumed, j)) work.push_back(j);
+            if (work.empty()) break;
+            for (uint32_t j : work) {
+                const Flags &f = get(left, j - 1);
+                if (f == zero) assumed.erase(j); else assumed[j] = f;
+                HIPCHK(hipMemcpyAsync(m->d_flags_in + (size_t)j * FW, f.data(), sizeof f, hipMemcpyHostToDevice, st));
+            }
+            if (work.size() > m->list_cap) {
+                if (m->d_list) (void)hipFree(m->d_list);
+                m->d_list = nullptr; m->list_cap = 0;
+                HIPCHK(hipMalloc((void **)&m->d_list, work.size() * 4));
+                m->list_cap = work.size();
+            }
+            HIPCHK(hipMemcpyAsync(m->d_list, work.data(), work.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(m->d_next, 0, 4, st));
+            launch_pool_init(m->pool, st);
+            DevReads rd2 = rd;
+            rd2.n_reads = (uint32_t)work.size();
+            launch_map(m->ix->dev, m->sc, rd2, m->P, m->d_results, m->d_next, 0xFFFFFFFFu, 0, nullptr,
+                       (uint32_t)std::min<size_t>(work.size(), m->n_slots), st, m->pool, m->d_list, nullptr, nullptr, false, fl_in, fl_out);
+            HIPCHK(hipGetLastError());
+            for (uint32_t j : work)
+                HIPCHK(hipMemcpyAsync(m->h_results.data() + j, m->d_results + j, sizeof(DevResult), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            rc = resolve_overflows(&work);
+            if (rc) return rc;
+            rc = fetch_left(work);
+            if (rc) return rc;
+            m->carry_reads += (uint32_t)work.size();
+            m->carry_rounds++;
+            todo.clear();
+            for (uint32_t j : work) if (j + 1 < n_reads) todo.push_back(j + 1);
+        }
+        const Flags &last = get(left, n_reads - 1);
+        memcpy(m->carry_flags, last.data(), sizeof m->carry_flags);
+        m->carry_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_c).count();
     }
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
@@ -906,6 +1009,19 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
 }
 
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
+extern "C" int unc_mapper_set_read_order(unc_mapper_t *m, int order) {
+    if (!m || (order != UNC_ORDER_INDEPENDENT && order != UNC_ORDER_T1)) return fail(UNC_ERR_ARG, "unc_mapper_set_read_order: UNC_ORDER_INDEPENDENT or UNC_ORDER_T1");
+    m->read_order = order;
+    memset(m->carry_flags, 0, sizeof m->carry_flags);      // a new run: the Mapper's flags start clear (mapper.cpp:88)
+    return UNC_OK;
+}
+extern "C" int unc_mapper_last_carry_over(const unc_mapper_t *m, uint32_t *reads, uint32_t *rounds, float *ms) {
+    if (!m) return fail(UNC_ERR_ARG, "null argument");
+    if (reads) *reads = m->carry_reads;
+    if (rounds) *rounds = m->carry_rounds;
+    if (ms) *ms = m->carry_ms;
+    return UNC_OK;
+}
 extern "C" void unc_mapper_set_profile(unc_mapper_t *m, int on) { if (m) m->profile = on != 0; }
 extern "C" int unc_mapper_kernel_info(const unc_mapper_t *m, uint32_t *out6) {
     if (!m || !out6) return fail(UNC_ERR_ARG, "null argument");
