@@ -63,7 +63,9 @@ typedef struct { float range, offset, digitisation; } unc_calib_t;
 #define UNC_READ_SEED_OVERFLOW 2u      /* per-event seed list exhausted: result for this read is invalid */
 #define UNC_READ_POOL_DRY 16u          /* with CLUSTER_OVERFLOW: the shared pool of cluster nodes was empty (the read's own allowance was not used up) */
 #define UNC_READ_SORT_FAULT 8u        /* internal: the runs of child keys handed to the merge were not ascending (never expected; result invalid) */
-#define UNC_READ_NORM_FULL 4u          /* chunked path: >= 6000 unread events (the reference's #SKIP branch, mapper.cpp:336-351) */
+#define UNC_READ_NORM_FULL 4u          /* chunked path: >= 6000 unread events.  The reference's #SKIP branch (mapper.cpp:336-351) is OUT OF SCOPE:
+                                         * unc_rt_create refuses chunk_time * sample_rate > 12000 samples, below which a chunk cannot yield 6000 events
+                                         * (the detector never fires on consecutive samples) -- the bit is the belt to that pair of braces */
 
 /* per-read notes (unc_hit_t::notes): conditions under which the reference's Mapper carries state from one read into the NEXT read
  * mapped by the same thread -- which the batch path, where every read starts from a fresh Mapper, does not reproduce (with

@@ -241,9 +241,9 @@ def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4)
 
 def case_loud_overflows(lib, oracle_lib, example, goldens):
     """Device scratch that is too small is REPORTED per read (unc_hit_t.status) and by the call's return code -- never a silent
-    wrong answer: a per-event seed list of one entry (UNC_READ_SEED_OVERFLOW), and on the chunked path a chunk of more than 6000
-    events (UNC_READ_NORM_FULL: the reference's #SKIP branch, mapper.cpp:336-351, needs chunks of 8 s and more and is not
-    reproduced).  Reads that did not overflow still answer as the oracle does."""
+    wrong answer: a per-event seed list of one entry (UNC_READ_SEED_OVERFLOW); on the chunked path, chunk lengths that could fill the
+    rolling normaliser (the reference's #SKIP branch, mapper.cpp:336-351: out of scope) are refused at creation.  Reads that did not
+    overflow still answer as the oracle does."""
     dev_index = _index(lib, example)
     oix = oracle_lib.Index(example["prefix"])
     n = 4
@@ -260,20 +260,17 @@ def case_loud_overflows(lib, oracle_lib, example, goldens):
     assert not hits["mapped"][bad].any()
     ok = np.flatnonzero(~bad)
     assert_hits_equal(hits[ok], [want[i] for i in ok], "reads without seed overflow")
-    # chunked path: one 15 s chunk of an off-target read = more than 6000 events before anything is popped
-    from tools.simulate_reads import simulate_reads
-    sim = simulate_reads(np.zeros(20000, np.uint8), [20000], 1, seed=9, read_bases=5200, off_target=1.0)
+    # chunked path: the reference's #SKIP branch (a ring of 6000 unread events, mapper.cpp:336-351) is out of scope, formally: chunks
+    # long enough to reach it are refused when the pool is created; 3 s chunks (12 000 samples, at most 6000 events) are the limit
     p = capi.default_params(lib)
     p.chunk_time = 15.0
-    rt = capi.Realtime(dev_index, 1, p)
-    sig = np.ascontiguousarray(sim["signal"], dtype=np.int16)
-    assert 40000 < sig.size <= 60000
-    ch = np.zeros(1, dtype=capi.RT_CHUNK)
-    ch[0]["channel"], ch[0]["read_number"], ch[0]["flags"], ch[0]["n_samples"], ch[0]["offset"] = 0, 0, capi.RT_FIRST | capi.RT_LAST, sig.size, 0
-    ch[0]["calib"]["range"], ch[0]["calib"]["offset"], ch[0]["calib"]["digitisation"] = CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION
-    res = rt.process_chunks(ch, sig, allow_overflow=True)      # (without allow_overflow the call raises, as map_batch above)
-    assert res[0]["state"] == capi.RT_FAILED and (int(res[0]["hit"]["status"]) & 4) and not res[0]["hit"]["mapped"]
-    rt.close()
+    with pytest.raises(capi.UncalledHipError, match="SKIP"):
+        capi.Realtime(dev_index, 1, p)
+    p.chunk_time = 3.0
+    capi.Realtime(dev_index, 1, p).close()
+    p.chunk_time = 3.0 + 1.0 / 4000.0
+    with pytest.raises(capi.UncalledHipError):
+        capi.Realtime(dev_index, 1, p)
 
 
 # chunked-path sets: (parameter overrides, chunk length in samples)

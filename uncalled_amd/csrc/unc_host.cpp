@@ -1335,6 +1335,15 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     if (p->max_paths == 0 || p->max_paths > 65535 || p->max_rep_copy > (uint32_t)MAX_REP_COPY_LIMIT || p->max_consec_stay > 255 ||
         p->max_events > 65535)
         return fail(UNC_ERR_ARG, "unsupported parameter value");
+    // A chunk may hold at most 2 * NORM_LEN samples (3 s at 4 kHz; the reference's default is 1 s).  The detector never fires on two
+    // consecutive samples (a peak needs a sample to be recorded and more than window / 2 further ones to be confirmed, and a short-window
+    // peak above the threshold resets the long-window detector: event_detector.cpp:221-279), so such a chunk yields at most NORM_LEN events
+    // and the rolling normaliser, which update() leaves empty after every chunk, cannot fill: the #SKIP branch of Mapper::process_chunk
+    // (mapper.cpp:336-351) -- which on a full ring drops the forest and, when the second push fails too, leaves the chunk unprocessed
+    // so that it is fed to the detector AGAIN -- is unreachable for every chunk this interface accepts, here and in the reference.
+    if (!(p->chunk_time > 0.0f) || !(p->sample_rate > 0.0f) || (double)p->chunk_time * (double)p->sample_rate > 2.0 * (double)NORM_LEN)
+        return fail(UNC_ERR_ARG, "chunk_time * sample_rate = %.0f samples: chunks of more than %u samples are not supported (mapper.cpp:336-351, "
+                                 "the #SKIP branch of the reference, is out of scope)", (double)p->chunk_time * (double)p->sample_rate, 2u * NORM_LEN);
     HIPCHK(hipSetDevice(ix->device));
     unc_rt *rt = new unc_rt();
     struct Guard { unc_rt *p; ~Guard() { if (p) unc_rt_free(p); } } guard{rt};
