@@ -1329,6 +1329,531 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
     if (A->wave_ticks && lane == 0) atomicAdd(A->wave_ticks, (unsigned long long)((uint64_t)wall_clock64() - wave_t0));
 }
 
+// =====================================================================================================================
+// SEVERAL WAVEFRONTS PER READ (the chunked / realtime path).  A flow cell has 512 channels: one wavefront per channel
+// leaves three quarters of the chip's SIMDs idle, and a lone wavefront's event is bound by its own chain of dependent
+// instructions, not by the memory system.  k_map_team gives a channel a TEAM of W wavefronts (one workgroup): the match
+// probabilities and the extension of the parents -- 46 % of a lone wavefront's event -- are split over the team, the
+// rest of the event (sort / walk / sources / seeds) is the leader's, on the functions of the one-wavefront kernel.
+//
+// Phase E in a team: the passes of 64 parents are dealt round by round, wave w taking pass r * W + w.  What a child needs from
+// the passes before its own is a handful of COUNTS -- children, keys filed per run, dead-end seeds -- so a round is: every wave
+// works its pass up to the child slots (parents, candidates, FM, slots) and publishes the uncut counts; one barrier; every wave
+// adds up what the waves before it counted and writes its children where the one-wavefront kernel would have put them.  The
+// max_paths cut-off only ever removes a SUFFIX of the creation order: a wave whose pass starts past the cut writes nothing, the
+// wave that straddles it cuts as the one-wavefront kernel does, and the counts of the waves before it are exact as published.
+// =====================================================================================================================
+constexpr int TEAM_MAX = 4;
+struct TeamCnt {
+    uint32_t chtot, m[5], xtot, ecnt;      // children of the pass, keys per run of sorted survivors' children, children of sources, dead-end seeds
+    uint32_t first_is_surv, pad0;
+    uint64_t first_pk, last_pk;            // order check of the sorted survivors across passes
+};
+__shared__ TeamCnt s_team_cnt[2][TEAM_MAX];
+__shared__ uint32_t s_team_flags;                  // over the waves of an event: 1 boundary child, 2 parents unsorted, 4 seed list overflow
+__shared__ unsigned long long s_team_nbr;          // get_neighbor calls counted by the followers
+__shared__ uint32_t s_team_ctl;                    // leader -> followers after an event: 0 go on, 1 / 2 read decided, 3 chunk mapped (park)
+__shared__ __attribute__((aligned(16))) uint64_t s_e_x[TEAM_MAX - 1][S_E_WORDS];   // the followers' staging for phase E
+
+__device__ __forceinline__ void team_barrier() { __syncthreads(); }
+
+template <int W>
+static __device__ __noinline__ void phase_P_team(kargs_t A_, float level, int lane, int wave) {
+    const kargs_t A = uniform_ptr(A_);
+    const UNC_AS_GLOBAL float4 *const model4 = (const UNC_AS_GLOBAL float4 *)A->ix.model4;
+#pragma unroll 4
+    for (int j = wave; j < NKMER / WAVE; j += W) {
+        const uint32_t k = (uint32_t)j * WAVE + (uint32_t)lane;
+        const float4 row = g_load(model4 + k);
+        const float mu = row.x, v2 = row.y, ld = row.z;
+        const float d = __fsub_rn(level, mu);
+        const double q = -((double)d * (double)d) / (double)v2;
+        s_probs[k] = (float)(q - (double)ld);
+    }
+}
+
+// Running totals every wave of the team keeps (identically) while the rounds go by
+struct TeamTotals { uint32_t nchild, n_seedp, scnt[5], scntx; uint64_t run_last; };
+
+template <bool PROF, bool NARROW, int W>
+static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int lane, int wave, TeamTotals &TT) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    using Row = std::conditional_t<NARROW, uint32_t, uint64_t>;
+    constexpr int RES_BITS = 30;
+    constexpr uint32_t PSTRIDE = (uint32_t)WAVE * (uint32_t)W;       // parents of one round
+    uint64_t *const stg = wave == 0 ? s_e : s_e_x[wave > 0 ? wave - 1 : 0];
+    uint64_t *const s_res = stg;                      // [parent lane << 2 | base]
+    Row *const s_pstart = reinterpret_cast<Row *>(stg + CAND_MAX), *const s_pend = s_pstart + WAVE;
+    uint64_t *const s_phist = reinterpret_cast<uint64_t *>(s_pend + WAVE);
+    float *const s_plast = reinterpret_cast<float *>(s_phist + WAVE), *const s_psubc = s_plast + WAVE;
+    uint32_t *const s_pmoves = reinterpret_cast<uint32_t *>(s_psubc + WAVE), *const s_pmeta = s_pmoves + WAVE;
+    uint16_t *const s_cdesc = reinterpret_cast<uint16_t *>(s_pmeta + WAVE);         // per child: parent lane | type << 6 | child of a source << 9
+    uint16_t *const s_ckpos = s_cdesc + CHILD_MAX;                                   // narrow keys: a child's position among its pass's keys of its run
+    uint16_t *const s_cand = s_cdesc;                                                // (dead before the descriptors are written)
+
+    const FmView ix = fm_view(A);
+    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+    const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
+    const uint32_t event_i = ctx_get(s_w.event_i), n_parents = ctx_get(s_w.n_parents), cur = ctx_get(s_w.cur), n_surv_par = ctx_get(s_w.n_surv_par);
+    const float thr_lane = A->ix.thresholds[lane];
+    const uint32_t klb = NARROW ? A->ix.key_len_bits : 0u;
+    const uint32_t p_max_consec_stay = A->P.max_consec_stay, p_seed_len = A->P.seed_len, p_max_rep_copy = A->P.max_rep_copy, p_min_rep_len = A->P.min_rep_len;
+    const float p_min_seed_prob = A->P.min_seed_prob, p_max_stay = __fmul_rn(A->P.max_stay_frac, (float)A->P.seed_len);
+    const uint32_t par_off = A->sc.off_paths + cur * (max_paths << PATH_SHIFT), chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT);
+    const uint32_t pord_off = A->sc.off_order + cur * (max_paths << 2);
+    const uint32_t seedp_off = A->sc.off_seedp, ukeys_off = A->sc.off_keys, str_off = A->sc.off_streams, info_off = A->sc.off_info;
+    const uint32_t run_bytes = max_paths << 3;
+    const float level_old = event_i >= (uint32_t)SEED_LEN ? gld<float>(sb, A->sc.off_levels + (((event_i - (uint32_t)SEED_LEN) & (LEVEL_RING - 1u)) << 2)) : 0.0f;
+    const UNC_AS_GLOBAL float4 *const model4 = (const UNC_AS_GLOBAL float4 *)A->ix.model4;
+
+    uint32_t c_nbr = 0;
+    bool bchild = false, par_bad = false, seed_over = false;
+    TT.nchild = 0; TT.n_seedp = 0; TT.scntx = 0; TT.run_last = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) TT.scnt[t] = 0;
+
+    // this wave's passes: parents wave * 64 + lane of every round; record headers are fetched one round ahead
+    const uint32_t pi0 = (uint32_t)wave * WAVE + (uint32_t)lane;
+    uint32_t phys_cur = pi0 < n_parents ? gld<uint32_t>(sb, pord_off + (pi0 << 2)) : 0u;
+    uint32_t phys_nxt = pi0 + PSTRIDE < n_parents ? gld<uint32_t>(sb, pord_off + ((pi0 + PSTRIDE) << 2)) : 0u;
+    uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
+    if (pi0 < n_parents) {
+        q0c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
+    }
+    for (uint32_t rbase = 0, rnd = 0; rbase < n_parents && TT.nchild < max_paths; rbase += PSTRIDE, ++rnd) {
+        const uint32_t base = rbase + (uint32_t)wave * WAVE;
+        const uint32_t pi = base + (uint32_t)lane;
+        const bool have = pi < n_parents;
+        const uint4 q0 = q0c, q1 = q1c;
+        phys_cur = phys_nxt;
+        if (pi + PSTRIDE < n_parents) {
+            q0c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
+        }
+        if (pi + 2 * PSTRIDE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * PSTRIDE) << 2));
+        uint32_t pmoves = 0, pmeta = 0;
+        Row pstart = 1, pend = 1;
+        float plast = 0.0f, psub = 0.0f;
+        uint64_t phist = 0;
+        if (have) {
+            if constexpr (NARROW) { pstart = q0.x; pend = q0.y; }
+            else { const uint64_t r = ((uint64_t)q0.y << 32) | q0.x; pstart = r >> KEY_LEN_BITS; pend = pstart + (r & KEY_LEN_MASK); }
+            pmoves = q0.z; pmeta = q0.w;
+            plast = __uint_as_float(q1.x); psub = __uint_as_float(q1.y); phist = ((uint64_t)q1.w << 32) | q1.z;
+        }
+        const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
+        const bool pfull = plen == (uint32_t)SEED_LEN;
+        const uint32_t okmer = (uint32_t)phist & KMASK;
+        float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
+        if (pfull) { const float4 row = g_load(model4 + okmer); o_mu = row.x; o_v2 = row.y; o_ld = row.z; }
+        const Row plen_fm = pend - pstart + 1;
+        // the merge of the children's keys relies on the survivors being in ascending (start, length) order: inside the pass here,
+        // across passes after the exchange
+        uint64_t first_pk = 0, last_pk = ~0ull;
+        if constexpr (NARROW) {
+            const uint64_t pk = pi < n_surv_par ? ((uint64_t)pstart << 32) | (uint32_t)(pend - pstart) : ~0ull;
+            const uint64_t pp = (uint64_t)__shfl_up((unsigned long long)pk, 1);
+            if (__any(lane > 0 && pi < n_surv_par && !(pk > pp))) par_bad = true;
+            first_pk = bcast64(pk, 0); last_pk = bcast64(pk, WAVE - 1);
+        }
+        int thr_bin;
+        if constexpr (NARROW) thr_bin = 32 + __clz((int)plen_fm); else thr_bin = __clzll((long long)plen_fm);
+        const float thr = __shfl(thr_lane, thr_bin);
+        const uint32_t kmer = pmeta & META_KMER_MASK;
+        const uint32_t stays = (pmeta >> META_STAY_SHIFT) & 255u;
+        const bool stay_ok = have && stays < p_max_consec_stay && s_probs[kmer] >= thr;
+        const float4 np = *reinterpret_cast<const float4 *>(&s_probs[(kmer << 2) & KMASK]);
+        uint32_t mask = (!(np.x < thr) ? 1u : 0u) | (!(np.y < thr) ? 2u : 0u) | (!(np.z < thr) ? 4u : 0u) | (!(np.w < thr) ? 8u : 0u);
+        if (!have) mask = 0;
+        s_pstart[lane] = pstart; s_pend[lane] = pend; s_pmoves[lane] = pmoves; s_pmeta[lane] = pmeta; s_plast[lane] = plast;
+        const uint32_t ncand = (uint32_t)__popc(mask);
+        uint32_t ctot;
+        const uint32_t coff = excl_sum_bits<3>(ncand, &ctot);
+        {
+            uint32_t w = coff;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
+        }
+        wave_sync();
+        for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
+            const uint32_t ci = c0 + (uint32_t)lane;
+            if (ci < ctot) {
+                const uint32_t cd = s_cand[ci];
+                if constexpr (NARROW) {
+                    uint32_t ns, ne;
+                    fm32_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
+                    s_res[cd] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull;
+                } else {
+                    uint64_t ns, ne;
+                    fm_get_neighbor(ix, s_pstart[cd >> 2], s_pend[cd >> 2], cd & 3u, &ns, &ne);
+                    s_res[cd] = ns <= ne ? (ns << RES_BITS) | (ne - ns + 1) : 0ull;
+                }
+            }
+        }
+        wave_sync();
+        // ---- the pass's children as if nothing were cut off: who, where in the pass, where among the pass's keys of its run
+        const uint32_t rb = (uint32_t)lane << 2;
+        uint32_t vmask = (s_res[rb] != 0 ? 1u : 0u) | (s_res[rb + 1] != 0 ? 2u : 0u) | (s_res[rb + 2] != 0 ? 4u : 0u) | (s_res[rb + 3] != 0 ? 8u : 0u);
+        vmask &= mask;
+        const uint32_t nch = (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask);
+        uint32_t chtot;
+        const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
+        wave_sync();             // (the candidate list is dead: its space takes the descriptors)
+        const bool is_src = pi >= n_surv_par;
+        uint32_t mcount[5] = {0, 0, 0, 0, 0}, xtot = 0;
+        {
+            uint32_t cpos[5];
+            bool ex[5];
+            ex[0] = stay_ok; cpos[0] = choff;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                ex[b + 1] = (vmask >> b) & 1u;
+                cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u));
+            }
+            uint32_t kp[5] = {0, 0, 0, 0, 0};
+            if constexpr (NARROW) {
+                if (base < n_surv_par) {
+#pragma unroll
+                    for (uint32_t t = 0; t < 5; ++t) {
+                        const uint64_t mt = __ballot(ex[t] && !is_src);
+                        kp[t] = (uint32_t)prefix_popc(mt);
+                        mcount[t] = (uint32_t)__popcll(mt);
+                    }
+                }
+                if (base + WAVE > n_surv_par) {
+                    const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
+                    uint32_t xo = excl_sum_bits<3>(nfit, &xtot);
+                    if (is_src) {
+#pragma unroll
+                        for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t)
+                if (ex[t]) {
+                    s_cdesc[cpos[t]] = (uint16_t)((uint32_t)lane | (t << 6) | (is_src ? 1u << 9 : 0u));
+                    if constexpr (NARROW) s_ckpos[cpos[t]] = (uint16_t)kp[t];
+                }
+        }
+        {
+            float subc = psub;
+            uint64_t hist = phist;
+            if (pfull) {
+                const float d = __fsub_rn(level_old, o_mu);
+                const double q = -((double)d * (double)d) / (double)o_v2;
+                subc = __fadd_rn(psub, (float)(q - (double)o_ld));
+                if ((pmoves >> (SEED_LEN - 2)) & 1u) {
+                    const uint32_t cnt = (uint32_t)__popc(pmoves & ((1u << (SEED_LEN - 1)) - 1u));
+                    const uint32_t pos = 2u * (cnt - 1u);
+                    const uint64_t fifo = hist >> 10;
+                    const uint32_t nk = ((okmer << 2) & KMASK) | ((uint32_t)(fifo >> pos) & 3u);
+                    hist = (uint64_t)nk | ((fifo & ~(3ull << pos)) << 10);
+                }
+            }
+            s_psubc[lane] = subc; s_phist[lane] = hist;
+        }
+        // dead ends that would become seeds if their parent is reached (update_seeds(prev_path, true), :513-519 / is_seed_valid :842-863)
+        bool ecand = false;
+        uint32_t e_count = 0, e_mc = 0;
+        if (have && nch == 0 && !(pmeta & META_SA_CHECKED)) {
+            const uint32_t mc = (uint32_t)__popc(pmoves);
+            const float pprob = __fdiv_rn(__fsub_rn(plast, psub), (float)SEED_LEN);
+            const bool base_ok = plen == p_seed_len && pprob >= p_min_seed_prob;
+            const bool uniq = plen_fm == 1 && (pmoves & 1u) == 1u && (float)(plen - mc) <= p_max_stay;
+            const bool rep = plen_fm <= (Row)p_max_rep_copy && mc >= p_min_rep_len;
+            ecand = base_ok && (uniq || rep);
+            e_count = (uint32_t)plen_fm;
+            e_mc = mc;
+        }
+        const uint32_t ecnt = (uint32_t)__popcll(__ballot(ecand));
+        if (lane == 0) {
+            TeamCnt c;
+            c.chtot = chtot; c.xtot = xtot; c.ecnt = ecnt; c.first_is_surv = base < n_surv_par ? 1u : 0u; c.pad0 = 0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) c.m[t] = mcount[t];
+            c.first_pk = first_pk; c.last_pk = last_pk;
+            s_team_cnt[rnd & 1u][wave] = c;
+        }
+        team_barrier();
+        // ---- what the waves before this one counted; the round's totals
+        uint32_t b_child = TT.nchild, b_seed = TT.n_seedp, b_x = TT.scntx, b_m[5];
+        uint32_t r_child = 0, r_seed = 0, r_x = 0, r_m[5] = {0, 0, 0, 0, 0};
+        uint64_t prev_last = TT.run_last, round_last = 0;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) b_m[t] = TT.scnt[t];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const TeamCnt c = s_team_cnt[rnd & 1u][w];
+            const uint32_t ct = uniform32(c.chtot), cx = uniform32(c.xtot), ce = uniform32(c.ecnt);
+            if (w < wave) { b_child += ct; b_seed += ce; b_x += cx; prev_last = uniform64(c.last_pk); }
+            r_child += ct; r_seed += ce; r_x += cx;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { const uint32_t v = uniform32(c.m[t]); if (w < wave) b_m[t] += v; r_m[t] += v; }
+            if (w == W - 1) round_last = uniform64(c.last_pk);
+        }
+        if constexpr (NARROW) { if (base < n_surv_par && !(first_pk > prev_last)) par_bad = true; }
+        const bool cut = TT.nchild + r_child > max_paths;         // (the same for every wave)
+        const uint32_t room = b_child >= max_paths ? 0u : max_paths - b_child;
+        const uint32_t nwrite = chtot < room ? chtot : room;
+        const bool visited = have && choff < room;
+        if (room > 0) {
+            if (choff + nch < room) c_nbr += ncand;
+            else
+                for (uint32_t b = 0; b < 4; ++b)
+                    if (((mask >> b) & 1u) && choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u)) < room) c_nbr++;
+        }
+        const bool ended_seed = ecand && visited;
+        const uint64_t em = __ballot(ended_seed);
+        {
+            const uint32_t pos = b_seed + (uint32_t)prefix_popc(em);
+            if (ended_seed) {
+                if (pos < max_seed_paths) {
+                    SeedPath sp; sp.start = pstart; sp.count = e_count; sp.evt = event_i - 1u; sp.ref_len = e_mc; sp.pad = 0;
+                    gst(sb, seedp_off + pos * (uint32_t)sizeof(SeedPath), sp);
+                } else seed_over = true;
+            }
+        }
+        // one lane per child that fits
+        uint32_t kept_m[5] = {0, 0, 0, 0, 0}, kept_x = 0;
+        for (uint32_t l0 = 0; l0 < nwrite; l0 += WAVE) {
+            const uint32_t li = l0 + (uint32_t)lane;
+            const bool on = li < nwrite;
+            uint32_t run = 7u;
+            if (on) {
+                const uint32_t d = s_cdesc[li];
+                const uint32_t pl = d & 63u, type = (d >> 6) & 7u, ci = (pl << 2) | ((type - 1u) & 3u);
+                const uint32_t pmt = s_pmeta[pl], pmv = s_pmoves[pl];
+                const float last = s_plast[pl], subc = s_psubc[pl];
+                const uint64_t hist = s_phist[pl];
+                const uint32_t pk = pmt & META_KMER_MASK;
+                Row cs, ce;
+                uint32_t ck, mv;
+                if (type == 0) { cs = s_pstart[pl]; ce = s_pend[pl]; ck = pk; mv = 0; }
+                else {
+                    const uint64_t pr = s_res[ci];
+                    if constexpr (NARROW) { cs = (uint32_t)pr; ce = cs + (uint32_t)(pr >> 32) - 1u; }
+                    else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
+                    ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
+                }
+                SortKey key;
+                const uint32_t gi = b_child + li;
+                const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
+                const uint32_t co = chd_off + (gi << PATH_SHIFT);
+                if constexpr (NARROW) gst(sb, co, make_uint4(cs, ce, c.moves, c.meta));
+                else { const uint64_t r = (cs << KEY_LEN_BITS) | (ce - cs); gst(sb, co, make_uint4((uint32_t)r, (uint32_t)(r >> 32), c.moves, c.meta)); }
+                gst(sb, co + 16u, make_uint4(__float_as_uint(c.last), __float_as_uint(subc), (uint32_t)c.hist, (uint32_t)(c.hist >> 32)));
+                if constexpr (NARROW) {
+                    run = (d >> 9) ? 5u : type;
+                    const uint32_t kb = run == 0u ? b_m[0] : run == 1u ? b_m[1] : run == 2u ? b_m[2] : run == 3u ? b_m[3] : run == 4u ? b_m[4] : b_x;
+                    gst(sb, str_off + run * run_bytes + ((kb + (uint32_t)s_ckpos[li]) << 3), key.a);
+                    gst(sb, info_off + (gi << 3), key.b);
+                    if (cs == ce) {
+                        const ulonglong2 kr = g_load(kmer_ranges + ck);
+                        if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
+                    }
+                } else {
+                    gst(sb, ukeys_off + (gi << 4), key);
+                }
+            }
+            if (NARROW && cut) {       // (only the round that hits the cut-off needs the kept counts)
+#pragma unroll
+                for (uint32_t t = 0; t < 5; ++t) kept_m[t] += (uint32_t)__popcll(__ballot(run == t));
+                kept_x += (uint32_t)__popcll(__ballot(run == 5u));
+            }
+        }
+        if (!cut) {
+            TT.nchild += r_child; TT.n_seedp += r_seed; TT.scntx += r_x;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) TT.scnt[t] += r_m[t];
+            TT.run_last = round_last;
+        } else {
+            // the buffer fills in this round: the waves tell each other what they really wrote (the other half of the count slots is free)
+            if (lane == 0) {
+                TeamCnt c;
+                c.chtot = nwrite; c.xtot = kept_x; c.ecnt = (uint32_t)__popcll(em); c.first_is_surv = 0; c.pad0 = 0;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) c.m[t] = kept_m[t];
+                c.first_pk = 0; c.last_pk = 0;
+                s_team_cnt[(rnd + 1u) & 1u][wave] = c;
+            }
+            team_barrier();
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const TeamCnt c = s_team_cnt[(rnd + 1u) & 1u][w];
+                TT.nchild += uniform32(c.chtot); TT.n_seedp += uniform32(c.ecnt); TT.scntx += uniform32(c.xtot);
+#pragma unroll
+                for (int t = 0; t < 5; ++t) TT.scnt[t] += uniform32(c.m[t]);
+            }
+            team_barrier();        // (the slots are written again two rounds on at the earliest, but the loop ends here: keep it simple)
+        }
+        wave_sync();
+    }
+    // what the leader needs of the followers: flags, their share of the work counter
+    const uint32_t fl = (__any(bchild) ? 1u : 0u) | (par_bad ? 2u : 0u) | (__any(seed_over) ? 4u : 0u);
+    if (wave != 0) {
+        const uint64_t tot = wave_sum64((uint64_t)c_nbr);
+        if (lane == 0) { if (fl) atomicOr(&s_team_flags, fl); if (tot) atomicAdd(&s_team_nbr, (unsigned long long)tot); }
+        c_nbr = 0;
+    } else if (lane == 0 && fl) atomicOr(&s_team_flags, fl);
+    return c_nbr;
+}
+
+// The chunked path with a team of W wavefronts per channel (workgroup b = chunk descriptor b, slot = slot_map[b]; see the one-wavefront
+// kernel's resume branch for the state a channel keeps between chunks).  The leader (wave 0) owns the read's state and every phase
+// but P and E; the followers learn after each event whether it goes on.
+// (The register budget is the one-wavefront kernel's -- UNC_LB wavefronts per SIMD -- although a flow cell's 512 teams never fill the
+// chip: the phases the two kernels share are compiled ONCE, for the looser of their callers' budgets, and a team kernel without the
+// bound took the batch kernel from 126 to 197 VGPRs, i.e. from 16 to 8 wavefronts per CU.)
+template <bool PROF, bool NARROW, int W>
+__global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
+    const kargs_t A = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Aval;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const bool lead = wave == 0;
+    const uint32_t r = blockIdx.x;
+    const uint32_t slot = A->slot_map ? A->slot_map[blockIdx.x] : blockIdx.x;
+    const gptr_t sb = (gptr_t)A->sc.base + (size_t)slot * A->sc.slot_bytes;
+    UNC_AS_GLOBAL SlotState *const st = reinterpret_cast<UNC_AS_GLOBAL SlotState *>(sb + A->sc.off_state);
+    const bool fresh = A->rd.new_read && A->rd.new_read[blockIdx.x];   // first chunk of a read
+
+    uint32_t event_i = 0, tstatus = 0, notes = 0;
+    Tracker T;
+    T.n = 0; T.n_lens = 0; T.max1 = 0; T.max2 = 0; T.status = 0; T.len_sum = 0.0f; T.n_alloc = 0;
+    T.mm.ref_st = 0; T.mm.rstart = 1; T.mm.rend = 0; T.mm.evt_st = 1; T.mm.evt_en = 0; T.mm.total_len = 0;  // NULL_ALN
+    uint64_t c_nbr = 0, c_sa = 0, c_lf = 0;      // per-lane partial counters (leader)
+    if (!fresh) {
+        if (uniform32(st->done)) return;             // (every wave reads the same word)
+        event_i = uniform32(st->event_i);
+        tstatus = uniform32(st->status);
+    }
+    if (lead) {
+        uint32_t n_parents = 0, cur = 0, n_surv_par = 0;
+        if (lane < 12) s_cyc[lane] = 0;
+        if (!fresh) {
+            n_parents = uniform32(st->n_parents); cur = uniform32(st->cur); n_surv_par = uniform32(st->n_surv);
+            notes = uniform32(st->notes);
+            T.n = st->n_clusters; T.n_lens = st->n_lens; T.max1 = st->len_max1; T.max2 = st->len_max2;
+            T.status = st->status; T.len_sum = st->len_sum; T.n_alloc = st->n_alloc;
+            T.mm.ref_st = st->max_map.ref_st; T.mm.rstart = st->max_map.rstart; T.mm.rend = st->max_map.rend;
+            T.mm.evt_st = st->max_map.evt_st; T.mm.evt_en = st->max_map.evt_en; T.mm.total_len = st->max_map.total_len;
+            if (lane == 0) { c_nbr = st->n_nbr; c_sa = st->n_sa; c_lf = st->n_lf; }
+        } else {
+            {   // a new read takes the channel over: what the previous one still holds goes back to the pool
+                Tracker old;
+                old.n_alloc = uniform32(st->n_alloc);
+                tracker_release(old, tracker_mem(A, sb), lane);
+            }
+            tracker_clear_heads(tracker_mem(A, sb), lane);
+        }
+        // sources_added_ is NOT cleared by Mapper::new_read / reset (mapper.cpp:88,219-246,612-623): a channel is one Mapper
+        if (lane < NKMER / 32) s_flags[lane] = st->sources_added[lane];
+        if (lane == 0) {
+            s_T = T;
+            s_w.event_i = event_i; s_w.n_parents = n_parents; s_w.cur = cur; s_w.n_surv_par = n_surv_par; s_w.tstatus = tstatus;
+            s_w.notes = notes;
+            s_team_flags = 0; s_team_nbr = 0ull; s_team_ctl = 0;
+        }
+    }
+    team_barrier();
+    const uint32_t n_events = A->rd.info[r].n_events;
+    const float scale = A->rd.info[r].scale, shift = A->rd.info[r].shift;
+    const UNC_AS_GLOBAL float *const means = (const UNC_AS_GLOBAL float *)A->rd.means + A->rd.moff[r];
+    const uint32_t ring_mod = A->rd.ring_mod, ring_r0 = A->rd.ring0[r];
+    const uint32_t max_events = A->P.max_events, max_seed_paths = A->sc.max_seed_paths;
+
+    uint32_t done = 0;
+    float next_mean = event_i < n_events ? means[(ring_r0 + event_i) % ring_mod] : 0.0f;
+    for (;;) {
+        // map_next prologue, mapper.cpp:434-437 (norm_.empty() <=> every event popped)
+        if (event_i >= n_events && event_i < max_events && !tstatus) break;        // chunk mapped: park
+        if (event_i >= n_events || event_i >= max_events || tstatus) { done = 2; break; }
+        PhaseClock<PROF> clk;
+        const float level = __fadd_rn(__fmul_rn(scale, next_mean), shift);         // Normalizer::at
+        if (event_i + 1 < n_events) next_mean = means[(ring_r0 + event_i + 1) % ring_mod];
+        if (lead && lane == 0) gst(sb, A->sc.off_levels + ((event_i & (LEVEL_RING - 1u)) << 2), level);
+        phase_P_team<W>(A, level, lane, wave);
+        team_barrier();
+        if (lead) clk.end(0, lane);
+        TeamTotals TT;
+        c_nbr += phase_E_team<PROF, NARROW, W>(A, sb, lane, wave, TT);
+        team_barrier();
+        if (lead) {
+            clk.end(1, lane);
+            const uint32_t fl = uniform32(s_team_flags);
+            const unsigned long long nbr_f = s_team_nbr;
+            uint32_t n_seedp = TT.n_seedp, tst = 0;
+            if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
+            if (lane == 0) {
+                s_w.nchild = TT.nchild; s_w.n_seedp = n_seedp; s_w.bchild = fl & 1u; s_w.tstatus |= tst; s_w.par_unsorted = (fl >> 1) & 1u;
+                s_w.scnt[0] = TT.scnt[0]; s_w.scnt[1] = TT.scnt[1]; s_w.scnt[2] = TT.scnt[2]; s_w.scnt[3] = TT.scnt[3]; s_w.scnt[4] = TT.scnt[4];
+                s_w.scnt[5] = TT.scntx;
+                s_team_flags = 0; s_team_nbr = 0ull;
+                c_nbr += nbr_f;
+            }
+            wave_sync();
+            clk.reset();
+            if (ctx_get(s_w.nchild) > 0) {
+                phase_S<NARROW>(A, sb, lane);
+                clk.end(2, lane);
+                if (!ctx_get(s_w.walked)) phase_W<NARROW>(A, sb, lane);
+                clk.end(3, lane);
+            }
+            phase_F<NARROW>(A, sb, lane);
+            clk.end(4, lane);
+            bool conf = false;
+            if (ctx_get(s_w.n_seedp) > 0 && !ctx_get(s_w.tstatus)) {
+                const uint64_t c = phase_T<PROF>(A, sb, lane);
+                clk.reset();
+                c_sa += (uint32_t)c; c_lf += c >> 32;
+                conf = ctx_get(s_w.conf) != 0;
+            }
+            const uint32_t ts = ctx_get(s_w.tstatus);
+            const uint32_t code = ts ? 2u : conf ? 1u : 0u;
+            if (lane == 0) { s_team_ctl = code; if (!code) s_w.event_i = event_i + 1u; }
+            tstatus = ts;
+            clk.end(7, lane);
+        }
+        team_barrier();
+        const uint32_t code = uniform32(s_team_ctl);
+        if (code == 2u) { done = 2; break; }
+        if (code == 1u) { done = 1; break; }
+        event_i++;
+    }
+    if (!lead) return;
+    // ---------------- publish / park (the leader; as the one-wavefront kernel's chunked branch) ----------------
+    const uint32_t n_parents = ctx_get(s_w.n_parents), cur = ctx_get(s_w.cur), n_surv_par = ctx_get(s_w.n_surv_par);
+    notes = ctx_get(s_w.notes);
+    if (done && __any(lane < NKMER / 32 && s_flags[lane < NKMER / 32 ? lane : 0] != 0u)) notes |= UNC_NOTE_FLAGS_LEFT;
+    const uint64_t t_nbr = wave_sum64(c_nbr), t_sa = wave_sum64(c_sa), t_lf = wave_sum64(c_lf);
+    T = s_T;
+    T.status |= tstatus;
+    T.n_alloc = uniform32(T.n_alloc);
+    if (done && lane == 0) {
+        DevResult res;
+        res.done = done; res.status = T.status; res.event_i = event_i; res.notes = notes;
+        res.cluster = T.mm;
+        res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
+        res.ticks = 0ull; res.pad2 = 0;
+        for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
+        g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
+    }
+    if (done) tracker_release(T, tracker_mem(A, sb), lane);       // a decided read's nodes go back at once
+    if (lane == 0) {
+        st->read_idx = r; st->event_i = event_i; st->n_parents = n_parents; st->cur = cur; st->done = done;
+        st->n_surv = n_surv_par;
+        st->status = T.status; st->n_clusters = T.n; st->n_lens = T.n_lens;
+        st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
+        st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
+        st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
+        st->notes = done ? 0u : notes; st->n_alloc = T.n_alloc;
+        st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = 0;
+        if constexpr (PROF) { for (int i = 0; i < 12; ++i) st->cyc[i] = (fresh ? 0ull : st->cyc[i]) + s_cyc[i]; }
+    }
+    if (lane < NKMER / 32) st->sources_added[lane] = s_flags[lane];
+}
+
 }  // namespace unc
 
 #include "unc_kernels.h"
@@ -1336,7 +1861,7 @@ namespace unc {
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
                 const DevPool &pool, const uint32_t *read_list, unsigned long long *wave_ticks, const DevSched *sched, bool profile,
-                const uint32_t *flags_in, uint32_t *flags_out) {
+                const uint32_t *flags_in, uint32_t *flags_out, uint32_t team) {
     MapArgs a;
     a.flags_in = flags_in; a.flags_out = flags_out;
     if (sched) a.sched = *sched; else { a.sched.ctl = nullptr; a.sched.free_cells = a.sched.park_cells = nullptr; a.sched.cap_mask = a.sched.n_slots = 0; }
@@ -1344,6 +1869,16 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
     a.max_steps = max_steps; a.resume = resume; a.slot_map = slot_map; a.read_list = read_list; a.wave_ticks = wave_ticks;
     a.pool = pool;
     const bool narrow = ix.key_len_bits != 0;
+    if (team > 1 && resume && rd.ring_mod) {
+        // the chunked path with a team of wavefronts per channel (k_map_team): 2 or 4
+#define UNC_TEAM_LAUNCH(P_, N_, W_) hipLaunchKernelGGL((k_map_team<P_, N_, W_>), dim3(grid), dim3(WAVE * W_), 0, st, a)
+        if (team >= 4) { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 4); else UNC_TEAM_LAUNCH(true, false, 4); }
+                         else { if (narrow) UNC_TEAM_LAUNCH(false, true, 4); else UNC_TEAM_LAUNCH(false, false, 4); } }
+        else { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 2); else UNC_TEAM_LAUNCH(true, false, 2); }
+               else { if (narrow) UNC_TEAM_LAUNCH(false, true, 2); else UNC_TEAM_LAUNCH(false, false, 2); } }
+#undef UNC_TEAM_LAUNCH
+        return;
+    }
     if (profile && narrow) hipLaunchKernelGGL((k_map<true, true>), dim3(grid), dim3(WAVE), 0, st, a);
     else if (profile) hipLaunchKernelGGL((k_map<true, false>), dim3(grid), dim3(WAVE), 0, st, a);
     else if (narrow) hipLaunchKernelGGL((k_map<false, true>), dim3(grid), dim3(WAVE), 0, st, a);

@@ -1283,6 +1283,7 @@ struct unc_rt {
     const unc_index *ix = nullptr;
     unc_params_t P;
     uint32_t n_channels = 0;
+    uint32_t team = 4;            // wavefronts per channel in k_map (UNC_RT_TEAM)
     DevScratch sc;
     DevPool pool{};               // nodes of the channels' seed-cluster grids (a channel keeps its chunks until its read is decided)
     RtChan *d_chans = nullptr;
@@ -1349,6 +1350,8 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     struct Guard { unc_rt *p; ~Guard() { if (p) unc_rt_free(p); } } guard{rt};
     rt->ix = ix; rt->P = *p; rt->n_channels = n_channels;
     { const char *e = getenv("UNC_RT_PROFILE"); rt->profile = e && e[0] == '1'; }
+    // wavefronts per channel (k_map_team): 4 unless UNC_RT_TEAM says 1 (the one-wavefront kernel) or 2
+    { const char *e = getenv("UNC_RT_TEAM"); const long v = e ? atol(e) : 4; rt->team = v >= 4 ? 4u : v >= 2 ? 2u : 1u; }
     const size_t S = n_channels;
     size_t bytes = 0;
     {
@@ -1518,7 +1521,7 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
         rd.tgt_mean = rt->ix->model_mean; rd.tgt_stdv = rt->ix->model_stdv;
         rd.ring0 = rt->d_ring0; rd.new_read = rt->d_newread; rd.ring_mod = NORM_LEN;
         launch_map(rt->ix->dev, rt->sc, rd, rt->P, rt->d_results, rt->d_next, 0xFFFFFFFFu, 1, rt->d_slotmap, n_act, st, rt->pool, nullptr, nullptr, nullptr,
-                   rt->profile);
+                   rt->profile, nullptr, nullptr, rt->team);
         HIPCHK(hipEventRecord(rt->ev[2], st));
         HIPCHK(hipGetLastError());
         rt->h_info.resize(n_act);

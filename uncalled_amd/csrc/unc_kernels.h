@@ -11,7 +11,8 @@ void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc
 void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, const unc_params_t &P, DevResult *results,
                 uint32_t *next_read, uint32_t max_steps, uint32_t resume, const uint32_t *slot_map, uint32_t grid, hipStream_t st,
                 const DevPool &pool, const uint32_t *read_list = nullptr, unsigned long long *wave_ticks = nullptr,
-                const DevSched *sched = nullptr, bool profile = false, const uint32_t *flags_in = nullptr, uint32_t *flags_out = nullptr);
+                const DevSched *sched = nullptr, bool profile = false, const uint32_t *flags_in = nullptr, uint32_t *flags_out = nullptr,
+                uint32_t team = 1);   // chunked path only: wavefronts per channel (1, 2 or 4)
 void launch_sched_init(const DevSched &S, hipStream_t st);
 void launch_pool_init(const DevPool &B, hipStream_t st);
 uint32_t map_kernel_waves_per_cu();
