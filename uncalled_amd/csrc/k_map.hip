@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
 // max_paths cut-off only ever removes a SUFFIX of the creation order: a wave whose pass starts past the cut writes nothing, the
 // wave that straddles it cuts as the one-wavefront kernel does, and the counts of the waves before it are exact as published.
 // =====================================================================================================================
-constexpr int TEAM_MAX = 4;
+constexpr int TEAM_MAX = 8;
 struct TeamCnt {
     uint32_t chtot, m[5], xtot, ecnt;      // children of the pass, keys per run of sorted survivors' children, children of sources, dead-end seeds
     uint32_t first_is_surv, pad0;
@@ -1870,9 +1870,11 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
     a.pool = pool;
     const bool narrow = ix.key_len_bits != 0;
     if (team > 1 && resume && rd.ring_mod) {
-        // the chunked path with a team of wavefronts per channel (k_map_team): 2 or 4
+        // the chunked path with a team of wavefronts per channel (k_map_team): 2, 4 or 8
 #define UNC_TEAM_LAUNCH(P_, N_, W_) hipLaunchKernelGGL((k_map_team<P_, N_, W_>), dim3(grid), dim3(WAVE * W_), 0, st, a)
-        if (team >= 4) { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 4); else UNC_TEAM_LAUNCH(true, false, 4); }
+        if (team >= 8) { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 8); else UNC_TEAM_LAUNCH(true, false, 8); }
+                         else { if (narrow) UNC_TEAM_LAUNCH(false, true, 8); else UNC_TEAM_LAUNCH(false, false, 8); } }
+        else if (team >= 4) { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 4); else UNC_TEAM_LAUNCH(true, false, 4); }
                          else { if (narrow) UNC_TEAM_LAUNCH(false, true, 4); else UNC_TEAM_LAUNCH(false, false, 4); } }
         else { if (profile) { if (narrow) UNC_TEAM_LAUNCH(true, true, 2); else UNC_TEAM_LAUNCH(true, false, 2); }
                else { if (narrow) UNC_TEAM_LAUNCH(false, true, 2); else UNC_TEAM_LAUNCH(false, false, 2); } }
