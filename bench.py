@@ -289,7 +289,7 @@ def a_reads(a, workload):
 def measured_traffic(a, workload):
     """HBM bytes per launch of k_map from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected
     from inside this process): used only when they were taken on this workload and batch size, else null."""
-    pmc = ROOT / "profiles" / "r03_pmc_k_map.json"
+    pmc = ROOT / "profiles" / f"r04_pmc_k_map_{workload}.json"
     if not pmc.exists():
         return None, "no PMC pass committed for this kernel"
     d = json.loads(pmc.read_text())
@@ -304,7 +304,7 @@ def measured_traffic(a, workload):
 def issue_roofline(a, workload, launch_ms, clock_hz):
     """Issue side of k_map: wave-instructions of one launch (SQ_INSTS of the committed rocprofv3 pass on this workload and batch
     size -- the count is a property of kernel + batch, the duration is this run's) / (1024 SIMDs x clock x launch time)."""
-    sq = ROOT / "profiles" / "r03_pmc_sq_summary.json"
+    sq = ROOT / "profiles" / f"r04_pmc_sq_summary_{workload}.json"
     if not sq.exists():
         return None
     d = json.loads(sq.read_text())

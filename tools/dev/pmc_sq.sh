@@ -7,11 +7,13 @@
 #   <outdir>/summary.json         SQ counters + derived shares           (-> profiles/rNN_pmc_sq_summary.json)
 #   <outdir>/pmc_k_map.json       calibrated FETCH_SIZE + WRITE_SIZE     (-> profiles/rNN_pmc_k_map.json; bench.py reads it)
 OUT=${1:-gpurun_out/pmc_sq}; LIB=${2:-uncalled_amd/libuncalled_hip.so}; READS=${3:-50000}; shift 3
+# <reads> may carry the workload of tools/dev/ab_libs.py: 250000:grch38, 200000:chr20 (default ecoli)
+NREADS=${READS%%:*}; WORKLOAD=ecoli; case $READS in *:*) WORKLOAD=${READS#*:};; esac
 GROUPS_=${@:-a b d f w cf cw}
 ROOT=$(pwd); mkdir -p $ROOT/$OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift
   rm -rf $ROOT/$OUT/$name
-  AB_NOPROF=1 AB_RUNS=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/$OUT/$name -o pmc -- \
+  AB_NOPROF=1 AB_RUNS=1 timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/$OUT/$name -o pmc -- \
         python $ROOT/tools/dev/ab_libs.py $READS $ROOT/$LIB > $ROOT/$OUT/$name.log 2>&1 || echo "pass $name failed"; tail -1 $ROOT/$OUT/$name.log; }
 calib() { name=$1; shift
   rm -rf $ROOT/$OUT/$name
@@ -31,8 +33,8 @@ cw) calib cw WRITE_SIZE ;;
 esac
 done
 cd $ROOT
-python tools/dev/summarise_sq.py $OUT $READS
-if [ -d $OUT/f ] && [ -d $OUT/w ]; then python tools/dev/summarise_pmc.py $OUT $OUT/pmc_k_map.json $READS ecoli f w cf cw | tail -12; fi
+python tools/dev/summarise_sq.py $OUT $NREADS $OUT/summary.json $WORKLOAD
+if [ -d $OUT/f ] && [ -d $OUT/w ]; then python tools/dev/summarise_pmc.py $OUT $OUT/pmc_k_map.json $NREADS $WORKLOAD f w cf cw | tail -12; fi
 # (after the summaries, which take counters and durations from these files:) what goes home is k_map's and the calibration kernels'
 # rows only -- the complete CSVs of seven passes are more than gpurun merges back
 for f in $(find $OUT -name "*_counter_collection.csv" -o -name "*_kernel_trace.csv"); do

@@ -44,8 +44,9 @@ def durations(dirname, kernel_sub):
     return d
 
 
-res = {"workload": workload, "reads_per_launch": reads, "kernel": "unc::k_map<false, true> (32-bit rows)",
-       "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python tools/dev/ab_libs.py 50000 "
+res = {"workload": workload, "reads_per_launch": reads,
+       "kernel": "unc::k_map<false, false> (64-bit rows, 128-bit keys)" if workload == "grch38" else "unc::k_map<false, true> (32-bit rows)",
+       "command": f"rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python tools/dev/ab_libs.py {reads}:{workload} "
                   "uncalled_amd/libuncalled_hip.so (the bench's batch: same index, same reads, one k_map dispatch; one pass per counter; "
                   "tools/dev/pmc_sq.sh f w cf cw)"}
 calib = {}

@@ -10,6 +10,7 @@ from pathlib import Path
 
 src, reads = Path(sys.argv[1]), int(sys.argv[2])
 out = Path(sys.argv[3]) if len(sys.argv) > 3 else src / "summary.json"
+workload = sys.argv[4] if len(sys.argv) > 4 else "ecoli"
 tot, passes = {}, {}
 for d in sorted(p for p in src.iterdir() if p.is_dir()):
     cc = glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True)
@@ -32,7 +33,9 @@ for d in sorted(p for p in src.iterdir() if p.is_dir()):
             if "k_map" in r.get("Kernel_Name", ""):
                 dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
     passes[d.name] = {"counters": sorted(names), "k_map_dispatches": len(disp), "k_map_ms_under_pmc": dur}
-res = {"workload": "ecoli", "reads_per_launch": reads, "kernel": "unc::k_map<false, true> (32-bit rows)", "passes": passes, "counters": tot,
+res = {"workload": workload, "reads_per_launch": reads,
+       "kernel": "unc::k_map<false, false> (64-bit rows, 128-bit keys)" if workload == "grch38" else "unc::k_map<false, true> (32-bit rows)",
+       "passes": passes, "counters": tot,
        "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (MI355X_MICROARCH.md); one k_map dispatch per pass"}
 g = tot.get
 der = {}
