@@ -28,7 +28,7 @@ bench)
   timeout 1700 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 400 $OUT/bench_default.json; echo ;;
 stats)
   cd /tmp; export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r04 -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --secondary "" > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r04 -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass --secondary "" > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err
   cd $ROOT; ls $OUT/stats/*/ 2>/dev/null | head ;;
 e2e)
   timeout 900 python tools/dev/e2e_map.py 200000 > $OUT/e2e_map.json 2> $OUT/e2e_map.err; tail -c 600 $OUT/e2e_map.json; echo ;;

@@ -34,6 +34,7 @@
 #include "map_sched.h"
 #include "map_tracker.h"
 #include "map_sort.h"
+#include "map_sort_wide.h"
 
 namespace unc {
 
@@ -246,6 +247,8 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
     uint64_t par_carry = 0;
     bool par_bad = false;
+    uint64_t wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0, wm4 = 0;      // wide keys: which parents of the pass have a fitting child in each run ...
+    uint32_t ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0, wsx = 0, w_src_cpos0 = 0;   // ... the runs' fill before the pass, where the sources' children begin
     // parent index list and record headers are fetched one / two passes ahead of their use
     uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
     uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
@@ -280,9 +283,13 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
         if (pfull) { const float4 row = g_load(model4 + okmer); o_mu = row.x; o_v2 = row.y; o_ld = row.z; }
         const Row plen_fm = pend - pstart + 1;
-        if constexpr (NARROW) {
+        {
             // the merge of the children's keys relies on the survivors being in ascending (start, length) order: checked here
-            const uint64_t pk = pi < n_surv_par ? ((uint64_t)pstart << 32) | (uint32_t)(pend - pstart) : ~0ull;
+            uint64_t pk = ~0ull;
+            if (pi < n_surv_par) {
+                if constexpr (NARROW) pk = ((uint64_t)pstart << 32) | (uint32_t)(pend - pstart);
+                else pk = ((uint64_t)pstart << KEY_LEN_BITS) | (uint64_t)(pend - pstart);
+            }
             uint64_t pp = (uint64_t)__shfl_up((unsigned long long)pk, 1);
             if (lane == 0) pp = par_carry;
             if (__any(pi < n_surv_par && !(pk > pp))) par_bad = true;
@@ -389,15 +396,33 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                     s_ckpos[cpos[t]] = (uint16_t)kp[t];
                 }
         } else {
-            uint32_t w = choff;
-            if (stay_ok) { if (w < nwrite) s_cdesc[w] = (uint16_t)lane; ++w; }
+            // wide keys: the same six runs (map_sort_wide.h).  The staging has no room for a position per child: the lane that
+            // writes a child works it out from the five masks (a run takes at most one child per parent) and, for the children
+            // of sources -- the tail of the pass in creation order -- from where that tail begins
+            const bool is_src = pi >= n_surv_par;
+            uint32_t cpos[5];
+            bool ex[5];
+            ex[0] = stay_ok; cpos[0] = choff;
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
-                if (vmask & (1u << b)) {
-                    if (w < nwrite) s_cdesc[w] = (uint16_t)((uint32_t)lane | ((b + 1u) << 6));
-                    ++w;
-                }
+                ex[b + 1] = (vmask >> b) & 1u;
+                cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u));
             }
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t) ex[t] = ex[t] && cpos[t] < nwrite;      // the max_paths cut-off
+            wm0 = __ballot(ex[0] && !is_src); wm1 = __ballot(ex[1] && !is_src); wm2 = __ballot(ex[2] && !is_src);
+            wm3 = __ballot(ex[3] && !is_src); wm4 = __ballot(ex[4] && !is_src);
+            ws0 = scnt0; ws1 = scnt1; ws2 = scnt2; ws3 = scnt3; ws4 = scnt4; wsx = scntx;
+            scnt0 += (uint32_t)__popcll(wm0); scnt1 += (uint32_t)__popcll(wm1); scnt2 += (uint32_t)__popcll(wm2);
+            scnt3 += (uint32_t)__popcll(wm3); scnt4 += (uint32_t)__popcll(wm4);
+            {
+                const uint64_t srcm = __ballot(is_src);
+                w_src_cpos0 = srcm ? lane_get32(choff, (uint32_t)__ffsll((unsigned long long)srcm) - 1u) : chtot;
+                scntx += nwrite > w_src_cpos0 ? nwrite - w_src_cpos0 : 0u;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t)
+                if (ex[t]) s_cdesc[cpos[t]] = (uint16_t)((uint32_t)lane | (t << 6));
         }
         {
             // the children's prob_sums_[0] and the history slid by one event: the window's oldest event drops out, and if the
@@ -481,7 +506,11 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                         if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
                     }
                 } else {
-                    gst(sb, ukeys_off + (gi << 4), key);
+                    const bool csrc = base + pl >= n_surv_par;
+                    const uint64_t wm = type == 0u ? wm0 : type == 1u ? wm1 : type == 2u ? wm2 : type == 3u ? wm3 : wm4;
+                    const uint32_t ws = type == 0u ? ws0 : type == 1u ? ws1 : type == 2u ? ws2 : type == 3u ? ws3 : ws4;
+                    const uint32_t kpos = csrc ? wsx + (li - w_src_cpos0) : ws + (uint32_t)__popcll(wm & ((1ull << pl) - 1ull));
+                    gst(sb, str_off + (csrc ? 5u : type) * (run_bytes << 1) + (kpos << 4), key);
                 }
             }
         }
@@ -502,6 +531,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
 }
 
 static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1> KA_, KeyArr<4> KB_, int lane);
+static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<1> KA_, KeyArr<4> KB_, int lane);
 
 // ---------------- S: the children's keys in the reference's order (mapper.cpp:531, 866-871) ----------------
 template <bool NARROW>
@@ -622,6 +652,64 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
                 kl = 0;
                 wave_sync();
             }
+        }
+    }
+    if constexpr (!NARROW) {
+        // wide keys: the same runs, 16 bytes per key (map_sort_wide.h).  Moves repaired, the unsorted run sorted (into the sorted-keys
+        // area: the network pads to a power of two) and merged with the moves, the result merged with the stays and walked in LDS.
+        const uint32_t str_off = A->sc.off_streams, run_bytes = max_paths << 4;
+        uint32_t scnt0 = ctx_get(s_w.scnt[0]), scnt1 = ctx_get(s_w.scnt[1]), scnt2 = ctx_get(s_w.scnt[2]), scnt3 = ctx_get(s_w.scnt[3]),
+                 scnt4 = ctx_get(s_w.scnt[4]), nx = ctx_get(s_w.scnt[5]);
+        const uint32_t x_off = str_off + 5u * run_bytes;
+        if (n > MERGE_MIN && !ctx_get(s_w.par_unsorted)) {
+            if (scnt1 > 1) { const uint32_t v = repairw_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); scnt1 -= v; nx += v; }
+            if (scnt2 > 1) { const uint32_t v = repairw_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); scnt2 -= v; nx += v; }
+            if (scnt3 > 1) { const uint32_t v = repairw_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); scnt3 -= v; nx += v; }
+            if (scnt4 > 1) { const uint32_t v = repairw_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); scnt4 -= v; nx += v; }
+            wave_sync();
+            uint32_t xs_off = x_off;              // where the sorted unsorted-run lies
+            if (nx > 1) {
+                const UNC_AS_GLOBAL SortKey *const xin = reinterpret_cast<const UNC_AS_GLOBAL SortKey *>(sb + x_off);
+                if (nx <= 64) sort_regs<1>(xin, skeys, nx, lane);
+                else if (nx <= 128) sort_regs<2>(xin, skeys, nx, lane);
+                else if (nx <= 256) sort_regs<4>(xin, skeys, nx, lane);
+                else if (nx <= 512) sort_regs<8>(xin, skeys, nx, lane);
+                else sort_hybrid(xin, skeys, nx, lane);
+                xs_off = skeys_off;
+                wave_sync();
+            }
+            KeyArr<4> KM;       // the moves, base by base
+            KM.cum[0] = 0; KM.cum[1] = scnt1; KM.cum[2] = scnt1 + scnt2; KM.cum[3] = scnt1 + scnt2 + scnt3;
+            KM.n = KM.cum[3] + scnt4;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 4);
+            KeyArr<4> KB = KM;  // what the stays are merged with
+            if (nx > 0) {
+                if (KM.n > 0) {
+                    mergew_runs<4, 1>(sb, KM, kaw_single(xs_off, nx), ukeys_off, lane);      // (the unsorted-keys area is free in this mode)
+                    wave_sync();
+                    KB.adj[0] = ukeys_off;
+                } else KB.adj[0] = xs_off;
+                KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
+                KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
+            }
+            merge_walk_w(A, sb, kaw_single(str_off, scnt0), KB, lane);
+            CTX_SET(kl, 0u);
+            CTX_SET(walked, 1u);
+            wave_sync();
+            return;
+        }
+        // few children, or parents that were not in order: all runs into the unsorted-keys area, then the network as before
+        {
+            const uint32_t c[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
+            uint32_t cum = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 6; ++r) {
+                for (uint32_t i = (uint32_t)lane; i < c[r]; i += WAVE) g_store(ukeys + cum + i, gld<SortKey>(sb, str_off + r * run_bytes + (i << 4)));
+                cum += c[r];
+            }
+            UNC_SIM_CHECK(cum == n);
+            wave_sync();
         }
     }
     if (!kl) {
@@ -978,6 +1066,91 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
     }
     if (bad && lane == 0) s_w.tstatus |= UNC_READ_SORT_FAULT;
     walk_finish<true>(C, S, lane);
+}
+
+// wide keys, many children: the last merge -- the stays with everything else -- and the walk in one (merge_walk for 16-byte keys:
+// a key carries its own info word, the walk reads range, k-mer, seed probability and creation index off the tile)
+static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<1> KA_, KeyArr<4> KB_, int lane) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    SortKey *const tile = reinterpret_cast<SortKey *>(s_e);
+    const KeyArr<1> KA = ka_uniform(KA_);
+    const KeyArr<4> KB = ka_uniform(KB_);
+    const uint32_t n = KA.n + KB.n;
+    const WalkConst<false> C = walk_const<false>(A, sb);
+    WalkState<false> S;
+    S.n_seedp = ctx_get(s_w.n_seedp);
+    uint32_t a0 = 0, b0 = 0;
+    SortKey pend_key; pend_key.a = 0; pend_key.b = 0;      // the previous tile's last key: walked first in this tile
+    bool have_pend = false, bad = false;
+    const ulonglong2 no_range = make_ulonglong2(1ull, 0ull);
+    for (uint32_t o0 = 0; o0 < n; o0 += MERGEW_TILE) {
+        const uint32_t d1 = o0 + MERGEW_TILE < n ? o0 + MERGEW_TILE : n;
+        const bool last_tile = d1 == n;
+        const uint32_t a1 = last_tile ? KA.n : mergew_split(sb, KA, KB, d1, lane);
+        const uint32_t b1 = d1 - a1;
+        const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
+        {
+            SortKey v[MERGEW_C];
+#pragma unroll
+            for (uint32_t c = 0; c < MERGEW_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                v[c].a = 0; v[c].b = 0;
+                if (i < na) v[c] = kaw_load(sb, KA, a0 + i);
+                else if (i < tn) v[c] = kaw_load(sb, KB, b0 + (i - na));
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < MERGEW_C; ++c) {
+                const uint32_t i = (uint32_t)lane + c * WAVE;
+                if (i < tn) tile[i] = v[c];
+            }
+        }
+        wave_sync();
+        SortKey o[MERGEW_C];
+        uint32_t d, cnt;
+        mergew_tile(tile, na, nb, lane, o, d, cnt);
+        {   // the tile must come out ascending, and after the previous tile's last key
+            SortKey last = o[0];
+            bool w = false;
+#pragma unroll
+            for (uint32_t c = 1; c < MERGEW_C; ++c)
+                if (c < cnt) { w = w || !wk_lt(last, o[c]); last = o[c]; }
+            SortKey pl;
+            pl.a = (uint64_t)__shfl_up((unsigned long long)last.a, 1); pl.b = (uint64_t)__shfl_up((unsigned long long)last.b, 1);
+            if (lane == 0) pl = pend_key;
+            if (cnt > 0 && !wk_lt(pl, o[0])) w = true;
+            if (__any(w)) bad = true;
+        }
+        // sorted tile at logical positions 1 .. tn, the waiting key at 0
+        wave_sync();
+#pragma unroll
+        for (uint32_t c = 0; c < MERGEW_C; ++c)
+            if (c < cnt) tile[1u + d + c] = o[c];
+        if (lane == 0 && have_pend) tile[0] = pend_key;
+        wave_sync();
+        const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
+        for (uint32_t base = p0; base < p1; base += WAVE) {
+            const uint32_t p = base + (uint32_t)lane;
+            const bool have = p < p1;
+            const bool has_next = have && p < tn;
+            const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+            SortKey ki, kn;
+            ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
+            if (have) ki = tile[p];
+            if (has_next) kn = tile[p + 1u];
+            const uint64_t start = ki.a >> KEY_LEN_BITS, end = start + (ki.a & KEY_LEN_MASK), nstart = kn.a >> KEY_LEN_BITS;
+            const uint32_t kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
+            const uint32_t nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
+            const bool dup = has_next && kn.a == ki.a;          // equal fm_range_, :569 (sorted by seed_prob inside the run: the last one survives)
+            walk_core<false>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, ki.b, false, no_range, nv, lane);
+        }
+        pend_key.a = uniform64(tile[tn].a); pend_key.b = uniform64(tile[tn].b);
+        have_pend = true;
+        a0 = a1; b0 = b1;
+        wave_sync();
+    }
+    if (bad && lane == 0) s_w.tstatus |= UNC_READ_SORT_FAULT;
+    walk_finish<false>(C, S, lane);
 }
 
 // ---------------- F: remaining full-range sources, :605-624; the next parent list is complete after it ----------------
@@ -1501,7 +1674,8 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         const uint32_t choff = excl_sum_bits<3>(nch, &chtot);
         wave_sync();             // (the candidate list is dead: its space takes the descriptors)
         const bool is_src = pi >= n_surv_par;
-        uint32_t mcount[5] = {0, 0, 0, 0, 0}, xtot = 0;
+        uint32_t mcount[5] = {0, 0, 0, 0, 0}, xtot = 0, src_cpos0 = chtot;
+        uint64_t tm[5] = {0, 0, 0, 0, 0};          // which parents of the pass have a child in each run of sorted survivors' children
         {
             uint32_t cpos[5];
             bool ex[5];
@@ -1512,23 +1686,24 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                 cpos[b + 1] = choff + (stay_ok ? 1u : 0u) + (uint32_t)__popc(vmask & ((1u << b) - 1u));
             }
             uint32_t kp[5] = {0, 0, 0, 0, 0};
-            if constexpr (NARROW) {
-                if (base < n_surv_par) {
+            if (base < n_surv_par) {
 #pragma unroll
-                    for (uint32_t t = 0; t < 5; ++t) {
-                        const uint64_t mt = __ballot(ex[t] && !is_src);
-                        kp[t] = (uint32_t)prefix_popc(mt);
-                        mcount[t] = (uint32_t)__popcll(mt);
-                    }
+                for (uint32_t t = 0; t < 5; ++t) {
+                    const uint64_t mt = __ballot(ex[t] && !is_src);
+                    kp[t] = (uint32_t)prefix_popc(mt);
+                    mcount[t] = (uint32_t)__popcll(mt);
+                    tm[t] = mt;
                 }
-                if (base + WAVE > n_surv_par) {
-                    const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
-                    uint32_t xo = excl_sum_bits<3>(nfit, &xtot);
-                    if (is_src) {
+            }
+            if (base + WAVE > n_surv_par) {
+                const uint32_t nfit = is_src ? (ex[0] ? 1u : 0u) + (ex[1] ? 1u : 0u) + (ex[2] ? 1u : 0u) + (ex[3] ? 1u : 0u) + (ex[4] ? 1u : 0u) : 0u;
+                uint32_t xo = excl_sum_bits<3>(nfit, &xtot);
+                if (is_src) {
 #pragma unroll
-                        for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
-                    }
+                    for (uint32_t t = 0; t < 5; ++t) { kp[t] = xo; if (ex[t]) ++xo; }
                 }
+                const uint64_t srcm = __ballot(is_src);
+                src_cpos0 = srcm ? lane_get32(choff, (uint32_t)__ffsll((unsigned long long)srcm) - 1u) : chtot;
             }
 #pragma unroll
             for (uint32_t t = 0; t < 5; ++t)
@@ -1654,10 +1829,17 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                         if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
                     }
                 } else {
-                    gst(sb, ukeys_off + (gi << 4), key);
+                    // wide keys: no room for a position per child in the staging -- from the masks, and for the children of sources
+                    // (the tail of the pass in creation order) from where that tail begins
+                    const bool csrc = (d >> 9) != 0u;
+                    run = csrc ? 5u : type;
+                    const uint64_t wm = type == 0u ? tm[0] : type == 1u ? tm[1] : type == 2u ? tm[2] : type == 3u ? tm[3] : tm[4];
+                    const uint32_t kb = run == 0u ? b_m[0] : run == 1u ? b_m[1] : run == 2u ? b_m[2] : run == 3u ? b_m[3] : run == 4u ? b_m[4] : b_x;
+                    const uint32_t kpos = csrc ? kb + (li - src_cpos0) : kb + (uint32_t)__popcll(wm & ((1ull << pl) - 1ull));
+                    gst(sb, str_off + run * (run_bytes << 1) + (kpos << 4), key);
                 }
             }
-            if (NARROW && cut) {       // (only the round that hits the cut-off needs the kept counts)
+            if (cut) {       // (only the round that hits the cut-off needs the kept counts)
 #pragma unroll
                 for (uint32_t t = 0; t < 5; ++t) kept_m[t] += (uint32_t)__popcll(__ballot(run == t));
                 kept_x += (uint32_t)__popcll(__ballot(run == 5u));

@@ -157,7 +157,7 @@ struct DevScratch {
     uint32_t off_cl_chunks;  // u32   [max_clusters / 4 / 512 + 1]: the pool chunks this read holds
     uint32_t off_state;    // SlotState
     // narrow sort keys (DevIndex::key_len_bits > 0): the children's 64-bit keys leave phase E as sorted streams
-    uint32_t off_streams;  // u64     [6][max_paths]: stays, moves by base 0..3 (children of the sorted survivors), the rest
+    uint32_t off_streams;  // u64 (SortKey with 128-bit keys) [6][max_paths]: stays, moves by base 0..3 (children of the sorted survivors), the rest
     uint32_t off_info;     // u64     [max_paths]: a child's info word (SortKey::b) by creation index
     uint32_t off_tmp;      // u64     [max_paths]: intermediate run of the merge
 };

@@ -500,7 +500,9 @@ static void free_scratch(DevScratch &sc) {
 
 // Regions of one slot (DevScratch), each 256-byte aligned; everything below 4 GB so that kernels address a slot as
 // uniform base + 32-bit offset.
-static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, uint32_t n_buckets) {
+static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, const DevIndex &dix) {
+    const uint32_t n_buckets = dix.n_buckets;
+    const bool wide = dix.key_len_bits == 0;          // 128-bit sort keys: the runs of child keys hold 16-byte elements
     memset(&sc, 0, sizeof sc);
     sc.max_paths = P.max_paths;
     uint32_t kc = 64;
@@ -520,7 +522,7 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     const uint64_t o_cld = region(((uint64_t)n_buckets + 4) * 4);
     const uint64_t o_clc = region((max_nodes / CHUNK_NODES + 1) * 4);
     const uint64_t o_state = region(sizeof(SlotState));
-    const uint64_t o_streams = region(6ull * sc.max_paths * 8);
+    const uint64_t o_streams = region(6ull * sc.max_paths * (wide ? 16 : 8));
     const uint64_t o_info = region((uint64_t)sc.max_paths * 8);
     const uint64_t o_tmp = region((uint64_t)sc.max_paths * 8);
     if (off >= (1ull << 32)) return fail(UNC_ERR_ARG, "per-read scratch of %llu bytes does not fit 32-bit offsets (max_clusters %u)", (unsigned long long)off, max_clusters);
@@ -532,14 +534,14 @@ static int scratch_layout(DevScratch &sc, const unc_params_t &P, uint32_t max_cl
     return UNC_OK;
 }
 
-static uint64_t scratch_slot_bytes(const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, uint32_t n_buckets) {
+static uint64_t scratch_slot_bytes(const unc_params_t &P, uint32_t max_clusters, uint32_t max_seed_paths, const DevIndex &dix) {
     DevScratch t;
-    return scratch_layout(t, P, max_clusters, max_seed_paths, n_buckets) == UNC_OK ? t.slot_bytes : ~0ull;
+    return scratch_layout(t, P, max_clusters, max_seed_paths, dix) == UNC_OK ? t.slot_bytes : ~0ull;
 }
 
 static int alloc_scratch(DevScratch &sc, const unc_params_t &P, size_t n_slots, uint32_t max_clusters, uint32_t max_seed_paths,
-                         size_t *bytes_out, uint32_t n_buckets) {
-    int rc = scratch_layout(sc, P, max_clusters, max_seed_paths, n_buckets);
+                         size_t *bytes_out, const DevIndex &dix) {
+    int rc = scratch_layout(sc, P, max_clusters, max_seed_paths, dix);
     if (rc) return rc;
     const size_t bytes = (size_t)n_slots * sc.slot_bytes;
     HIPCHK(hipMalloc((void **)&sc.base, bytes));
@@ -615,7 +617,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
         const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
-        const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0, ix->dev.n_buckets);
+        const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0, ix->dev);
         size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
         if (n_slots < n_waves) n_slots = n_waves;
@@ -632,7 +634,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     // per read: the table of bucket heads of its seed-cluster grid and the list of its pool chunks; max_clusters / 4 is the number
     // of nodes a read may take from the pool below (its allowance)
     const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
-    int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes, ix->dev.n_buckets);
+    int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes, ix->dev);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
     {
@@ -902,10 +904,10 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                 m->big_cap = 0; m->big_slots = 0;
                 size_t free_b = 0, total_b = 0;
                 HIPCHK(hipMemGetInfo(&free_b, &total_b));
-                const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths, m->ix->dev.n_buckets);
+                const size_t per_slot = scratch_slot_bytes(m->P, (uint32_t)cap, m->sc.max_seed_paths, m->ix->dev);
                 const size_t fit = std::max<size_t>(1, free_b / 4 / per_slot);
                 const size_t n = std::min(want, fit);
-                int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr, m->ix->dev.n_buckets);
+                int rc2 = alloc_scratch(m->big, m->P, n, (uint32_t)cap, m->sc.max_seed_paths, nullptr, m->ix->dev);
                 if (rc2) { free_scratch(m->big); return rc2; }
                 m->big_cap = cap; m->big_slots = n; m->big_at_limit = n == fit;
             }
@@ -1356,7 +1358,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     const size_t S = n_channels;
     size_t bytes = 0;
     {
-        int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes, ix->dev.n_buckets);
+        int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes, ix->dev);
         if (rc) return rc;
         HIPCHK(hipMemset(rt->sc.base, 0, bytes));
         // the channels' node pool: 16 chunks (12 288 nodes) per channel on average, 64 on references of 2^26 rows and more (a read
