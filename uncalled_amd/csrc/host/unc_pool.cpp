@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -404,7 +405,10 @@ void MapPool::loader_main() {
             // meanwhile, so both buffers reach their final size during the first two batches and never grow again
             uint64_t need = b.used + r.signal.size() + 1;
             if (need > b.cap && b.meta.size() >= 16) {
-                const uint64_t est = (uint64_t)((double)b.used / (double)b.meta.size() * (double)batch_reads_ * 1.1);
+                // (... but never for more reads than are left: a small input must not page-lock gigabytes it will never fill -- round-3 advice)
+                const uint32_t left = reader_.reads_left_if_known();
+                const uint64_t full = left == 0xFFFFFFFFu ? batch_reads_ : std::min<uint64_t>(batch_reads_, b.meta.size() + 1u + left);
+                const uint64_t est = (uint64_t)((double)b.used / (double)b.meta.size() * (double)full * 1.1);
                 if (est > need) need = est < kBatchBytes / 2 ? est : kBatchBytes / 2;
                 if (need < b.used + r.signal.size() + 1) need = b.used + r.signal.size() + 1;
             }

@@ -87,6 +87,8 @@ public:
     uint32_t buffered() const { return (uint32_t)buffered_.size(); }
     uint64_t front_size() const { return buffered_.empty() ? 0 : buffered_.front().signal.size(); }   // samples of the read pop_read hands out next
     bool all_buffered() const;
+    // reads still to come when that is known -- no file left to open: the open file's unread reads + the buffered ones -- else UINT32_MAX
+    uint32_t reads_left_if_known() const { return fast5_list_.empty() ? (uint32_t)(read_paths_.size() + buffered_.size()) : 0xFFFFFFFFu; }
 
 private:
     bool open_next();
