@@ -51,6 +51,42 @@ def test_committed_bench_line_has_every_contract_field():
     assert abs(avg_ms - b["roofline"]["launch_ms"]) / b["roofline"]["launch_ms"] < 0.03
 
 
+def test_round4_bench_line():
+    """The committed round-4 line (profiles/r04_bench_default_final.json, one gpurun call on the shipped kernel): contract fields, the
+    roofline arithmetic, counter-backed traffic / issue on the headline AND on GRCh38, the exposure counts that bound the two parity
+    residuals (tie order, Mapper state carried between reads), and the rocprofv3 summary of the same command agreeing with the HIP
+    events of the line produced under it."""
+    b = _line("r04_bench_default_final.json")
+    assert b["metric"] == "reads_mapped_per_sec" and b["n_gpus"] == 1 and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert abs(b["value"] - 50000 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6 and b["value"] > 17000
+    blocks = {"ecoli": b, "chr20": b["secondary"]["chr20"], "grch38": b["secondary"]["grch38"]}
+    for name, blk in blocks.items():
+        r = blk["roofline"]
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and r["frac"] > 0.27, name
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+        assert r["traffic"] and r["issue"] and 0.15 < r["issue"]["utilisation"] < 0.35, name          # counters for every workload
+        v, c = blk["verify"], blk["cpu_baseline"]
+        assert v["all_steps_identical"] and v["paf_mismatches"] == 0 and c["paf_mismatches_vs_gpu"] == 0 and c["kind"] == "reference"
+        assert v["reads_that_filled_max_paths"] > 0                      # the condition under which Mapper state can leak exists ...
+        t1 = v["t1_order"]
+        assert t1["reads_mapped_again"] == v["reads_ending_with_sources_added_set"]      # ... and the -t 1 order re-maps exactly its victims
+        assert t1["reads_whose_paf_columns_changed"] == 0
+        tie = c["tie_order"]
+        assert tie["events_with_a_tie"] > 0 and set(tie["paf_lines_differing_from_stable"]) == {"pdqsort_restated", "reversed_ties"}
+        assert max(tie["paf_lines_differing_from_stable"].values()) <= 0.02 * tie["reads"], name
+    assert blocks["grch38"]["config"]["index_seq_len"] == 6200000000 and blocks["grch38"]["n_gpus"] == 1
+    assert blocks["grch38"]["value"] > 9000 and blocks["grch38"]["config"]["k_map_phase_cycle_share"]["add_seed"] < 0.25
+    rt = b["secondary"]["realtime:ecoli"]
+    assert rt["config"]["latency_ms"]["p95"] <= 100.0 and rt["verify"]["paf_mismatches"] == 0 and rt["verify"]["reads_checked"] >= 64
+    under = _line("r04_bench_under_rocprofv3.json")
+    import csv
+    rows = list(csv.DictReader((ROOT / "profiles" / "r04_rocprofv3_kernel_stats.csv").open()))
+    row = next(r for r in rows if "k_map<false, true>" in r["Name"])
+    avg_ms = float(row["AverageNs"]) * 1e-6
+    assert int(row["Calls"]) == under["steps"] + under["warmup"]
+    assert abs(avg_ms - under["roofline"]["launch_ms"]) / avg_ms < 0.03
+
+
 def test_algorithmic_bytes_formula():
     import importlib.util
     import sys
