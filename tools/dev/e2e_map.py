@@ -57,7 +57,8 @@ t_reader = time.time() - t0
 # steady state can be told apart
 import select
 t0 = time.time()
-p = subprocess.Popen([sys.executable, "-u", "-m", "uncalled_amd", "map", str(prefix), str(d)], cwd=str(ROOT), stdout=subprocess.PIPE,
+extra = sys.argv[2:]          # further arguments of `uncalled_amd map`, e.g. -t 2 (independent read order instead of the default -t 1 order)
+p = subprocess.Popen([sys.executable, "-u", "-m", "uncalled_amd", "map", str(prefix), str(d)] + extra, cwd=str(ROOT), stdout=subprocess.PIPE,
                      stderr=subprocess.PIPE, text=True, bufsize=1)
 stamps, mapped, n_lines = [], 0, 0
 for line in p.stdout:
@@ -84,7 +85,7 @@ bursts.append(cur[-1] if cur else stamps[-1])
 steady = None
 if len(bursts) > 1 and bursts[-1][0] > bursts[0][0]:
     steady = (bursts[-1][1] - bursts[0][1]) / (bursts[-1][0] - bursts[0][0])
-print(json.dumps({"workload": "python -m uncalled_amd map <ecoli_syn> <dir of multi-fast5 files>", "reads": n, "fast5_files": len(files),
+print(json.dumps({"workload": "python -m uncalled_amd map <ecoli_syn> <dir of multi-fast5 files> " + " ".join(extra), "reads": n, "fast5_files": len(files),
                   "fast5_bytes": sum(f.stat().st_size for f in files), "wall_s_incl_process_start_and_index_load": dt,
                   "reads_per_sec_end_to_end": n_lines / dt, "first_paf_line_after_s": t_first,
                   "reads_per_sec_steady_state": steady,
