@@ -621,3 +621,46 @@ def case_mid_reference(lib, oracle_lib, tmp_path, n=3, genome=800000, cut=8000):
     want = oracle_hits(oracle_lib.Index(prefix), raw, o, cal)
     assert_hits_equal(hits, want, "mid reference")
     assert (hits["n_nbr"] / np.maximum(hits["event_i"], 1)).max() > 300      # events well past the merge threshold
+
+
+def case_chunked_mid_reference(lib, oracle_lib, tmp_path, n=2, genome=800000, cut=8000, chunk_len=4000, n_channels=2):
+    """The chunked path where events have HUNDREDS of children (case_mid_reference's reference and thresholds): the team kernel's own
+    sort -- runs repaired by four waves at once, merge tiles dealt to the waves, the leader walking the sorted tiles in the other
+    waves' LDS -- only runs for events past the merge threshold, which the 10 kb example index hardly produces.  Chunk by chunk
+    against the oracle's chunk path, per-channel state carried from read to read."""
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
+    from uncalled_amd.realtime import MapPoolOrd
+    from tools.simulate_reads import simulate_reads
+    po = oracle_lib
+    names, lens, codes = synthetic_genome(1, genome, seed=11)
+    prefix = tmp_path / "mid"
+    build_from_codes(prefix, names, [""], lens, codes)
+    (tmp_path / "mid.uncl").write_text("default\t-10.07,-5.5,-5.0,-4.6,-4.3,-4.1\t0.3\t115.000\n")     # permissive: hundreds of children per event
+    sim = simulate_reads(codes, lens, n, seed=5)
+    off = sim["offsets"]
+    dev_index = capi.Index(prefix, lib=lib)
+    oix = po.Index(prefix)
+    p = capi.default_params(lib)
+    p.chunk_time = chunk_len / p.sample_rate
+    pool = MapPoolOrd(dev_index, n_channels=n_channels, params=p)
+    oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_channels)]
+    cal = (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    want = {}
+    for i in range(n):
+        raw = sim["signal"][int(off[i]):int(off[i]) + cut]
+        pool.add_read(i % n_channels, i, raw, cal, key=i)
+        want[i] = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+    got, rounds = {}, 0
+    while pool.running():
+        for key, r in pool.update():
+            got[key] = r
+        rounds += 1
+        assert rounds < 1000
+    names_dev = dev_index.seq_names()
+    for i in range(n):
+        h, o = got[i]["hit"], want[i]
+        assert int(h["status"]) == 0
+        assert capi.hit_paf_cols(h, names_dev) == po.hit_paf_cols(o, oix.ref_names()), i
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+            assert int(h[f]) == int(o[f]), (i, f)
+    assert max(int(want[i]["n_nbr"]) / max(int(want[i]["event_i"]), 1) for i in range(n)) > 300      # events well past the merge threshold

@@ -199,3 +199,9 @@ def test_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunk
 
 def test_big_forests(hip_lib, oracle_lib, example, goldens, tmp_path, monkeypatch):
     pc.case_big_forests(hip_lib, oracle_lib, example, goldens, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("team", [8, 4, 2, 1])
+def test_chunked_mid_reference_team_sort(hip_lib, oracle_lib, tmp_path, monkeypatch, team):
+    monkeypatch.setenv("UNC_RT_TEAM", str(team))
+    pc.case_chunked_mid_reference(hip_lib, oracle_lib, tmp_path, n=4, cut=8000)

@@ -47,6 +47,14 @@ def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
 
+@pytest.mark.parametrize("team", [8, 4, 1])
+def test_chunked_team_sizes(sim_lib, oracle_lib, example, goldens, monkeypatch, team):
+    """k_map_team with 8 and 4 wavefronts per channel, and the one-wavefront kernel (the other chunked cases of this suite run on
+    teams of 2, see conftest.py): the same reads, chunk by chunk, as the oracle maps them."""
+    monkeypatch.setenv("UNC_RT_TEAM", str(team))
+    pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, 2, 4, None)
+
+
 @pytest.mark.parametrize("shift", [4])          # (8 as well on the GPU)
 def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift):
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
@@ -116,3 +124,9 @@ def test_merge_check_and_fallback(sim_lib_norepair, oracle_lib, example, goldens
 
 def test_merge_walk_mid_reference(sim_lib, oracle_lib, tmp_path):
     pc.case_mid_reference(sim_lib, oracle_lib, tmp_path, n=2, cut=6000)          # (3 reads of 8000 samples on the GPU)
+
+
+@pytest.mark.parametrize("team", [2, 8])
+def test_chunked_mid_reference_team_sort(sim_lib, oracle_lib, tmp_path, monkeypatch, team):
+    monkeypatch.setenv("UNC_RT_TEAM", str(team))
+    pc.case_chunked_mid_reference(sim_lib, oracle_lib, tmp_path, n=2, cut=5000)          # (4 reads of 8000 samples on the GPU)

@@ -1594,6 +1594,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
     if (pi0 < n_parents) {
         q0c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
     }
+    PhaseClock<PROF> clk;       // (the leader's view of a round: 8 parents + candidates, 9 FM, 10 slots, 11 the wait at the exchange, 1 children)
     for (uint32_t rbase = 0, rnd = 0; rbase < n_parents && TT.nchild < max_paths; rbase += PSTRIDE, ++rnd) {
         const uint32_t base = rbase + (uint32_t)wave * WAVE;
         const uint32_t pi = base + (uint32_t)lane;
@@ -1649,6 +1650,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                 if (mask & (1u << b)) s_cand[w++] = (uint16_t)(((uint32_t)lane << 2) | b);
         }
         wave_sync();
+        if (wave == 0) clk.end(8, lane);
         for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
             const uint32_t ci = c0 + (uint32_t)lane;
             if (ci < ctot) {
@@ -1665,6 +1667,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             }
         }
         wave_sync();
+        if (wave == 0) clk.end(9, lane);
         // ---- the pass's children as if nothing were cut off: who, where in the pass, where among the pass's keys of its run
         const uint32_t rb = (uint32_t)lane << 2;
         uint32_t vmask = (s_res[rb] != 0 ? 1u : 0u) | (s_res[rb + 1] != 0 ? 2u : 0u) | (s_res[rb + 2] != 0 ? 4u : 0u) | (s_res[rb + 3] != 0 ? 8u : 0u);
@@ -1751,7 +1754,9 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             c.first_pk = first_pk; c.last_pk = last_pk;
             s_team_cnt[rnd & 1u][wave] = c;
         }
+        if (wave == 0) clk.end(10, lane);
         team_barrier();
+        if (wave == 0) clk.end(11, lane);
         // ---- what the waves before this one counted; the round's totals
         uint32_t b_child = TT.nchild, b_seed = TT.n_seedp, b_x = TT.scntx, b_m[5];
         uint32_t r_child = 0, r_seed = 0, r_x = 0, r_m[5] = {0, 0, 0, 0, 0};
@@ -1871,6 +1876,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             team_barrier();        // (the slots are written again two rounds on at the earliest, but the loop ends here: keep it simple)
         }
         wave_sync();
+        if (wave == 0) clk.end(1, lane);
     }
     // what the leader needs of the followers: flags, their share of the work counter
     const uint32_t fl = (__any(bchild) ? 1u : 0u) | (par_bad ? 2u : 0u) | (__any(seed_over) ? 4u : 0u);
@@ -1880,6 +1886,253 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         c_nbr = 0;
     } else if (lane == 0 && fl) atomicOr(&s_team_flags, fl);
     return c_nbr;
+}
+
+// ---- phase S in a team (narrow keys, an event of more than MERGE_MIN children whose parents were in order and that has no boundary
+// child: the common case; everything else is the leader's, on phase_S).  The leader's sort is half of a team's round, and most of it
+// is work on independent pieces: the four runs of moves are repaired by four waves at once (their misfits go to disjoint parts of the
+// unsorted run's room and are pushed together afterwards), the tiles of both merges are dealt to the waves -- a tile is independent
+// of its neighbours once its two merge-path splits are known -- and only the walk, which carries state from key to key, stays with
+// the leader: it walks the sorted tiles where the waves left them in LDS.
+__shared__ uint32_t s_team_v[TEAM_MAX];            // repair: misfits of run 1 + i; merge: keys of the tile wave i has left in its staging
+__shared__ uint32_t s_team_bad;                    // a tile did not come out ascending
+
+__device__ __forceinline__ uint64_t *team_stage(int wave) { return wave == 0 ? s_e : s_e_x[wave > 0 ? wave - 1 : 0]; }
+
+// tile [d0, d1) of merge(A, B): both splits, the tile's share of A and B staged in `tile`, each lane's outputs in o[0 .. cnt) (logical
+// positions d .. d + cnt of the tile); tn = keys of the tile
+template <int RA, int RB>
+__device__ __forceinline__ void team_merge_tile(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d0, uint32_t d1, uint64_t *tile, int lane,
+                                                uint64_t (&o)[MERGE_C], uint32_t &d, uint32_t &cnt, uint32_t &tn) {
+    const uint32_t n = A.n + B.n;
+    const uint32_t a0 = d0 == 0u ? 0u : merge_split(sb, A, B, d0, lane);
+    const uint32_t a1 = d1 == n ? A.n : merge_split(sb, A, B, d1, lane);
+    const uint32_t b0 = d0 - a0, b1 = d1 - a1;
+    const uint32_t na = a1 - a0, nb = b1 - b0;
+    tn = na + nb;
+    {
+        uint64_t v[MERGE_C];
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c) {
+            const uint32_t i = (uint32_t)lane + c * WAVE;
+            v[c] = 0;
+            if (i < na) v[c] = ka_load(sb, A, a0 + i);
+            else if (i < tn) v[c] = ka_load(sb, B, b0 + (i - na));
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < MERGE_C; ++c) {
+            const uint32_t i = (uint32_t)lane + c * WAVE;
+            if (i < tn) tile[mslot(i)] = v[c];
+        }
+    }
+    wave_sync();
+    d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
+    cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
+    uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+    while (__any(lo < hi)) {
+        if (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile[mslot(mid)] < tile[mslot(na + d - 1u - mid)]) lo = mid + 1u; else hi = mid;
+        }
+    }
+    uint32_t ia = lo, ib = d - lo;
+    uint64_t va = ia < na ? tile[mslot(ia)] : ~0ull, vb = ib < nb ? tile[mslot(na + ib)] : ~0ull;
+#pragma unroll
+    for (uint32_t c = 0; c < MERGE_C; ++c) {
+        const bool ta = va < vb;
+        o[c] = ta ? va : vb;
+        if (ta) ++ia; else ++ib;
+        const uint32_t idx = ta ? ia : na + ib;
+        const bool ok = ta ? ia < na : ib < nb;
+        uint64_t x = ~0ull;
+        if (ok && c + 1u < cnt) x = tile[mslot(idx)];
+        if (ta) va = x; else vb = x;
+    }
+    wave_sync();
+}
+
+// returns false when the event is not one for the team (the leader then runs phase_S)
+template <int W>
+static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lane, int wave) {
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    const uint32_t n = ctx_get(s_w.nchild);
+    if (!(n > MERGE_MIN) || ctx_get(s_w.par_unsorted) || ctx_get(s_w.bchild) || !MERGE_REPAIR) return false;     // (uniform over the team)
+    const uint32_t max_paths = A->sc.max_paths;
+    const uint32_t str_off = A->sc.off_streams, run_bytes = max_paths << 3, x_off = str_off + 5u * run_bytes;
+    uint64_t *const tile = team_stage(wave);
+    uint32_t scnt[5] = {ctx_get(s_w.scnt[0]), ctx_get(s_w.scnt[1]), ctx_get(s_w.scnt[2]), ctx_get(s_w.scnt[3]), ctx_get(s_w.scnt[4])};
+    uint32_t nx = ctx_get(s_w.scnt[5]);
+    // ---- repair: the moves with base r - 1 are run r, taken by wave (r - 1) mod W; its misfits go behind the unsorted run's keys and everything the earlier
+    // runs could send there (room: the runs hold n keys together)
+    for (uint32_t r = (uint32_t)wave + 1u; r <= 4u; r += (uint32_t)W) {          // (run r's misfits are counted in s_team_v[r - 1])
+        uint32_t area = nx;
+        for (uint32_t q = 1; q < r; ++q) area += scnt[q];
+        const uint32_t v = scnt[r] > 1u ? repair_run(sb, str_off + r * run_bytes, scnt[r], x_off, area, lane) : 0u;
+        if (lane == 0) s_team_v[r - 1u] = v;
+    }
+    if (wave == 0 && lane == 0) s_team_bad = 0;
+    team_barrier();
+    {
+        // the misfits, pushed together behind the unsorted run (few keys; the leader); every wave learns the new counts
+        uint32_t v[4], area = nx, dst = nx;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) v[q] = uniform32(s_team_v[q]);
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (wave == 0 && v[q] && area != dst)
+                for (uint32_t i0 = 0; i0 < v[q]; i0 += WAVE) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    uint64_t kq = 0;
+                    if (i < v[q]) kq = gld<uint64_t>(sb, x_off + ((area + i) << 3));
+                    wave_sync();
+                    if (i < v[q]) gst(sb, x_off + ((dst + i) << 3), kq);
+                    wave_sync();
+                }
+            area += scnt[q + 1u]; dst += v[q];
+            scnt[q + 1u] -= v[q];
+        }
+        nx = dst;
+    }
+    // ---- the unsorted run: the leader (the network is a single wavefront's)
+    if (wave == 0 && nx > 1) {
+        KeyArr<6> KX;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { KX.adj[r] = x_off; KX.cum[r] = 0; }
+        KX.n = nx;
+        sort_any64(sb, KX, x_off, lane);
+        wave_sync();
+    }
+    team_barrier();
+    // ---- moves + unsorted -> tmp, tile by tile
+    KeyArr<4> KM;
+    KM.cum[0] = 0; KM.cum[1] = scnt[1]; KM.cum[2] = scnt[1] + scnt[2]; KM.cum[3] = scnt[1] + scnt[2] + scnt[3];
+    KM.n = KM.cum[3] + scnt[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) KM.adj[r] = str_off + (r + 1u) * run_bytes - (KM.cum[r] << 3);
+    KeyArr<4> KB = KM;
+    if (nx > 0) {
+        if (KM.n > 0) {
+            const KeyArr<1> KX1 = ka_single(x_off, nx);
+            const uint32_t nm = KM.n + nx, out_off = A->sc.off_tmp;
+            for (uint32_t t = (uint32_t)wave; t * MERGE_TILE < nm; t += (uint32_t)W) {
+                const uint32_t d0 = t * MERGE_TILE, d1 = d0 + MERGE_TILE < nm ? d0 + MERGE_TILE : nm;
+                uint64_t o[MERGE_C];
+                uint32_t d, cnt, tn;
+                team_merge_tile<4, 1>(sb, KM, KX1, d0, d1, tile, lane, o, d, cnt, tn);
+#pragma unroll
+                for (uint32_t c = 0; c < MERGE_C; ++c)
+                    if (c < cnt) tile[mslot(d + c)] = o[c];
+                wave_sync();
+#pragma unroll
+                for (uint32_t c = 0; c < MERGE_C; ++c) {
+                    const uint32_t i = (uint32_t)lane + c * WAVE;
+                    if (i < tn) gst(sb, out_off + ((d0 + i) << 3), tile[mslot(i)]);
+                }
+                wave_sync();
+            }
+            team_barrier();
+            KB.adj[0] = A->sc.off_tmp;
+        } else KB.adj[0] = x_off;
+        KB.cum[1] = KB.cum[2] = KB.cum[3] = KB.n = KM.n + nx;
+        KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
+    }
+    // ---- stays + the rest, merged tile by tile into the waves' staging and walked there by the leader, W tiles at a time
+    const KeyArr<1> KA = ka_single(str_off, scnt[0]);
+    const uint32_t nk = KA.n + KB.n;            // == n
+    const WalkConst<true> C = walk_const<true>(A, sb);
+    WalkState<true> S;
+    S.n_seedp = ctx_get(s_w.n_seedp);
+    const uint32_t kl = A->ix.key_len_bits;
+    const float source_prob = C.source_prob;
+    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+    const UNC_AS_GLOBAL uint64_t *const infow = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);
+    uint64_t pend_key = 0;
+    bool have_pend = false, bad = false;
+    for (uint32_t g0 = 0; g0 * MERGE_TILE < nk; g0 += (uint32_t)W) {
+        const uint32_t t = g0 + (uint32_t)wave;
+        if (t * MERGE_TILE < nk) {
+            const uint32_t d0 = t * MERGE_TILE, d1 = d0 + MERGE_TILE < nk ? d0 + MERGE_TILE : nk;
+            uint64_t o[MERGE_C];
+            uint32_t d, cnt, tn;
+            team_merge_tile<1, 4>(sb, KA, KB, d0, d1, tile, lane, o, d, cnt, tn);
+            {   // the tile must come out ascending (its place after the tile before it is the leader's to check)
+                uint64_t last = o[0];
+                bool w = false;
+#pragma unroll
+                for (uint32_t c = 1; c < MERGE_C; ++c)
+                    if (c < cnt) { w = w || !(o[c] > last); last = o[c]; }
+                const uint64_t pl = (uint64_t)__shfl_up((unsigned long long)last, 1);
+                if (lane > 0 && cnt > 0 && !(o[0] > pl)) w = true;
+                if (__any(w) && lane == 0) atomicOr(&s_team_bad, 1u);
+            }
+            // sorted tile at logical positions 1 .. tn (0: the key that waits for its successor, the leader's to fill)
+#pragma unroll
+            for (uint32_t c = 0; c < MERGE_C; ++c)
+                if (c < cnt) tile[mslot(1u + d + c)] = o[c];
+            if (lane == 0) s_team_v[wave] = tn;
+        }
+        team_barrier();
+        if (wave == 0) {
+            for (uint32_t w = 0; w < (uint32_t)W && (g0 + w) * MERGE_TILE < nk; ++w) {
+                uint64_t *const wt = team_stage((int)w);
+                const uint32_t tn = uniform32(s_team_v[w]);
+                const bool last_tile = (g0 + w + 1u) * MERGE_TILE >= nk;
+                if (have_pend) {
+                    if (lane == 0) wt[mslot(0)] = pend_key;
+                    if (!(uniform64(wt[mslot(1)]) > pend_key)) bad = true;
+                }
+                wave_sync();
+                const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
+                uint64_t bq0 = 0, bq1 = 0;
+                {
+                    const uint32_t pa = p0 + (uint32_t)lane, pb = pa + WAVE;
+                    if (pa <= tn) bq0 = infow[wt[mslot(pa)] & 0xFFFFu];
+                    if (pb <= tn) bq1 = infow[wt[mslot(pb)] & 0xFFFFu];
+                }
+                ulonglong2 krq = make_ulonglong2(1ull, 0ull);
+                if (p0 + (uint32_t)lane < p1) {
+                    const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
+                    if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+                }
+                for (uint32_t base = p0; base < p1; base += WAVE) {
+                    const uint32_t p = base + (uint32_t)lane;
+                    const bool have = p < p1;
+                    const bool has_next = have && p < tn;
+                    const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+                    const uint64_t ki = have ? wt[mslot(p)] : ~0ull, kn = has_next ? wt[mslot(p + 1u)] : ~0ull;
+                    const uint64_t bi = bq0;
+                    uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
+                    const uint64_t bf = bcast64(bq1, 0);
+                    if (lane == WAVE - 1) bn = bf;
+                    bq0 = bq1;
+                    const ulonglong2 krc = krq;
+                    krq = make_ulonglong2(1ull, 0ull);
+                    if (p + WAVE < p1) {
+                        const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
+                        if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+                    }
+                    uint32_t start, end, nstart, kmer, nkmer;
+                    uint64_t sbw;
+                    bool dup;
+                    walk_decode_narrow<true>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
+                    walk_core<true>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, true, krc, nv, lane);
+                    bq1 = p + 2 * WAVE <= tn ? infow[wt[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
+                }
+                pend_key = uniform64(wt[mslot(tn)]);
+                have_pend = true;
+                wave_sync();
+            }
+        }
+        team_barrier();
+    }
+    if (wave == 0) {
+        if ((bad || uniform32(s_team_bad)) && lane == 0) s_w.tstatus |= UNC_READ_SORT_FAULT;
+        walk_finish<true>(C, S, lane);
+        CTX_SET(kl, kl);
+        CTX_SET(walked, 1u);
+        wave_sync();
+    }
+    return true;
 }
 
 // The chunked path with a team of W wavefronts per channel (workgroup b = chunk descriptor b, slot = slot_map[b]; see the one-wavefront
@@ -1962,7 +2215,7 @@ __global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
         c_nbr += phase_E_team<PROF, NARROW, W>(A, sb, lane, wave, TT);
         team_barrier();
         if (lead) {
-            clk.end(1, lane);
+            clk.reset();          // (phase E keeps its own clock: parts 8..11, the children in 1)
             const uint32_t fl = uniform32(s_team_flags);
             const unsigned long long nbr_f = s_team_nbr;
             uint32_t n_seedp = TT.n_seedp, tst = 0;
@@ -1971,12 +2224,21 @@ __global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
                 s_w.nchild = TT.nchild; s_w.n_seedp = n_seedp; s_w.bchild = fl & 1u; s_w.tstatus |= tst; s_w.par_unsorted = (fl >> 1) & 1u;
                 s_w.scnt[0] = TT.scnt[0]; s_w.scnt[1] = TT.scnt[1]; s_w.scnt[2] = TT.scnt[2]; s_w.scnt[3] = TT.scnt[3]; s_w.scnt[4] = TT.scnt[4];
                 s_w.scnt[5] = TT.scntx;
+                s_w.walked = 0u;
                 s_team_flags = 0; s_team_nbr = 0ull;
                 c_nbr += nbr_f;
             }
             wave_sync();
             clk.reset();
-            if (ctx_get(s_w.nchild) > 0) {
+        }
+        bool team_sorted = false;
+        if constexpr (NARROW) {
+            team_barrier();       // (the event's counts are in the context: every wave decides alike whether the sort is the team's)
+            team_sorted = phase_S_team<W>(A, sb, lane, wave);
+            if (lead && team_sorted) clk.end(2, lane);
+        }
+        if (lead) {
+            if (ctx_get(s_w.nchild) > 0 && !team_sorted) {
                 phase_S<NARROW>(A, sb, lane);
                 clk.end(2, lane);
                 if (!ctx_get(s_w.walked)) phase_W<NARROW>(A, sb, lane);
