@@ -1758,20 +1758,36 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         team_barrier();
         if (wave == 0) clk.end(11, lane);
         // ---- what the waves before this one counted; the round's totals
+        // (lane l < W looks at wave l's counts, packed three words wide -- no field can overflow into its neighbour: 8 passes hold at
+        // most 2 560 children and 512 keys per run -- and an inclusive prefix over those lanes gives every wave its bases and the totals)
         uint32_t b_child = TT.nchild, b_seed = TT.n_seedp, b_x = TT.scntx, b_m[5];
-        uint32_t r_child = 0, r_seed = 0, r_x = 0, r_m[5] = {0, 0, 0, 0, 0};
-        uint64_t prev_last = TT.run_last, round_last = 0;
+        uint32_t r_child, r_seed, r_x, r_m[5];
+        uint64_t prev_last = TT.run_last, round_last;
+        {
+            const TeamCnt c = s_team_cnt[rnd & 1u][(uint32_t)lane < (uint32_t)W ? lane : 0];
+            const bool mine = (uint32_t)lane < (uint32_t)W;
+            uint32_t q0 = mine ? (c.chtot | (c.xtot << 16)) : 0u;
+            uint32_t q1 = mine ? (c.m[0] | (c.m[1] << 10) | (c.m[2] << 20)) : 0u;
+            uint32_t q2 = mine ? (c.m[3] | (c.m[4] << 10) | (c.ecnt << 20)) : 0u;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) b_m[t] = TT.scnt[t];
+            for (int d = 1; d < W; d <<= 1) {
+                const uint32_t y0 = (uint32_t)__shfl_up((int)q0, d), y1 = (uint32_t)__shfl_up((int)q1, d), y2 = (uint32_t)__shfl_up((int)q2, d);
+                if (lane >= d) { q0 += y0; q1 += y1; q2 += y2; }
+            }
+            const uint32_t t0 = lane_get32(q0, (uint32_t)W - 1u), t1 = lane_get32(q1, (uint32_t)W - 1u), t2 = lane_get32(q2, (uint32_t)W - 1u);
+            r_child = t0 & 0xFFFFu; r_x = t0 >> 16;
+            r_m[0] = t1 & 1023u; r_m[1] = (t1 >> 10) & 1023u; r_m[2] = t1 >> 20;
+            r_m[3] = t2 & 1023u; r_m[4] = (t2 >> 10) & 1023u; r_seed = t2 >> 20;
+            round_last = lane_get64(c.last_pk, (uint32_t)W - 1u);
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const TeamCnt c = s_team_cnt[rnd & 1u][w];
-            const uint32_t ct = uniform32(c.chtot), cx = uniform32(c.xtot), ce = uniform32(c.ecnt);
-            if (w < wave) { b_child += ct; b_seed += ce; b_x += cx; prev_last = uniform64(c.last_pk); }
-            r_child += ct; r_seed += ce; r_x += cx;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) { const uint32_t v = uniform32(c.m[t]); if (w < wave) b_m[t] += v; r_m[t] += v; }
-            if (w == W - 1) round_last = uniform64(c.last_pk);
+            for (int t = 0; t < 5; ++t) b_m[t] = TT.scnt[t];
+            if (wave > 0) {
+                const uint32_t e0 = lane_get32(q0, (uint32_t)wave - 1u), e1 = lane_get32(q1, (uint32_t)wave - 1u), e2 = lane_get32(q2, (uint32_t)wave - 1u);
+                b_child += e0 & 0xFFFFu; b_x += e0 >> 16;
+                b_m[0] += e1 & 1023u; b_m[1] += (e1 >> 10) & 1023u; b_m[2] += e1 >> 20;
+                b_m[3] += e2 & 1023u; b_m[4] += (e2 >> 10) & 1023u; b_seed += e2 >> 20;
+                prev_last = lane_get64(c.last_pk, (uint32_t)wave - 1u);
+            }
         }
         if constexpr (NARROW) { if (base < n_surv_par && !(first_pk > prev_last)) par_bad = true; }
         const bool cut = TT.nchild + r_child > max_paths;         // (the same for every wave)
