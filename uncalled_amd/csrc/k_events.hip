@@ -329,14 +329,18 @@ __device__ __forceinline__ uint32_t roll_unread(uint32_t n, uint32_t rd, uint32_
     return rd < wr ? wr - rd : (n - rd) + wr;   // Normalizer::unread_size, normalizer.cpp:131-134
 }
 
+// lanes_per_wave: how many lanes of a wavefront follow a channel.  The lanes of a wavefront are different channels in different
+// detector states, so whenever ANY of them closes an event the whole wavefront walks the event path (event, profiler window, rolling
+// normaliser: two thirds of an iteration's instructions); with 64 channels per wavefront that is every sample.  A flow cell's 512
+// channels do not fill the chip anyway: one channel per wavefront pays the event path on one sample in nine.
 __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans,
                                                   float *norm_ring, unc_params_t P, float tgt_mean, float tgt_stdv,
-                                                  unc_evt_info_t *info, uint32_t *ring0_out) {
+                                                  unc_evt_info_t *info, uint32_t *ring0_out, uint32_t lanes_per_wave) {
     __shared__ double s_sum[RING * WAVE];
     __shared__ double s_sumsq[RING * WAVE];
     const int lane = lane_id();
-    const uint32_t ci = blockIdx.x * WAVE + lane;
-    if (ci >= n_chunks) return;   // no collectives in this kernel
+    const uint32_t ci = blockIdx.x * lanes_per_wave + (uint32_t)lane;
+    if ((uint32_t)lane >= lanes_per_wave || ci >= n_chunks) return;   // no collectives in this kernel
     const RtChunkDesc cd = chunks[ci];
     RtChan *C = chans + cd.channel;
     float *ring = norm_ring + (size_t)cd.channel * NORM_LEN;
@@ -466,8 +470,12 @@ __global__ __launch_bounds__(64) void k_rt_events(const int16_t *raw, const floa
 namespace unc {
 void launch_rt_events(const int16_t *raw, const float *raw_pa, const RtChunkDesc *chunks, uint32_t n_chunks, RtChan *chans, float *norm_ring,
                       const unc_params_t &P, float tgt_mean, float tgt_stdv, unc_evt_info_t *info, uint32_t *ring0_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + WAVE - 1) / WAVE), dim3(WAVE), 0, st, raw, raw_pa, chunks, n_chunks, chans, norm_ring, P,
-                       tgt_mean, tgt_stdv, info, ring0_out);
+    // as few channels per wavefront as a grid of 2048 wavefronts allows (512 channels: one each)
+    uint32_t lpw = (n_chunks + 2047u) / 2048u;
+    if (lpw < 1u) lpw = 1u;
+    if (lpw > (uint32_t)WAVE) lpw = WAVE;
+    hipLaunchKernelGGL(k_rt_events, dim3((n_chunks + lpw - 1) / lpw), dim3(WAVE), 0, st, raw, raw_pa, chunks, n_chunks, chans, norm_ring, P,
+                       tgt_mean, tgt_stdv, info, ring0_out, lpw);
 }
 void launch_events(const DevReads &rd, const unc_params_t &P, hipStream_t st, uint32_t reads_per_wave) {
     if (reads_per_wave == 0 || reads_per_wave > (uint32_t)WAVE) reads_per_wave = WAVE;
