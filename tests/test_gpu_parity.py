@@ -205,3 +205,10 @@ def test_big_forests(hip_lib, oracle_lib, example, goldens, tmp_path, monkeypatc
 def test_chunked_mid_reference_team_sort(hip_lib, oracle_lib, tmp_path, monkeypatch, team):
     monkeypatch.setenv("UNC_RT_TEAM", str(team))
     pc.case_chunked_mid_reference(hip_lib, oracle_lib, tmp_path, n=4, cut=8000)
+
+
+@pytest.mark.parametrize("team", [8, 2])
+def test_team_round_that_fills_the_buffer_exactly(hip_lib, team):
+    from pathlib import Path
+    from tests.test_lanesim_parity import _fuzz_round
+    _fuzz_round(Path(__file__).resolve().parents[1] / "uncalled_amd" / "libuncalled_hip.so", 9512, "rt", team)

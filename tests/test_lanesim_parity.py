@@ -130,3 +130,28 @@ def test_merge_walk_mid_reference(sim_lib, oracle_lib, tmp_path):
 def test_chunked_mid_reference_team_sort(sim_lib, oracle_lib, tmp_path, monkeypatch, team, n):
     monkeypatch.setenv("UNC_RT_TEAM", str(team))
     pc.case_chunked_mid_reference(sim_lib, oracle_lib, tmp_path, n=n, cut=2600, chunk_len=2000, n_channels=1)     # (4 reads of 8000 samples on the GPU)
+
+
+def _fuzz_round(lib_path, seed, mode, team):
+    """one seeded round of tests/dev/fuzz_parity.py in a process of its own (it loads the library named by UNC_FUZZ_LIB)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, UNC_RT_TEAM=str(team))
+    if lib_path:
+        env["UNC_FUZZ_LIB"] = str(lib_path)
+    r = subprocess.run([sys.executable, str(root / "tests" / "dev" / "fuzz_parity.py"), "1", str(seed), mode], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=str(root))
+    assert r.returncode == 0 and "device == oracle" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
+def test_team_round_that_fills_the_buffer_exactly(sim_lib):
+    """Found by the seeded chunked fuzz run on teams of 8 (round 4, seed 9512: max_paths 60): a round of the team's phase E whose
+    children fill the path buffer EXACTLY cuts no child, yet the parents behind the last child are not reached any more
+    (mapper.cpp:521-523) -- their dead-end seeds had been counted into the totals the waves publish, and one SA look-up too many
+    followed.  The round now exchanges the kept counts like any round that hits the cut-off."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    _fuzz_round(root / "tests" / "lanesim" / "_build" / "libuncalled_sim.so", 9512, "rt", 2)

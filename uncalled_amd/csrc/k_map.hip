@@ -1790,7 +1790,10 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             }
         }
         if constexpr (NARROW) { if (base < n_surv_par && !(first_pk > prev_last)) par_bad = true; }
-        const bool cut = TT.nchild + r_child > max_paths;         // (the same for every wave)
+        // the buffer fills in this round (the same for every wave).  ">=": a round that fills it EXACTLY cuts no child, but the parents
+        // behind the last child are not reached any more (mapper.cpp:521-523) -- their dead-end seeds were counted into the published
+        // totals and must not stay there (seeded fuzz run, seed 9512: one SA look-up too many)
+        const bool cut = TT.nchild + r_child >= max_paths;
         const uint32_t room = b_child >= max_paths ? 0u : max_paths - b_child;
         const uint32_t nwrite = chtot < room ? chtot : room;
         const bool visited = have && choff < room;
