@@ -724,8 +724,11 @@ def main():
                     sec[w] = r
                     log(f"secondary {w}: {r['value']:.0f} ms per round (p95 {r['config']['latency_ms']['p95']:.0f})")
                     continue
+                # one untimed step over the WHOLE batch, then one timed step.  (Rounds 2-3 warmed up on 8 192 reads: the first launch
+                # that touches all of a 120 GB node pool and 48 GB of slots is 15-20 % slower than the next one -- GRCh38, same
+                # process: 29.1 s then 23.6 s -- and was the one that got timed.)
                 r = run_workload(a, w, a_reads(a, w), 1, 1, rank, world, local_rank, dist, barrier, cache, lib,
-                                 dev_name, extras, 0.0 if a.no_cpu_baseline else 60.0, warmup_reads=8192)
+                                 dev_name, extras, 0.0 if a.no_cpu_baseline else 60.0)
                 r = {k: v for k, v in r.items() if k != "dt"}
                 r["unit"] = "reads/s"
                 r["n_gpus"] = world
