@@ -224,7 +224,7 @@ def case_parameter_variants(lib, oracle_lib, example, goldens, n=6):
 
 def case_narrow_buckets(lib, oracle_lib, example, goldens, monkeypatch, shift=4):
     """The seed-cluster grid with buckets of 2^shift rows instead of 2^12: on the 20 k-row example index a seed's window then
-    spans hundreds of buckets (add_seed's gather runs in several rounds of WIN_BUCKETS), clusters move from bucket to bucket as
+    spans hundreds of buckets (the lane that adds a seed walks them one after the other), clusters move from bucket to bucket as
     they grow, and every bucket holds a cluster or none -- per event against the oracle's set, then a batch."""
     monkeypatch.setenv("UNC_BUCKET_SHIFT", str(shift))
     ix = capi.Index(example["prefix"], lib=lib)

@@ -55,7 +55,7 @@ constexpr int KEYB_MOVES_SHIFT = 11;     // 5 bits: popcount(event_moves_)
 struct alignas(8) SeedPath { uint64_t start; uint32_t count; uint32_t evt; uint32_t ref_len; uint32_t pad; };
 
 // SeedTracker state (seed_tracker.hpp:69-110): the std::set<SeedCluster> (ordered by ref_en_.start desc, evt_en_ desc) is kept per
-// read as a GRID OF BUCKETS over ref_en_.start (k_map.hip, add_seed): unordered nodes of NODE_K clusters chained from a per-read
+// read as a GRID OF BUCKETS over ref_en_.start (map_tracker.h, add_seeds): unordered nodes of NODE_K clusters chained from a per-read
 // table of bucket heads.  A cluster = a hot key of 16 bytes (all the scan of add_seed reads: ref_en_.start, evt_en_, total_len_) + a
 // cold part of 32 bytes (what a merge needs on top: ref_st_, ref_en_.end, evt_st_).
 //   node  = header 16 B (count, next node + 1) | NODE_K hot keys | NODE_K cold parts, padded to a multiple of 128 bytes
@@ -71,8 +71,9 @@ constexpr uint32_t POOL_CHUNK_BYTES = 192u << 10;      // 768 nodes of 256 bytes
 constexpr uint32_t NODE_K = UNC_NODE_K;
 constexpr uint32_t NODE_BYTES = (16 + NODE_K * 48 + 127) / 128 * 128;      // 256 (384 for 7 clusters, 512 for 10)
 constexpr uint32_t CHUNK_NODES = POOL_CHUNK_BYTES / NODE_BYTES;
-constexpr uint32_t WIN_BUCKETS = 64 / NODE_K;          // buckets whose nodes one wavefront looks at together (12 x 5 = 60 lanes)
-constexpr uint32_t BUCKET_SHIFT_MIN = WIN_BUCKETS >= 9 ? 12 : WIN_BUCKETS >= 5 ? 13 : 14;   // a window of 2^15 rows fits WIN_BUCKETS
+// the narrowest bucket: 2^12 rows.  A seed's window of `event` rows then spans at most 9 buckets with the default max_events; the lane
+// that adds the seed walks them one after the other (map_tracker.h), and wider buckets make more seeds of an event wait for each other
+constexpr uint32_t BUCKET_SHIFT_MIN = 12;
 static_assert(CHUNK_NODES * NODE_BYTES == POOL_CHUNK_BYTES, "node layout");
 
 struct ClusterVal { uint64_t ref_st, rstart, rend; uint32_t evt_st, evt_en, total_len; };
