@@ -12,6 +12,49 @@ GOLD = ROOT / "tests" / "golden"
 EX_PREFIX = GOLD / "example_index" / "example_ref"
 
 
+def build_lock():
+    """Builds of test infrastructure (oracle, emulator library, host module) are serialised across the workers of a parallel run:
+    the first worker builds, the others find the targets up to date."""
+    import contextlib
+    import fcntl
+
+    @contextlib.contextmanager
+    def _lock():
+        with open(ROOT / "tests" / ".build.lock", "w") as fh:
+            fcntl.flock(fh, fcntl.LOCK_EX)
+            try:
+                yield
+            finally:
+                fcntl.flock(fh, fcntl.LOCK_UN)
+    return _lock()
+
+
+def locked_make(*args):
+    with build_lock():
+        subprocess.run(["make", "-s", *args], check=True)
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite is mostly the kernel sources under the emulator, one fiber set per test and single-threaded: without a GPU
+    (and unless the command line or UNC_TEST_WORKERS says otherwise) the tests are spread over worker processes (pytest-xdist),
+    13 minutes -> 3 on 8 cores.  The GPU suite stays in ONE process: its tests time kernels and share the device."""
+    import os
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
+        return None
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return None
+    want = os.environ.get("UNC_TEST_WORKERS")
+    n = int(want) if want is not None else max(0, min(6, (os.cpu_count() or 1) - 2))
+    if n < 2 or _has_gpu():
+        return None
+    config.option.numprocesses = n
+    config.option.dist = "load"
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "lanesim: runs the HIP kernel sources under the CPU SIMT emulator")
@@ -39,7 +82,7 @@ def oracle_lib():
     """TEST INFRASTRUCTURE: the plain-C restatement (builds on demand)."""
     from oracle import pyoracle
     if not pyoracle.available():
-        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "oracle"], check=True)
+        locked_make("-C", str(ROOT / "oracle"), "oracle")
     return pyoracle
 
 
@@ -50,7 +93,7 @@ def ref_lib():
     if not pyref.available():
         if not Path("/root/reference/src/mapper.cpp").exists():
             pytest.skip("reference sources not present (GPU box): oracle/_ref was not prebuilt")
-        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "ref"], check=True)
+        locked_make("-C", str(ROOT / "oracle"), "ref")
     return pyref
 
 
@@ -77,9 +120,9 @@ def sim_lib():
     os.environ.setdefault("UNC_RT_TEAM", "2")
     extra = os.environ.get("UNC_LANESIM_EXTRA")      # dev: the emulator suite over a variant build (extra -D flags)
     if extra:
-        subprocess.run(["make", "-s", "-C", str(ROOT / "tests" / "lanesim"), "OUT=_build_extra", "EXTRA=" + extra], check=True)
+        locked_make("-C", str(ROOT / "tests" / "lanesim"), "OUT=_build_extra", "EXTRA=" + extra)
         return capi.load(ROOT / "tests" / "lanesim" / "_build_extra" / "libuncalled_sim.so")
-    subprocess.run(["make", "-s", "-C", str(ROOT / "tests" / "lanesim")], check=True)
+    locked_make("-C", str(ROOT / "tests" / "lanesim"))
     return capi.load(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so")
 
 
@@ -91,7 +134,8 @@ def sim_host(sim_lib):
     import sysconfig
     import __graft_entry__ as g
     out_dir = ROOT / "tests" / "lanesim" / "_build"
-    mod = g.build_host(lib=out_dir / "libuncalled_sim.so", out_dir=out_dir)
+    with build_lock():
+        mod = g.build_host(lib=out_dir / "libuncalled_sim.so", out_dir=out_dir)
     assert mod.name == "_uncalled_amd" + sysconfig.get_config_var("EXT_SUFFIX")
     spec = importlib.util.spec_from_file_location("_uncalled_amd", mod)
     m = importlib.util.module_from_spec(spec)

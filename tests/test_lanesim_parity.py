@@ -110,11 +110,11 @@ def test_big_forests(sim_lib, oracle_lib, example, goldens, tmp_path, monkeypatc
 def sim_lib_norepair():
     """The emulator library built with UNC_MERGE_REPAIR=0: the runs of child keys reach the merge with their out-of-order
     pairs still in them, so the merge's own check has to notice and send the event through the bitonic network."""
-    import subprocess
     from pathlib import Path
     from uncalled_amd import capi
+    from conftest import locked_make
     root = Path(__file__).resolve().parents[1]
-    subprocess.run(["make", "-s", "-C", str(root / "tests" / "lanesim"), "OUT=_build_norepair", "EXTRA=-DUNC_MERGE_REPAIR=0"], check=True)
+    locked_make("-C", str(root / "tests" / "lanesim"), "OUT=_build_norepair", "EXTRA=-DUNC_MERGE_REPAIR=0")
     return capi.load(root / "tests" / "lanesim" / "_build_norepair" / "libuncalled_sim.so")
 
 
