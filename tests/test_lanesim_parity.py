@@ -28,7 +28,7 @@ def test_example_read_full_path(sim_lib, oracle_lib, example, goldens):
     pc.case_example_read_full_path(sim_lib, oracle_lib, example, goldens)
 
 
-@pytest.mark.parametrize("max_paths,n_reads", [(10000, 6), (97, 6)])     # ((300, 8) too on the GPU; 300 here in the sliced case)
+@pytest.mark.parametrize("max_paths,n_reads", [(10000, 6), (97, 6), (300, 8)])
 def test_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads):
     pc.case_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads)
 
@@ -55,7 +55,7 @@ def test_chunked_team_sizes(sim_lib, oracle_lib, example, goldens, monkeypatch, 
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, 2, 3, None)
 
 
-@pytest.mark.parametrize("shift", [4])          # (8 as well on the GPU)
+@pytest.mark.parametrize("shift", [4, 8])
 def test_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift):
     pc.case_narrow_buckets(sim_lib, oracle_lib, example, goldens, monkeypatch, shift)
 
@@ -126,7 +126,7 @@ def test_merge_walk_mid_reference(sim_lib, oracle_lib, tmp_path):
     pc.case_mid_reference(sim_lib, oracle_lib, tmp_path, n=2, cut=6000)          # (3 reads of 8000 samples on the GPU)
 
 
-@pytest.mark.parametrize("team,n", [(2, 2)])       # (teams of 8 / 4 / 2 / 1 on the GPU; a team of 8 here costs another minute of emulation)
+@pytest.mark.parametrize("team,n", [(2, 2), (4, 2), (8, 2)])       # (1 as well on the GPU; a team of 8 is two minutes of emulation)
 def test_chunked_mid_reference_team_sort(sim_lib, oracle_lib, tmp_path, monkeypatch, team, n):
     monkeypatch.setenv("UNC_RT_TEAM", str(team))
     pc.case_chunked_mid_reference(sim_lib, oracle_lib, tmp_path, n=n, cut=2600, chunk_len=2000, n_channels=1)     # (4 reads of 8000 samples on the GPU)
