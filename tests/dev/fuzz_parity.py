@@ -4,7 +4,8 @@
 around the defaults, random mapper geometry (slots, slice length, wavefronts, tiny pools).  Everything is seeded: a failure
 prints the seed that reproduces it.
 
-    python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path; wide: the batch path with 128-bit sort keys)"""
+    python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path; wide: the batch path with 128-bit sort keys;
+                                                                         t1: the batch path in UNC_ORDER_T1 with path buffers small enough to leak flags)"""
 import sys
 import tempfile
 import time
@@ -96,6 +97,37 @@ def rt_round(seed, dix, oix, codes, lens):
     return n, f"{n_ch} channels, chunks of {chunk_len}, max_chunks {max_chunks}, max_paths {p.max_paths}"
 
 
+def t1_round(seed, dix, oix, codes, lens):
+    """`uncalled map -t 1`: ONE mapper, the reads back to back in random batch splits, path buffers small enough that reads leave
+    sources_added_ flags behind; against the oracle's shared Mapper.  Counts the reads the carry-over changed."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 9))
+    sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1200)), off_target=float(rng.choice([0.0, 0.3])),
+                         dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))
+    p = draw_params(rng)
+    p.max_paths = int(rng.choice([40, 60, 97, 130, 200, 400]))
+    n_waves = int(rng.integers(1, 3))
+    kw = dict(n_waves=n_waves, n_slots=n_waves * int(rng.integers(1, 4)), slice_events=int(rng.choice([0, 13, 64, 1024])))
+    raw, off = sim["signal"], sim["offsets"]
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    want = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=False)
+    indep = oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True)
+    changed = sum(1 for i in range(n) if any(int(want[i][f]) != int(indep[i][f]) for f in ("event_i", "n_nbr", "n_sa", "mapped", "rf_st")))
+    m = capi.Mapper(dix, params=p, **kw)
+    m.set_read_order(capi.ORDER_T1)
+    cuts = sorted(set(int(c) for c in rng.integers(1, n, size=int(rng.integers(0, 3)))))
+    got, again, lo = [], 0, 0
+    for hi in cuts + [n]:
+        if hi == lo:
+            continue
+        b_off = (off[lo:hi + 1] - off[lo]).astype(np.uint64)
+        got.append(m.map_batch(raw[int(off[lo]):int(off[hi])], b_off, cal[lo:hi]))
+        again += m.last_carry_over()[0]
+        lo = hi
+    assert_hits_equal(np.concatenate(got), want, f"seed {seed}, -t 1 order")
+    return n, f"{kw}, max_paths {p.max_paths}, batches cut at {cuts}, carry-over changes {changed} reads, {again} mapped again"
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -113,11 +145,12 @@ def main():
             seed = seed0 + k
             rng = np.random.default_rng(seed)
             dix, oix, codes, lens = idx[int(rng.integers(0, len(idx)))]
-            if rt:
+            t1 = len(sys.argv) > 3 and sys.argv[3] == "t1"
+            if rt or t1:
                 try:
-                    n, what = rt_round(seed, dix, oix, codes, lens)
+                    n, what = (rt_round if rt else t1_round)(seed, dix, oix, codes, lens)
                 except Exception as e:
-                    print(f"FAILED (chunked path) at seed {seed}: {e!r}"[:700], flush=True)
+                    print(f"FAILED ({'chunked path' if rt else '-t 1 order'}) at seed {seed}: {e!r}"[:700], flush=True)
                     return 1
                 n_reads_total += n
                 print(f"seed {seed}: {n} reads ok ({what}) [{time.time() - t0:.0f} s]", flush=True)
