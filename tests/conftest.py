@@ -68,9 +68,15 @@ def _has_gpu():
         return False
 
 
+# the longest emulator cases (a minute or two each): started first, so that a parallel run does not end on one of them alone
+SLOW_FIRST = ("test_chunked_mid_reference_team_sort", "test_chunked_stage_tap", "test_matches_small_builder_on_repeats",
+              "test_chunked_realtime_path", "test_cluster_pool_pressure", "test_narrow_buckets", "test_parameter_variants")
+
+
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
         return
+    items.sort(key=lambda it: 0 if it.name.split("[")[0] in SLOW_FIRST else 1)      # (stable: the rest keeps its order)
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
         if "gpu" in it.keywords:
