@@ -35,6 +35,15 @@ def refs(tmp):
     build_from_codes(pre, n2, [""] * 3, l2, c2)
     Path(str(pre) + ".uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
     out.append((pre, c2, l2))
+    if os.environ.get("UNC_FUZZ_MID"):
+        # UNC_FUZZ_MID=1: ONLY a mid-sized reference with permissive thresholds (tests/parity_cases.py:case_mid_reference) -- events of
+        # hundreds of children, so that every round goes through the runs-and-merge sort (and, chunked, the team's own sort) instead
+        # of the network the small references mostly take.  Ten times slower per round.
+        n3, l3, c3 = synthetic_genome(1, 800000, seed=11)
+        pre3 = Path(tmp) / "mid"
+        build_from_codes(pre3, n3, [""], l3, c3)
+        Path(str(pre3) + ".uncl").write_text("default\t-10.07,-5.5,-5.0,-4.6,-4.3,-4.1\t0.3\t115.000\n")
+        return [(pre3, c3, l3)]
     return out
 
 
