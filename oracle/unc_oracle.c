@@ -1243,6 +1243,9 @@ int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_
     h->n_events = m->evdt.total_events;
     h->event_i = m->event_i;
     h->mean_event_len = m->evdt.total_events ? evdt_mean_event_len(&m->evdt) : 0.0f;
+    /* (as in unc_o_trace_finish: what this read leaves set is what the channel's next read starts with) */
+    for (uint32_t k = 0; k < UNC_O_NKMER; ++k)
+        if (m->sources_added[k]) { h->notes |= UNC_O_NOTE_FLAGS_LEFT; break; }
     minibwa_counters_t c1;
     minibwa_counters_get(&c1);
     h->n_nbr = c1.n_2occ - m->c0.n_2occ;

@@ -101,7 +101,7 @@ def rt_round(seed, dix, oix, codes, lens):
         h, o = got[i]["hit"], want[i]
         assert int(h["status"]) == 0, (i, int(h["status"]))
         assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), (i, capi.hit_paf_cols(h, names), po.hit_paf_cols(o, oix.ref_names()))
-        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f, int(h[f]), int(o[f]))
     return n, f"{n_ch} channels, chunks of {chunk_len}, max_chunks {max_chunks}, max_paths {p.max_paths}"
 

@@ -313,7 +313,7 @@ def case_chunked_variants(lib, oracle_lib, example, goldens, n_channels=2, n_rea
             h, o = got[i]["hit"], want[i]
             assert int(h["status"]) == 0
             assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), (ov, chunk_len, i)
-            for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+            for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
                 assert int(h[f]) == int(o[f]), (ov, chunk_len, i, f)
             assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), (ov, chunk_len, i)
 
@@ -441,7 +441,7 @@ def case_chunked_flags_carry_over(lib, oracle_lib, tmp_path):
     names_dev = ix.seq_names()
     for i in range(n):
         assert capi.hit_paf_cols(got[i], names_dev) == po.hit_paf_cols(want[i], oix.ref_names()), i
-        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(got[i][f]) == int(want[i][f]), (i, f)
     assert any(int(want[i]["n_nbr"]) != int(alone[i]["n_nbr"]) or int(want[i]["event_i"]) != int(alone[i]["event_i"]) for i in range(1, n))
 
@@ -488,7 +488,7 @@ def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, 
         h, o = got[i]["hit"], want[i]
         assert int(h["status"]) == 0
         assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), i
-        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f)
         assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), i
     if long_read:
@@ -661,6 +661,6 @@ def case_chunked_mid_reference(lib, oracle_lib, tmp_path, n=2, genome=800000, cu
         h, o = got[i]["hit"], want[i]
         assert int(h["status"]) == 0
         assert capi.hit_paf_cols(h, names_dev) == po.hit_paf_cols(o, oix.ref_names()), i
-        for f in ("event_i", "n_nbr", "n_sa", "n_lf"):
+        for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f)
     assert max(int(want[i]["n_nbr"]) / max(int(want[i]["event_i"]), 1) for i in range(n)) > 300      # events well past the merge threshold

@@ -1431,10 +1431,19 @@ extern "C" int unc_rt_tap_channel(unc_rt_t *rt, uint32_t channel, unc_rt_tap_t *
     return UNC_OK;
 }
 
-static void rt_unmapped(const unc_rt *rt, const RtHostChan &hc, const SlotState &s, const unc_evt_info_t *inf, unc_hit_t *h) {
+// unc_hit_t::notes of a channel's read: what the kernel has noted so far (path buffer full) and, once the read has ENDED -- by the
+// kernel's decision or by the host's (max_chunks, last chunk) --, whether sources_added_ flags are left for the channel's next read
+static uint32_t rt_notes(const SlotState &s, bool ended) {
+    uint32_t notes = s.notes;
+    if (ended)
+        for (uint32_t w : s.sources_added) if (w) { notes |= UNC_NOTE_FLAGS_LEFT; break; }
+    return notes;
+}
+
+static void rt_unmapped(const unc_rt *rt, const RtHostChan &hc, const SlotState &s, const unc_evt_info_t *inf, unc_hit_t *h, bool ended = true) {
     DevResult res;
     memset(&res, 0, sizeof res);
-    res.done = 2; res.status = s.status; res.event_i = s.event_i;
+    res.done = 2; res.status = s.status; res.event_i = s.event_i; res.notes = rt_notes(s, ended);
     res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
     unc_evt_info_t z;
     memset(&z, 0, sizeof z);
@@ -1560,6 +1569,7 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
             DevResult res;
             memset(&res, 0, sizeof res);
             res.done = 1; res.event_i = s.event_i; res.cluster = s.max_map; res.n_nbr = s.n_nbr; res.n_sa = s.n_sa; res.n_lf = s.n_lf;
+            res.notes = rt_notes(s, true);
             fill_hit(rt->ix, rt->P, res, inf, hc.raw_len, &results[i].hit);
             results[i].state = UNC_RT_MAPPED;
             hc.state = 0;
@@ -1577,7 +1587,7 @@ static int rt_process(unc_rt_t *rt, uint32_t n_chunks, const unc_rt_chunk_t *chu
             hc.state = 0;
         } else {
             results[i].state = UNC_RT_MAPPING;
-            rt_unmapped(rt, hc, s, &inf, &results[i].hit);                  // progress so far (event_i, counters)
+            rt_unmapped(rt, hc, s, &inf, &results[i].hit, false);           // progress so far (event_i, counters)
         }
         if (rt->profile && hc.state == 0) for (int k = 0; k < 12; ++k) rt->cyc_sum[k] += s.cyc[k];
     }
