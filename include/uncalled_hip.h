@@ -70,7 +70,8 @@ typedef struct { float range, offset, digitisation; } unc_calib_t;
 /* per-read notes (unc_hit_t::notes): conditions under which the reference's Mapper carries state from one read into the NEXT read
  * mapped by the same thread -- which the batch path, where every read starts from a fresh Mapper, does not reproduce (with
  * `-t N > 1` the reference's own outcome then depends on which thread gets which read).  A batch whose reads carry neither
- * note is mapped exactly as `uncalled map -t 1` maps it, whatever the order. */
+ * note is mapped exactly as `uncalled map -t 1` maps it, whatever the order.  The chunked path (unc_rt_*) reports the same two
+ * bits per read -- there a channel IS one Mapper and the carry-over is reproduced, the bits only say that it happened. */
 #define UNC_NOTE_PATHS_FULL 1u         /* after some event the path buffer held max_paths paths (mapper.cpp:480,507,521,543,577,607) */
 #define UNC_NOTE_FLAGS_LEFT 2u         /* sources_added_ flags were still set when the read ended (mapper.cpp:88,612-623) */
 
