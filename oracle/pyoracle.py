@@ -202,6 +202,13 @@ class Mapper:
         lib().unc_o_chunk_read(self.h, sig.ctypes.data, sig.size, chunk_len, hit.ctypes.data, C.byref(used))
         return hit[0], used.value
 
+    def rt_ended(self):
+        """the ENDED flag of the read chunk_read mapped last"""
+        f = lib().unc_o_rt_ended
+        f.argtypes = [C.c_void_p]
+        f.restype = C.c_int
+        return bool(f(self.h))
+
     def set_max_chunks(self, n):
         lib().unc_o_set_max_chunks(self.h, n)
 

@@ -191,6 +191,9 @@ double ref_map_batch_pool(int n_threads, uint32_t n_reads, const float *signals,
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+static int g_last_ended = 0;
+int ref_last_ended() { return g_last_ended; }      // Paf::is_ended() of the read ref_chunk_read mapped last
+
 // One read through the Mapper's chunk API the way MapPoolOrd drives it (map_pool_ord.cpp:61-112 ->
 // RealtimePool::try_add_chunk realtime_pool.cpp:112-142 -> MapperThread::run :349-358), single threaded.
 int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,
@@ -220,10 +223,16 @@ int ref_chunk_read(void *mp, const float *signal, uint32_t n, uint32_t chunk_len
         for (;;) {
             m->process_chunk();
             if (m->map_chunk()) { done = true; break; }
-            if (m->chunk_mapped()) break;
+            if (m->chunk_mapped()) {
+                // the pool's thread comes round again (MapperThread::run is a loop over its mappers) before MapPoolOrd's next update
+                // brings a chunk: a read whose chunks are used up, or that has reached max_events, is ended HERE, not on the next chunk
+                if (m->map_chunk()) done = true;
+                break;
+            }
         }
         if (done) break;
     }
+    g_last_ended = m->get_read().loc_.is_ended() ? 1 : 0;
     fill_hit(m, m->get_read().loc_, out);
     minibwa_counters_t c;
     minibwa_counters_get(&c);

@@ -73,6 +73,7 @@ double ref_map_batch_pool(int n_threads, uint32_t n_reads, const float *signals,
 int ref_chunk_read(void *m, const float *signal, uint32_t n, uint32_t chunk_len, uint32_t number, ref_hit_t *out,
                    uint32_t *chunks_used);
 void ref_set_max_chunks(uint32_t max_chunks);
+int ref_last_ended(void);          /* Paf::is_ended() of the read ref_chunk_read mapped last */
 /* stage tap of the chunked path (same layout as unc_o_rt_tap_t): Mapper::evdt_ / evt_prof_ / norm_ after ref_chunk_read */
 typedef struct {
     uint32_t det_t, det_total_events;

@@ -1205,6 +1205,8 @@ void unc_o_rt_tap(const unc_o_mapper_t *m, unc_o_rt_tap_t *out, float *ring) {
 }
 
 void unc_o_set_max_chunks(unc_o_mapper_t *m, uint32_t max_chunks) { m->max_chunks = max_chunks; }
+/* ReadBuffer::loc_.is_ended() of the read unc_o_chunk_read mapped last (Paf::ENDED, set by Mapper::map_chunk :386) */
+int unc_o_rt_ended(const unc_o_mapper_t *m) { return m->rt.ended; }
 
 /* One read on this mapper (= one channel), chunk by chunk.  chunks_used: chunks handed to the mapper. */
 int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_t chunk_len, unc_o_hit_t *out,
@@ -1230,7 +1232,12 @@ int unc_o_chunk_read(unc_o_mapper_t *m, const float *signal, uint32_t n, uint32_
         for (;;) {   /* RealtimePool::MapperThread::run, realtime_pool.cpp:349-358 */
             rt_process_chunk(m);
             if (rt_map_chunk(m)) { done = 1; break; }
-            if (rt_chunk_mapped(m)) break;
+            if (rt_chunk_mapped(m)) {
+                /* the pool's thread comes round again before the next chunk arrives: a read whose chunks are used up, or that has
+                 * reached max_events, ends here (map_chunk's first two exits), not on the next chunk */
+                if (rt_map_chunk(m)) done = 1;
+                break;
+            }
         }
         if (done) break;
     }

@@ -120,6 +120,7 @@ typedef struct {
     float prof_queue[28];
 } unc_o_rt_tap_t;
 void unc_o_rt_tap(const unc_o_mapper_t *m, unc_o_rt_tap_t *out, float *ring);
+int unc_o_rt_ended(const unc_o_mapper_t *m);      /* the last chunked read's Paf ENDED flag (mapper.cpp:386) */
 
 /* step-wise trace */
 void unc_o_trace_begin(unc_o_mapper_t *m, const float *signal, uint32_t n);

@@ -83,13 +83,14 @@ def rt_round(seed, dix, oix, codes, lens):
     oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_ch)]
     for om in oms:
         om.set_max_chunks(max_chunks)
-    want, got = {}, {}
+    want, got, used, ended = {}, {}, {}, {}
     off = sim["offsets"]
     cal = (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     for i in range(n):
         raw = sim["signal"][int(off[i]):int(off[i + 1])]
         pool.add_read(i % n_ch, i, raw, cal, key=i)
-        want[i] = oms[i % n_ch].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+        want[i], used[i] = oms[i % n_ch].chunk_read(po.calibrate(raw, *cal), chunk_len)
+        ended[i] = oms[i % n_ch].rt_ended()
     rounds = 0
     while pool.running():
         for key, r in pool.update():
@@ -103,6 +104,8 @@ def rt_round(seed, dix, oix, codes, lens):
         assert capi.hit_paf_cols(h, names) == po.hit_paf_cols(o, oix.ref_names()), (i, capi.hit_paf_cols(h, names), po.hit_paf_cols(o, oix.ref_names()))
         for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f, int(h[f]), int(o[f]))
+        assert pool.chunks_used[i] == used[i], (i, "chunks", pool.chunks_used[i], used[i])
+        assert bool(got[i]["ended"]) == ended[i], (i, "ended", int(got[i]["ended"]), ended[i])
     return n, f"{n_ch} channels, chunks of {chunk_len}, max_chunks {max_chunks}, max_paths {p.max_paths}"
 
 

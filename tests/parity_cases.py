@@ -299,10 +299,11 @@ def case_chunked_variants(lib, oracle_lib, example, goldens, n_channels=2, n_rea
         pool = MapPoolOrd(dev_index, n_channels=n_channels, params=p)
         assert pool.chunk_len == chunk_len
         oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_channels)]
-        want, got = {}, {}
+        want, got, fate = {}, {}, {}
         for i, (raw, cal) in enumerate(reads):
             pool.add_read(i % n_channels, i, raw, cal, key=i)
-            want[i] = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+            want[i], used = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)
+            fate[i] = (used, oms[i % n_channels].rt_ended())
         rounds = 0
         while pool.running():
             for key, r in pool.update():
@@ -316,6 +317,7 @@ def case_chunked_variants(lib, oracle_lib, example, goldens, n_channels=2, n_rea
             for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
                 assert int(h[f]) == int(o[f]), (ov, chunk_len, i, f)
             assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), (ov, chunk_len, i)
+            assert (pool.chunks_used[i], bool(got[i]["ended"])) == fate[i], (ov, chunk_len, i)       # chunks the read was given, Paf::ENDED
 
 
 def assert_rt_taps_equal(a, ring_a, b, ring_b, what):
@@ -471,11 +473,12 @@ def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, 
     for om in oms:
         if max_chunks:
             om.set_max_chunks(max_chunks)
-    want = {}
+    want, fate = {}, {}
     for i, (raw, cal) in enumerate(reads):
         ch = i % n_channels
         pool.add_read(ch, i, raw, cal, key=i)
-        want[i] = oms[ch].chunk_read(po.calibrate(raw, *cal), 4000)[0]
+        want[i], used = oms[ch].chunk_read(po.calibrate(raw, *cal), 4000)
+        fate[i] = (used, oms[ch].rt_ended())
     got = {}
     rounds = 0
     while pool.running():
@@ -491,6 +494,7 @@ def case_chunked_realtime_path(lib, oracle_lib, example, goldens, n_channels=3, 
         for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f)
         assert got[i]["state"] == (capi.RT_MAPPED if o["mapped"] else capi.RT_FAILED), i
+        assert (pool.chunks_used[i], bool(got[i]["ended"])) == fate[i], i        # chunks the read was given, Paf::ENDED
     if long_read:
         assert int(want[1]["event_i"]) > 6500 and not want[1]["mapped"]
     if n_channels == 1 and not max_chunks and not long_read:
@@ -645,11 +649,12 @@ def case_chunked_mid_reference(lib, oracle_lib, tmp_path, n=2, genome=800000, cu
     pool = MapPoolOrd(dev_index, n_channels=n_channels, params=p)
     oms = [po.Mapper(oix, to_oracle_params(p)) for _ in range(n_channels)]
     cal = (CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
-    want = {}
+    want, fate = {}, {}
     for i in range(n):
         raw = sim["signal"][int(off[i]):int(off[i]) + cut]
         pool.add_read(i % n_channels, i, raw, cal, key=i)
-        want[i] = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)[0]
+        want[i], used = oms[i % n_channels].chunk_read(po.calibrate(raw, *cal), chunk_len)
+        fate[i] = (used, oms[i % n_channels].rt_ended())
     got, rounds = {}, 0
     while pool.running():
         for key, r in pool.update():
@@ -663,4 +668,5 @@ def case_chunked_mid_reference(lib, oracle_lib, tmp_path, n=2, genome=800000, cu
         assert capi.hit_paf_cols(h, names_dev) == po.hit_paf_cols(o, oix.ref_names()), i
         for f in ("event_i", "n_nbr", "n_sa", "n_lf", "notes"):
             assert int(h[f]) == int(o[f]), (i, f)
+        assert (pool.chunks_used[i], bool(got[i]["ended"])) == fate[i], i
     assert max(int(want[i]["n_nbr"]) / max(int(want[i]["event_i"]), 1) for i in range(n)) > 300      # events well past the merge threshold

@@ -243,7 +243,7 @@ def test_chunked_path_matches_golden(oracle_lib, example, goldens):
         (67, 41, 67, 6948, 6977, 29, 107)
 
 
-@pytest.mark.parametrize("max_chunks", [1000000, 2])
+@pytest.mark.parametrize("max_chunks", [1000000, 2, 1])
 def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, goldens, max_chunks):
     po, pr = oracle_lib, ref_lib
     pr.init(example["prefix"])
@@ -255,6 +255,7 @@ def test_chunked_path_equals_live_reference(oracle_lib, ref_lib, example, golden
         (h, hu), (r, ru) = om.chunk_read(sig, 4000), rm.chunk_read(sig, 4000, i)
         assert po.hit_paf_cols(h, ix.ref_names()) == r.paf_cols(), i
         assert (hu, int(h["event_i"]), int(h["n_nbr"]), int(h["n_sa"]), int(h["n_lf"])) == (ru, r.event_i, r.n_nbr, r.n_sa, r.n_lf), i
+        assert om.rt_ended() == bool(pr.lib().ref_last_ended()), i          # Paf::ENDED (mapper.cpp:386)
     pr.lib().ref_set_max_chunks(1000000)
 
 

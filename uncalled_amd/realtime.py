@@ -14,6 +14,7 @@ class MapPoolOrd:
         self.chunk_len = chunk_len or int(p.chunk_time * p.sample_rate)     # ReadBuffer::PRMS.chunk_len()
         self.queues = [[] for _ in range(n_channels)]                       # channels_[ch]: (number, raw, calib, key)
         self.chunk_idx = [0] * n_channels
+        self.chunks_used = {}                                                # key -> chunks the read was given before it was decided
 
     def add_read(self, channel, number, raw_i16, calib, key=None):
         """calib = (range, offset, digitisation) of the channel; key identifies the read in the results."""
@@ -50,6 +51,7 @@ class MapPoolOrd:
             if r["state"] == capi.RT_MAPPING:
                 self.chunk_idx[ch] += 1
             else:
+                self.chunks_used[self.queues[ch][0][3]] = self.chunk_idx[ch] + 1
                 out.append((self.queues[ch][0][3], r.copy()))
                 self.queues[ch].pop(0)
                 self.chunk_idx[ch] = 0
