@@ -179,8 +179,18 @@ def main():
                 kw["max_clusters"] = int(rng.choice([8, 64]))
             cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
             try:
-                hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal)
+                tight = "pool_chunks" in kw or "max_clusters" in kw
+                hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal, allow_overflow=tight)
                 want = oracle_hits(oix, sim["signal"], sim["offsets"], cal, to_oracle_params(p), fresh_mapper_per_read=True)
+                loud = np.flatnonzero(hits["status"])
+                if loud.size:
+                    # a pool or an allowance too small for these reads even when a read has it to itself (the mid-sized reference: tens
+                    # of thousands of seeds per read): reported per read, the OTHER reads are right, and with room every read is
+                    ok = np.flatnonzero(hits["status"] == 0)
+                    assert_hits_equal(hits[ok], want[ok], f"seed {seed}, reads beside the overflowed ones")
+                    kw = {k: v for k, v in kw.items() if k not in ("pool_chunks", "max_clusters")}
+                    hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal)
+                    kw["loud_overflows_first"] = int(loud.size)
                 assert_hits_equal(hits, want, f"seed {seed}")
             except Exception as e:
                 print(f"FAILED at seed {seed}: {kw} max_paths={p.max_paths} max_events={p.max_events}: {e!r}"[:600], flush=True)
