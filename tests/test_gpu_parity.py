@@ -207,6 +207,14 @@ def test_chunked_mid_reference_team_sort(hip_lib, oracle_lib, tmp_path, monkeypa
     pc.case_chunked_mid_reference(hip_lib, oracle_lib, tmp_path, n=4, cut=8000)
 
 
+@pytest.mark.parametrize("team", [8, 1])
+def test_chunked_pool_chunks_go_back(hip_lib, oracle_lib, example, goldens, monkeypatch, team):
+    """tests/test_lanesim_parity.py: a pool of two chunks, twelve reads in a row on one channel"""
+    monkeypatch.setenv("UNC_RT_TEAM", str(team))
+    monkeypatch.setenv("UNC_RT_POOL_CHUNKS", "2")
+    pc.case_chunked_realtime_path(hip_lib, oracle_lib, example, goldens, 1, 12, None)
+
+
 @pytest.mark.parametrize("team", [8, 2])
 def test_team_round_that_fills_the_buffer_exactly(hip_lib, team):
     from pathlib import Path

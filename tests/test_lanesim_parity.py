@@ -47,6 +47,16 @@ def test_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels
     pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, n_channels, n_reads, max_chunks)
 
 
+@pytest.mark.parametrize("team", [2, 1])
+def test_chunked_pool_chunks_go_back(sim_lib, oracle_lib, example, goldens, monkeypatch, team):
+    """A channel's chunks of the node pool go back when its read is decided or replaced: six reads in a row on ONE channel with a pool
+    of two chunks (UNC_RT_POOL_CHUNKS; a read here needs one) -- a chunk that is not handed back leaves the third read dry.  (Round 4:
+    a slot state written without its node count did exactly that, and no chunked case of this suite was long enough to notice.)"""
+    monkeypatch.setenv("UNC_RT_TEAM", str(team))
+    monkeypatch.setenv("UNC_RT_POOL_CHUNKS", "2")
+    pc.case_chunked_realtime_path(sim_lib, oracle_lib, example, goldens, 1, 6, None)
+
+
 @pytest.mark.parametrize("team", [8, 4, 1])
 def test_chunked_team_sizes(sim_lib, oracle_lib, example, goldens, monkeypatch, team):
     """k_map_team with 8 and 4 wavefronts per channel, and the one-wavefront kernel (the other chunked cases of this suite run on

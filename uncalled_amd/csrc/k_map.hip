@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
                 st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
                 st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
-                st->notes = notes;        // (a decided read's final notes stay for the chunked path's host side; a new read starts from 0) st->n_alloc = T.n_alloc;
+                st->notes = notes; st->n_alloc = T.n_alloc;        // (a decided read's final notes stay for the chunked path's host side; a new read starts from 0)
                 st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = t_start;
                 if constexpr (PROF) {
                     if (sliced) { for (int i = 0; i < 12; ++i) st->cyc[i] = s_cyc[i]; }
@@ -2310,7 +2310,7 @@ __global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
         st->len_max1 = T.max1; st->len_max2 = T.max2; st->len_sum = T.len_sum;
         st->max_map.ref_st = T.mm.ref_st; st->max_map.rstart = T.mm.rstart; st->max_map.rend = T.mm.rend;
         st->max_map.evt_st = T.mm.evt_st; st->max_map.evt_en = T.mm.evt_en; st->max_map.total_len = T.mm.total_len;
-        st->notes = notes;        // (a decided read's final notes stay for the chunked path's host side; a new read starts from 0) st->n_alloc = T.n_alloc;
+        st->notes = notes; st->n_alloc = T.n_alloc;        // (a decided read's final notes stay for the chunked path's host side; a new read starts from 0)
         st->n_nbr = t_nbr; st->n_sa = t_sa; st->n_lf = t_lf; st->t_start = 0;
         if constexpr (PROF) { for (int i = 0; i < 12; ++i) st->cyc[i] = (fresh ? 0ull : st->cyc[i]) + s_cyc[i]; }
     }

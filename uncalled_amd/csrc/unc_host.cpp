@@ -1379,8 +1379,11 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
                 n_chunks = clamped;
             }
         }
+        n_chunks = std::max<size_t>(64, n_chunks);
+        // (the override is taken as it is, also below the floor: how the tests make a pool small enough to notice a chunk that is not
+        // handed back)
         if (const char *e = getenv("UNC_RT_POOL_CHUNKS")) { const long v = atol(e); if (v > 0) n_chunks = (size_t)v; }
-        rc = alloc_pool(rt->pool, (uint32_t)std::max<size_t>(64, n_chunks), &bytes);
+        rc = alloc_pool(rt->pool, (uint32_t)n_chunks, &bytes);
         if (rc) return rc;
     }
 #define RALLOC(ptr, type, count)                                   \
