@@ -362,9 +362,11 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     sync()
     barrier()
     t0 = time.perf_counter()
-    ms_ev, ms_map, kept = [], [], []
+    ms_ev, ms_map, kept, step_ms = [], [], [], []
     for _ in range(steps):
-        hits = one_step()
+        ts = time.perf_counter()
+        hits = one_step()                  # (returns the hits: the step is complete on the device when it returns)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         e, m = mapper.last_timing()
         ms_ev.append(e)
         ms_map.append(m)
@@ -442,6 +444,8 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        "mapped_fraction": float(hits["mapped"].mean()),
                        "mean_events_per_read": float(hits["event_i"].mean()),
                        "kernel_ms": {"k_events": ev_ms, "k_map": map_ms},
+                       "step_ms": {"median": float(np.median(step_ms)), "min": float(np.min(step_ms)), "max": float(np.max(step_ms)),
+                                   "k_map_min": float(np.min(ms_map)), "k_map_max": float(np.max(ms_map))},
                        "k_map_phase_cycle_share": phase_share,
                        "k_map_phase_cycle_share_source": "extra untimed pass over the first min(n, 50 000) reads, profiling instantiation of k_map",
                        "k_map_wave_busy": round(wave_busy, 4),
@@ -581,6 +585,77 @@ def realtime_workload(a, ix, prefix, codes, lens, local_rank, ref_label, steps, 
     return out
 
 
+def _r(x, sig=6):
+    """floats of the printed line: 6 significant digits"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def _pick(d, *keys):
+    return {k: _r(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_block(blk, top=True):
+    """The numbers of one measured block that go into the printed line (everything else: bench_detail.json)."""
+    if "error" in blk or "skipped" in blk:
+        return {k: str(v)[:160] for k, v in blk.items()}
+    out = _pick(blk, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")
+    cfg = blk.get("config", {})
+    c = _pick(cfg, "reads_per_gpu_per_step", "mapped_fraction", "mean_events_per_read", "chunks_per_sec", "reads_finished")
+    if "kernel_ms" in cfg:
+        c["kernel_ms"] = {k: _r(v, 5) for k, v in cfg["kernel_ms"].items()}
+    if "latency_ms" in cfg:
+        c["latency_ms"] = {k: _r(v, 4) for k, v in cfg["latency_ms"].items()}
+    if "step_ms" in cfg:
+        c["step_ms"] = {k: _r(v, 5) for k, v in cfg["step_ms"].items()}
+    if cfg.get("remapped_reads"):
+        c["remapped_reads"] = cfg["remapped_reads"]["n"]
+    if cfg.get("node_pool"):
+        c["node_pool"] = cfg["node_pool"]
+    out["config"] = c
+    if "roofline" in blk:
+        keys = ("achieved", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "launch_ms")
+        out["roofline"] = _pick(blk["roofline"], *((("bound", "kernel", "peak", "unit") + keys) if top else keys))
+        out["roofline"].setdefault("traffic", None)
+    if "cpu_baseline" in blk:
+        out["cpu_baseline"] = _pick(blk["cpu_baseline"], "value", "unit", "cores", "kind", "paf_reads_checked", "paf_mismatches_vs_gpu")
+        out["cpu_baseline"]["sample"] = str(blk["cpu_baseline"].get("sample", ""))[:120 if top else 48]
+    if "verify" in blk:
+        v = blk["verify"]
+        out["verify"] = _pick(v, "steps_hashed", "all_steps_identical", "reads_checked_vs_cpu", "paf_mismatches", "reads_checked")
+        if "hits_sha256" in v:
+            out["verify"]["hits_sha16"] = v["hits_sha256"][:16]
+    return out
+
+
+LINE_LIMIT = 8192       # the driver keeps a bounded tail of stdout: the line must fit in it whole (round 4's 21.7 KB line did not parse)
+
+
+def emit(out):
+    """Full record -> bench_detail.json (path on stderr); ONE compact JSON line -> stdout."""
+    detail = Path(os.environ.get("UNC_BENCH_DETAIL", ROOT / "gpurun_out" / "bench_detail.json"))
+    try:
+        detail.parent.mkdir(parents=True, exist_ok=True)
+        detail.write_text(json.dumps(out, indent=1))
+        log(f"full record (prose notes, thread sweeps, phase shares, code object): {detail}")
+    except OSError as e:
+        log(f"could not write {detail}: {e}")
+    line = compact_block(out)
+    line["config"]["workload"] = out["config"]["workload"][:200]
+    line["config"]["parallelism"] = out["config"].get("parallelism")
+    for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        line[k] = out[k]
+    if "secondary" in out:
+        line["secondary"] = {k: compact_block(v, top=False) for k, v in out["secondary"].items()}
+    if "bench_wall_s" in out:
+        line["bench_wall_s"] = _r(out["bench_wall_s"], 4)
+    txt = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    assert len(txt) < LINE_LIMIT, len(txt)
+    print(txt, flush=True)
+    return txt
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU; torch.distributed.run on this
     node, rendezvous on 127.0.0.1) with the same arguments, pass their output through, return their exit code.  The reference's
@@ -600,7 +675,7 @@ def launch_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=None,
@@ -617,6 +692,7 @@ def main():
     ap.add_argument("--chr20-reads", type=int, default=200000, help="reads of the chr20 block (config 3)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("UNC_BENCH_BUDGET_S", 1500)),
                     help="secondary blocks are skipped once this much wall time has gone")
+    ap.add_argument("--secondary-steps", type=int, default=3, help="timed steps of the chr20 / grch38 blocks (after one untimed step over the whole batch)")
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--rt-ref", choices=["ecoli", "chr20", "grch38"], default="ecoli", help="reference of the realtime workload")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)      # internal: cpu_baseline_subprocess
@@ -630,13 +706,19 @@ def main():
         a.reads = a_reads(argparse.Namespace(reads=int(os.environ.get("UNC_BENCH_READS", 50000)), chr20_reads=a.chr20_reads,
                                              grch38_reads=a.grch38_reads), a.workload)
 
+    if a.gpus is None:
+        # started by a launcher without --gpus (`torchrun --nproc-per-node 8 bench.py`): the launcher's world is the statement
+        a.gpus = int(os.environ.get("WORLD_SIZE", 1))
+        if a.gpus > 1 and int(os.environ.get("RANK", 0)) == 0:
+            log(f"--gpus not given: n_gpus = WORLD_SIZE = {a.gpus}")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a.gpus)         # plain `python bench.py --gpus N`: one rank per GPU, this process only relays
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == a.gpus, f"--gpus {a.gpus} but the launcher started {world} rank(s): the line would state the wrong n_gpus"
+    if world != a.gpus:      # an EXPLICIT --gpus that disagrees with the launcher: the line would state the wrong n_gpus
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (n_gpus would be wrong); drop --gpus or fix the launcher")
     # UNC_BENCH_LIB: tests point this at the lanesim build of the same sources to run the world > 1 plumbing on CPU ranks
     lib_path = os.environ.get("UNC_BENCH_LIB")
     have_gpu = lib_path is None
@@ -672,7 +754,7 @@ def main():
         out = realtime_workload(a, ix, prefix, codes, lens, local_rank, a.rt_ref, a.steps, a.warmup,
                                 cpu_budget_s=0.0 if a.no_cpu_baseline else 20.0)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
 
     extras = not a.no_profile_pass
@@ -724,14 +806,15 @@ def main():
                     sec[w] = r
                     log(f"secondary {w}: {r['value']:.0f} ms per round (p95 {r['config']['latency_ms']['p95']:.0f})")
                     continue
-                # one untimed step over the WHOLE batch, then one timed step.  (Rounds 2-3 warmed up on 8 192 reads: the first launch
+                # one untimed step over the WHOLE batch, then --secondary-steps timed steps (median / min / max in config.step_ms).  (Rounds 2-3 warmed up on 8 192 reads: the first launch
                 # that touches all of a 120 GB node pool and 48 GB of slots is 15-20 % slower than the next one -- GRCh38, same
                 # process: 29.1 s then 23.6 s -- and was the one that got timed.)
-                r = run_workload(a, w, a_reads(a, w), 1, 1, rank, world, local_rank, dist, barrier, cache, lib,
+                r = run_workload(a, w, a_reads(a, w), a.secondary_steps, 1, rank, world, local_rank, dist, barrier, cache, lib,
                                  dev_name, extras, 0.0 if a.no_cpu_baseline else 60.0)
                 r = {k: v for k, v in r.items() if k != "dt"}
                 r["unit"] = "reads/s"
                 r["n_gpus"] = world
+                r["steps"], r["warmup"] = a.secondary_steps, 1
                 r["wall_s_incl_index_build"] = time.time() - t0
                 sec[w] = r
                 if rank == 0:
@@ -744,7 +827,7 @@ def main():
             out["secondary"] = sec
     if rank == 0:
         out["bench_wall_s"] = time.time() - T_START
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -90,7 +90,7 @@ def test_round4_bench_line():
     assert abs(avg_ms - under["roofline"]["launch_ms"]) / avg_ms < 0.03
 
 
-def test_algorithmic_bytes_formula():
+def _bench_module():
     import importlib.util
     import sys
     spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
@@ -101,6 +101,58 @@ def test_algorithmic_bytes_formula():
         spec.loader.exec_module(mod)
     finally:
         sys.argv = argv
+    return mod
+
+
+def strict_line(txt):
+    """What a driver with a bounded stdout tail and a strict parser accepts: one line, well under 8 KB, no NaN / Infinity."""
+    def refuse(c):
+        raise ValueError("non-finite constant in the bench line: " + c)
+    assert "\n" not in txt.strip() and len(txt) < 8192, len(txt)
+    return json.loads(txt, parse_constant=refuse)
+
+
+def test_printed_line_is_compact_and_strict(tmp_path, monkeypatch, capsys):
+    """Round 4's line was a 21.7 KB essay the driver could not parse (BENCH_r04.json: parsed null).  bench.py now prints a compact line
+    (emit): the full record of round 4 -- every prose note, sweep and table of it -- goes through emit() and must come out under 8 KB,
+    strictly parseable, with roofline.frac and cpu_baseline.value reachable at the top level and per secondary block; the prose
+    lands in bench_detail.json."""
+    mod = _bench_module()
+    full = _line("r04_bench_default_final.json")
+    monkeypatch.setenv("UNC_BENCH_DETAIL", str(tmp_path / "bench_detail.json"))
+    txt = mod.emit(full)
+    printed = capsys.readouterr().out.strip()
+    assert printed == txt
+    b = strict_line(printed)
+    assert len(printed) < 4608, len(printed)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "verify", "secondary"):
+        assert k in b, k
+    assert b["roofline"]["bound"] == "hbm" and b["roofline"]["peak"] == 8000.0 and b["roofline"]["unit"] == "GB/s"
+    assert abs(b["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 and b["roofline"]["traffic"] > 0
+    assert abs(b["roofline"]["achieved"] - b["roofline"]["algorithmic_bytes_per_launch"] / (b["roofline"]["launch_ms"] * 1e-3) / 1e9) < 1e-4 * b["roofline"]["achieved"]
+    assert abs(b["cpu_baseline"]["value"] - full["cpu_baseline"]["value"]) < 1e-3 and b["cpu_baseline"]["cores"] == 64
+    assert b["cpu_baseline"]["kind"] == "reference" and b["cpu_baseline"]["paf_mismatches_vs_gpu"] == 0
+    assert "workload" in b["config"] and b["config"]["reads_per_gpu_per_step"] == 50000 and "k_map" in b["config"]["kernel_ms"]
+    for name in ("chr20", "grch38"):
+        blk = b["secondary"][name]
+        assert blk["roofline"]["frac"] > 0.2 and blk["cpu_baseline"]["value"] > 0 and blk["verify"]["paf_mismatches"] == 0
+        assert abs(blk["value"] - full["secondary"][name]["value"]) < 1e-5 * blk["value"]
+    assert b["secondary"]["realtime:ecoli"]["config"]["latency_ms"]["p95"] < 100
+    # no string of the line is prose: nothing longer than the workload name
+    def strings(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in strings(b)) <= 200
+    detail = json.loads((tmp_path / "bench_detail.json").read_text())
+    assert detail["cpu_baseline"]["tie_order"]["reads"] > 0 and "k_map_code_object" in detail["config"]      # the prose and tables live here
+
+
+def test_algorithmic_bytes_formula():
+    mod = _bench_module()
     hits = np.zeros(2, dtype=[("n_events", "<u4"), ("event_i", "<u4"), ("n_nbr", "<u8"), ("n_lf", "<u8"), ("n_sa", "<u8"), ("mapped", "<i4")])
     hits["n_events"] = [10, 20]; hits["event_i"] = [5, 20]; hits["n_nbr"] = [100, 7]; hits["n_lf"] = [3, 0]; hits["n_sa"] = [1, 0]
     hits["mapped"] = [1, 0]

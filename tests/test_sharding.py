@@ -80,10 +80,11 @@ def test_bench_py_two_ranks_gloo(sim_lib, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    b = json.loads(lines[0])
+    from test_bench_contract import strict_line
+    b = strict_line(lines[0])                                       # compact, strictly parseable (round 4's line was not)
     assert b["n_gpus"] == 2 and b["steps"] == 2 and b["scaling"] == "weak" and b["metric"] == "reads_mapped_per_sec"
     assert b["config"]["reads_per_gpu_per_step"] == 3
-    assert abs(b["value"] - 3 * 2 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6     # whole job: both ranks' reads
+    assert abs(b["value"] - 3 * 2 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-4     # whole job: both ranks' reads
     assert b["verify"]["all_steps_identical"] and b["verify"]["steps_hashed"] == 2
     assert "cpu_baseline" not in b and "secondary" not in b                               # N > 1: neither is run
 
@@ -102,16 +103,63 @@ def test_bench_py_launches_its_own_ranks(sim_lib, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    b = json.loads(lines[0])
+    from test_bench_contract import strict_line
+    b = strict_line(lines[0])
     assert b["n_gpus"] == 2 and b["config"]["reads_per_gpu_per_step"] == 2
     sec = b["secondary"]["example"]
     assert sec["n_gpus"] == 2 and sec["value"] > 0 and sec["verify"]["all_steps_identical"]
-    assert abs(sec["value"] - 2 * 2 / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 1e-6
+    assert abs(sec["value"] - 2 * 2 / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 1e-4
     # a launcher that started a different number of ranks than --gpus says is refused
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "example", "--reads", "2"], env=env1,
                        capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert r.returncode != 0 and "n_gpus" in r.stderr
+
+
+def test_bench_py_eight_ranks_dry_run(sim_lib, tmp_path):
+    """The driver's 8-GPU run, dry: plain `python bench.py --gpus 8` on eight gloo ranks over the emulator library (tiny workload).  No
+    hardware curve can be measured here; what CAN be checked is that eight ranks rendezvous, rank 0 alone builds / names the index
+    behind the barrier, every rank maps its own shard, the MAX-over-ranks timing and the budget all-reduce agree on eight ranks, and
+    ONE compact line comes out with n_gpus 8 in the headline and in the secondary block (the N > 1 form of BASELINE config 4)."""
+    import json
+    import subprocess
+    from test_bench_contract import strict_line
+    env = dict(os.environ, UNC_DIST_BACKEND="gloo", UNC_BENCH_LIB=str(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so"),
+               UNC_BENCH_CACHE=str(tmp_path), UNC_BENCH_DETAIL=str(tmp_path / "bench_detail.json"), OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--workload", "example",
+                        "--reads", "1", "--secondary", "example", "--secondary-steps", "1"], env=env, capture_output=True, text=True,
+                       timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    b = strict_line(lines[0])
+    assert b["n_gpus"] == 8 and b["scaling"] == "weak" and b["config"]["reads_per_gpu_per_step"] == 1
+    assert abs(b["value"] - 8 * 1 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-4          # whole job: eight ranks' reads
+    sec = b["secondary"]["example"]
+    assert sec["n_gpus"] == 8 and sec["verify"]["all_steps_identical"] and abs(sec["value"] - 8 / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 1e-4
+    assert "cpu_baseline" not in b                                                            # N > 1: no rank runs (or waits for) a CPU leg
+    detail = json.loads((tmp_path / "bench_detail.json").read_text())
+    assert detail["n_gpus"] == 8 and detail["secondary"]["example"]["n_gpus"] == 8
+
+
+def test_launcher_without_gpus_flag_is_adopted(sim_lib, tmp_path):
+    """round-4 advice: `torchrun --nproc-per-node 2 bench.py` (no --gpus) used to die on an assert with no JSON line; the launcher's
+    WORLD_SIZE is now the statement, and only an EXPLICIT --gpus that disagrees is refused."""
+    import subprocess
+    from test_bench_contract import strict_line
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UNC_DIST_BACKEND="gloo", UNC_BENCH_LIB=str(ROOT / "tests" / "lanesim" / "_build" / "libuncalled_sim.so"),
+               UNC_BENCH_CACHE=str(tmp_path), UNC_BENCH_DETAIL=str(tmp_path / "bench_detail.json"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "example",
+                        "--reads", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = strict_line([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2
 
 
 def test_numa_placement_plan(tmp_path):
