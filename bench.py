@@ -458,6 +458,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        "remapped_reads": {"n": remap_n, "ms": round(remap_ms, 1),
                                           "note": "reads that found the seed-cluster node pool dry, mapped again after the batch (inside the step)"},
                        "reads_in_flight": mapper.geometry(),
+                       "node_pool": mapper.pool_usage(),
                        "index_seq_len": int(ix.size), "index_device_bytes": int(ix.device_bytes())},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -123,7 +123,8 @@ def sim_lib():
     # the chunked path's teams: 8 wavefronts per channel are 512 fibers per emulated workgroup -- three times the run time of the
     # chunked cases.  The emulator suite runs them on teams of 2 and has dedicated cases for 4 and 8 (test_chunked_team_sizes); the
     # GPU suite runs everything on the default (8).
-    os.environ.setdefault("UNC_RT_TEAM", "2")
+    # (UNC_SIM_RT_TEAM is read by the emulator build only: the gfx950 library in the same process keeps its default of 8)
+    os.environ.setdefault("UNC_SIM_RT_TEAM", "2")
     extra = os.environ.get("UNC_LANESIM_EXTRA")      # dev: the emulator suite over a variant build (extra -D flags)
     if extra:
         locked_make("-C", str(ROOT / "tests" / "lanesim"), "OUT=_build_extra", "EXTRA=" + extra)

@@ -230,6 +230,7 @@ template <class T> static inline T __lanesim_fetch_or(T *p, T v) { T o = *p; *p 
 #define __hip_atomic_fetch_or(p, v, order, scope) __lanesim_fetch_or((p), (v))
 template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 
 // ---- host API subset -------------------------------------------------------------------------

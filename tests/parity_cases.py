@@ -580,6 +580,23 @@ def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2,
     assert m4.last_remap()[0] > 0
     for name in capi.RESULT_FIELDS:
         assert np.array_equal(hits[name], hits2[name]) and np.array_equal(hits[name], hits3[name]) and np.array_equal(hits[name], hits4[name]), name
+    # the pool is sized by NEED (unc_mapper_pool_usage): a named size stays as it is and its high-water mark is reported ...
+    u = m.pool_usage()
+    assert u["chunks"] == pool_chunks and u["resizes"] == 0 and u["high_water_ever"] == pool_chunks          # it ran dry: every chunk was out
+    u3 = m3.pool_usage()
+    assert u3["chunks"] == 64 and 0 < u3["high_water_last_batch"] <= 3 * n_waves and u3["resizes"] == 0      # at most a chunk per read in flight here
+    # ... the default starts from the rule of thumb and is then kept at twice the most chunks that were out at once (never below
+    # one per slot / 16): the first batch shrinks it, the second finds it sized and leaves it; answers unchanged
+    m5 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60)
+    before = m5.geometry()["pool_chunks"]
+    hits5 = m5.map_batch(raw, off, cal)
+    u5 = m5.pool_usage()
+    assert before > 16 and u5["chunks"] == max(16, 2 * u5["high_water_ever"]) and u5["resizes"] == 1 and m5.last_remap()[0] == 0
+    assert u5["high_water_last_batch"] == u3["high_water_last_batch"]
+    hits6 = m5.map_batch(raw, off, cal)
+    assert m5.pool_usage()["resizes"] == 1 and m5.pool_usage()["chunks"] == u5["chunks"] and m5.last_remap()[0] == 0
+    for name in capi.RESULT_FIELDS:
+        assert np.array_equal(hits[name], hits5[name]) and np.array_equal(hits[name], hits6[name]), name
 
 
 def case_big_forests(lib, oracle_lib, example, goldens, tmp_path, monkeypatch, wide_too=True):

@@ -1,0 +1,74 @@
+"""-m gpu: the DEVICE paths of the BWA-format index builders (replacement for bwa_idx_build, bwa_index.hpp:92-101).
+
+Every scale test and every bench block maps against an index that uncalled_amd/build_index.py (`sa_device="cuda"`) or
+uncalled_amd/build_index_big.py (`device="cuda"`) built on the GPU; the CPU suite pins the same code on torch-CPU / numpy only.  Here
+the device builds of a 2 Mb repeat-rich, masked reference are compared byte for byte -- all five files -- with the numpy builder
+(itself byte-identical to `bwa index` on the bundled example, tests/test_build_index_big.py, tests/test_oracle.py), the suffix
+array of a device-built 20 kb index with a naive suffix array, and the C ABI loads the device-built index and answers FM queries
+as the oracle does on the CPU-built one."""
+import filecmp
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from uncalled_amd import build_index as small   # noqa: E402
+from uncalled_amd import build_index_big as big   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+SUFS = (".pac", ".ann", ".amb", ".bwt", ".sa")
+
+
+def repeat_rich_masked(total, seed, n_contigs=3):
+    """i.i.d. contigs with 30 % N-runs (.amb holes) + long exact repeats, an inverted repeat (a reverse-complement copy: ties between
+    the two strands of the text), a tandem repeat and a homopolymer run -- ties far deeper than one 21-symbol key"""
+    names, lens, codes, holes, n_ambs = small.masked_synthetic_genome(n_contigs, total, seed, mean_run=2000, name="rep")
+    codes = codes.copy()
+    rng = np.random.default_rng(seed)
+    q = total // 8
+    codes[q:q + 30000] = codes[3 * q:3 * q + 30000]                      # exact repeat, 30 kb
+    codes[5 * q:5 * q + 12000] = 3 - codes[2 * q:2 * q + 12000][::-1]    # inverted repeat
+    unit = rng.integers(0, 4, 53).astype(np.uint8)
+    codes[6 * q:6 * q + 53 * 300] = np.tile(unit, 300)                   # tandem repeat
+    codes[7 * q:7 * q + 5000] = 0                                        # poly-A
+    return names, lens, codes, holes, n_ambs
+
+
+def test_device_builders_equal_the_numpy_builder_byte_for_byte(tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    names, lens, codes, holes, n_ambs = repeat_rich_masked(2_000_003, seed=11)
+    annos = [""] * len(names)
+    small.build_from_codes(tmp_path / "cpu", names, annos, lens, codes, holes, n_ambs, uncl_text=None)                       # numpy
+    small.build_from_codes(tmp_path / "dev", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda")     # torch sorts on the GPU
+    # chunk / piece far below the defaults: dozens of chunk and piece boundaries on 4 M symbols, as 6.2 G symbols have with the defaults
+    big.build_from_codes_big(tmp_path / "big", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda", chunk=1 << 18, piece=1 << 17)
+    big.build_from_codes_big(tmp_path / "bigd", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda")     # defaults: one chunk
+    for other in ("dev", "big", "bigd"):
+        for suf in SUFS:
+            assert filecmp.cmp(tmp_path / ("cpu" + suf), tmp_path / (other + suf), shallow=False), (other, suf)
+
+
+def test_device_built_suffix_array_against_naive(tmp_path, hip_lib, oracle_lib):
+    """20 kb slice: SA of every row of the device-built index (through the C ABI on the GPU: unc_fm_sa) == naive suffix array of
+    fwd + revcomp; the oracle on the same files agrees row by row (as tests/test_oracle.py does for the bundled `bwa index` files)."""
+    from uncalled_amd import capi
+    names, lens, codes, holes, n_ambs = repeat_rich_masked(20_000, seed=12, n_contigs=1)
+    small.build_from_codes(tmp_path / "s", names, [""], lens, codes, holes, n_ambs, sa_device="cuda")
+    big.build_from_codes_big(tmp_path / "b", names, [""], lens, codes, holes, n_ambs, device="cuda", chunk=3000, piece=4096)
+    for suf in SUFS:
+        assert filecmp.cmp(tmp_path / ("s" + suf), tmp_path / ("b" + suf), shallow=False), suf
+    n = codes.size
+    t = np.concatenate((codes, 3 - codes[::-1]))
+    s = bytes(t + 1)
+    naive = sorted(range(2 * n + 1), key=lambda i: s[i:])
+    oix = oracle_lib.Index(tmp_path / "s")
+    assert oix.size == 2 * n
+    assert [oix.sa(k) for k in range(1, 2 * n + 1)] == naive[1:]
+    ix = capi.Index(tmp_path / "s", lib=hip_lib)
+    rows = np.arange(1, 2 * n + 1, dtype=np.uint64)
+    assert np.array_equal(ix.sa(rows), np.array(naive[1:], dtype=np.uint64))
+    assert np.array_equal(ix.kmer_ranges(), oix.kmer_ranges())

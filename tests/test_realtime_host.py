@@ -133,6 +133,16 @@ def case_oversized_chunk_is_refused(unc):
     assert str(out[0][2]).split("\t")[0] == "ok" and int(str(out[0][2]).split("\t")[1]) == int(4000 * 450.0 / 4000.0)
     assert pool.all_finished()
     assert pool.add_chunk(unc.Chunk("next", 1, 3, 0, noise, 0, 4000)) and pool.active_count() == 1
+    # two reads given up on ONE channel between two updates (round-4 advice): read 3 is mapping; a chunk of read 4 takes the channel
+    # over (3 is reset); an oversized chunk of read 4 arrives before update() and ends 4 as well.  Both get their unmapped + ended line
+    # -- the reference reports every reset read (a single give-up record per channel lost read 3's)
+    assert pool.update() == [] and pool.active_count() == 1
+    assert pool.add_chunk(unc.Chunk("four", 1, 4, 0, noise, 0, 4000))
+    assert not pool.add_chunk(unc.Chunk("four", 1, 4, 4000, noise, 4000, 5000))
+    out = pool.update()
+    assert sorted((ch, nm, str(p).split("\t")[0], p.is_ended(), p.is_mapped()) for ch, nm, p in out) == \
+        [(1, 3, "next", True, False), (1, 4, "four", True, False)]
+    assert pool.all_finished() and pool.update() == []
 
 
 def case_client_sim_feeds_the_decision_loop(unc, tmp_path, goldens):

@@ -213,8 +213,9 @@ class RealtimeSession:
     "keep"               | Paf.KEEP                                         | stop_receiving_read
     A mapped read is ejected when depleting, an unmapped one when enriching; everything else is kept."""
 
-    def __init__(self, unc, conf, client, pool, emit=None, clock=time.time):
+    def __init__(self, unc, conf, client, pool, emit=None, clock=time.time, sim=True):
         self.unc, self.client, self.pool, self.clock = unc, client, pool, clock
+        self.sim = sim      # the chunk source is the simulator: an ejection's answer is a delay, written as Paf.DELAY (scripts/uncalled:231-232)
         self.emit = emit or (lambda paf: paf.print_paf())
         self.eject_mapped = conf.realtime_mode == int(unc.RealtimePool.DEPLETE)
         self.skip_odd = conf.active_chs == int(unc.RealtimePool.EVEN)
@@ -238,7 +239,9 @@ class RealtimeSession:
 
     def _eject(self, ch, number, paf, waited):
         paf.set_float(self.unc.Paf.EJECT, waited)
-        paf.set_int(self.unc.Paf.DELAY, self.client.unblock_read(ch, number))
+        answer = self.client.unblock_read(ch, number)
+        if self.sim:
+            paf.set_int(self.unc.Paf.DELAY, answer)
         self.chan[ch].ejected_read = number
 
     def decide(self):
@@ -253,7 +256,8 @@ class RealtimeSession:
             if self.skip_odd and ch % 2:
                 self.client.stop_receiving_read(ch, chunk.number)
             elif self.chan[ch].ejected_read == chunk.number:
-                sys.stdout.write("# chunk of %s arrived after its ejection: dropped\n" % chunk.id)
+                # (the reference's own words, spelling included: the line is part of the PAF stream its consumers see, scripts/uncalled:250)
+                sys.stdout.write("# recieved chunk from %s after unblocking\n" % chunk.id)
             else:
                 self.chan[ch].last_chunk_at = self.clock()
                 self.pool.add_chunk(chunk)
@@ -275,9 +279,9 @@ class RealtimeSession:
 
 
 def realtime_loop(unc, conf, client, pool, sim=True, emit=None, sleep=time.sleep):
-    """`uncalled sim`'s main loop: a RealtimeSession run to its end (`sim` is accepted for the reference's call shape; the
-    MinKNOW client, the only other chunk source, is out of scope)."""
-    RealtimeSession(unc, conf, client, pool, emit=emit).run(sleep=sleep)
+    """`uncalled sim`'s main loop: a RealtimeSession run to its end.  `sim`: the chunk source is the simulator (the MinKNOW client,
+    the only other one, is out of scope): its answer to an ejection is written as Paf.DELAY, as scripts/uncalled:231-232 does."""
+    RealtimeSession(unc, conf, client, pool, emit=emit, sim=sim).run(sleep=sleep)
 
 
 def sim_cmd(args):

@@ -128,6 +128,9 @@ def load(path=None):
     L.unc_mapper_kernel_info.restype = i32
     L.unc_mapper_geometry.argtypes = [vp, vp]
     L.unc_mapper_geometry.restype = None
+    if hasattr(L, "unc_mapper_pool_usage"):           # (older builds under uncalled_amd/variants/ lack it)
+        L.unc_mapper_pool_usage.argtypes = [vp, vp]
+        L.unc_mapper_pool_usage.restype = C.c_int
     L.unc_mapper_set_profile.argtypes = [vp, C.c_int]
     L.unc_mapper_set_profile.restype = None
     L.unc_mapper_last_wave_busy.argtypes = [vp]
@@ -322,6 +325,17 @@ class Mapper:
         out = np.zeros(5, dtype=np.uint32)
         self.L.unc_mapper_geometry(self.h, out.ctypes.data)
         return dict(zip(("n_waves", "n_slots", "slice_events", "pool_chunks", "max_clusters"), (int(x) for x in out)))
+
+    def pool_usage(self):
+        """Seed-cluster node pool: chunks (192 KB each) held now, high-water mark of chunks out at once in the last batch / ever,
+        times the library resized it (the pool is kept at twice the high-water mark; include/uncalled_hip.h)."""
+        if not hasattr(self.L, "unc_mapper_pool_usage"):
+            return None
+        out = np.zeros(4, dtype=np.uint32)
+        _check(self.L, self.L.unc_mapper_pool_usage(self.h, out.ctypes.data))
+        d = dict(zip(("chunks", "high_water_last_batch", "high_water_ever", "resizes"), (int(x) for x in out)))
+        d["gb"] = round(d["chunks"] * 192 * 1024 / 1e9, 2)
+        return d
 
     def kernel_info(self):
         """Register / scratch / LDS figures of the k_map instantiation this mapper launches, read off the code object."""

@@ -83,7 +83,7 @@ void RealtimePool::start_read(Chan &c, Chunk &chunk) {   // Mapper::new_read(Chu
 
 // request_reset on the read the channel is mapping: what the next update() reports unmapped + ended
 static void remember_old(RealtimePool::Chan &c) {
-    c.give_up = true; c.old_id = c.id; c.old_number = c.number; c.old_start = c.start; c.old_raw_len = c.raw_len;
+    c.given_up.push_back({c.id, c.number, c.start, c.raw_len});
 }
 
 // A chunk longer than chunk_time * sample_rate does not fit the per-channel staging of the device side: it is refused here
@@ -182,11 +182,12 @@ std::vector<MapResult> RealtimePool::update() {
     // reads given up since the last call: request_reset -> set_failed + set_ended (mapper.cpp:384-390)
     for (size_t ch = 0; ch < chans_.size(); ++ch) {
         Chan &c = chans_[ch];
-        if (!c.give_up) continue;
-        Paf p = unmapped_paf(c.old_id, (uint16_t)ch, c.old_start, c.old_raw_len);
-        p.set_ended();
-        ret.emplace_back((uint16_t)(ch + 1), c.old_number, p);
-        c.give_up = false;
+        for (const Chan::GivenUp &g : c.given_up) {
+            Paf p = unmapped_paf(g.id, (uint16_t)ch, g.start, g.raw_len);
+            p.set_ended();
+            ret.emplace_back((uint16_t)(ch + 1), g.number, p);
+        }
+        c.given_up.clear();
     }
     // every buffered chunk (at most one per channel) in one call: mapped completely before it returns
     std::vector<unc_rt_chunk_t> chunks;
@@ -252,7 +253,7 @@ std::vector<MapResult> RealtimePool::update() {
 }
 
 bool RealtimePool::all_finished() {
-    for (const Chan &c : chans_) if (c.active || c.has_pending || c.give_up) return false;
+    for (const Chan &c : chans_) if (c.active || c.has_pending || !c.given_up.empty()) return false;
     return true;
 }
 
@@ -264,7 +265,7 @@ uint32_t RealtimePool::active_count() const {
 
 void RealtimePool::stop_all() {
     stopped_ = true;
-    for (Chan &c : chans_) { c.active = c.has_pending = c.give_up = false; c.pending.clear(); }
+    for (Chan &c : chans_) { c.active = c.has_pending = false; c.given_up.clear(); c.pending.clear(); }
 }
 
 // ------------------------------------------------------------------ ClientSim-shaped chunk source over fast5 files

@@ -66,13 +66,15 @@ public:
         bool active = false;         // a read is being mapped (Mapper state MAPPING; its last chunk is fully mapped)
         bool has_pending = false;    // a chunk waits for the next update()
         bool pending_first = false;  // ... and it starts a read (Mapper::new_read(Chunk&))
-        bool give_up = false;        // request_reset: the read is reported unmapped + ended by the next update()
         uint32_t number = 0, chunks = 0;
         uint64_t start = 0, raw_len = 0;
         std::string id;
         Chunk pending;
-        // the read a give_up refers to when a new read has already taken the channel over
-        std::string old_id; uint32_t old_number = 0; uint64_t old_start = 0, old_raw_len = 0;
+        // request_reset: reads reported unmapped + ended by the next update().  A list, not one record: between two updates a channel
+        // can give up its mapping read (a new read takes it over) AND that new read's first chunk can be refused as oversized before it
+        // was ever mapped -- the reference reports every reset read (round-4 advice: one record lost the first of the two)
+        struct GivenUp { std::string id; uint32_t number; uint64_t start, raw_len; };
+        std::vector<GivenUp> given_up;
     };
 private:
     void start_read(Chan &c, Chunk &chunk);

@@ -166,7 +166,7 @@ __device__ __forceinline__ float tstat_win(const double *C, const double *Q, int
 
 struct EvRun {                        // what EventDetector carries from sample to sample
     Detector sd, ld;
-    uint32_t t, evt_st, total_events, n_kept;
+    uint32_t t, evt_st, total_events, n_kept, over;      // over: an event found the read's room in `means` full (reported, never silent)
     double evt_st_sum, mean_sum;
     float len_sum;
 };
@@ -185,9 +185,11 @@ __device__ __forceinline__ void fsm_step(EvRun &E, const unc_params_t &P, float 
         E.len_sum = __fadd_rn(E.len_sum, (float)length);
         E.total_events++;
         mean = __fmul_rn(__fadd_rn(mean, 0.0f), 1.0f);   // calibrate(): cal_offset_=0, cal_coef_=1
-        if (mean >= P.min_mean && mean <= P.max_mean && E.n_kept < mcap) {
-            means[E.n_kept++] = mean;
-            E.mean_sum += (double)mean;                  // Normalizer::set_signal's first sum, in index order
+        if (mean >= P.min_mean && mean <= P.max_mean) {
+            if (E.n_kept < mcap) {
+                means[E.n_kept++] = mean;
+                E.mean_sum += (double)mean;              // Normalizer::set_signal's first sum, in index order
+            } else E.over = 1u;
         }
     }
 }
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P, uint3
     EvRun E;
     E.sd = Detector{P.threshold1, P.window_length1, 0u, -1, FLT_MAX, false};
     E.ld = Detector{P.threshold2, P.window_length2, 0u, -1, FLT_MAX, false};
-    E.t = 1; E.evt_st = 0; E.total_events = 0; E.n_kept = 0; E.evt_st_sum = 0.0; E.mean_sum = 0.0; E.len_sum = 0.0f;
+    E.t = 1; E.evt_st = 0; E.total_events = 0; E.n_kept = 0; E.over = 0; E.evt_st_sum = 0.0; E.mean_sum = 0.0; E.len_sum = 0.0f;
     double C[WIN], Q[WIN];            // C[i] = cumulative sum at position (next sample's position) - 12 + i
 #pragma unroll
     for (int i = 0; i < WIN; ++i) { C[i] = 0.0; Q[i] = 0.0; }
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(64) void k_events(DevReads R, unc_params_t P, uint3
     inf.len_sum = E.len_sum;
     inf.scale = scale;
     inf.shift = shift;
-    inf.pad = 0;
+    inf.pad = E.over;        // 1: the read has more events than its room in `means` (the host fails the call loudly)
     R.info[r] = inf;
 }
 

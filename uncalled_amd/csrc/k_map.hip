@@ -2380,6 +2380,7 @@ __global__ void k_pool_init(DevPool B) {
         SchedQueue q;
         memset(&q, 0, sizeof q);
         q.tail = B.n_chunks;
+        q.low_water = B.n_chunks;
         *B.q = q;
     }
 }

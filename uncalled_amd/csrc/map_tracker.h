@@ -41,6 +41,15 @@ struct TrackerMem {
     PoolView pool;         // nodes
 };
 
+// a chunk off the pool's ring (lane 0 only), keeping the ring's low-water mark of free chunks (a pop per 768 nodes: rare)
+__device__ __forceinline__ uint32_t pool_pop(const PoolView &P) {
+    const uint32_t ch = sched_pop(P.q, P.cells, P.cap_mask);
+    if (ch != SCHED_EMPTY) {
+        const int32_t free_now = (int32_t)(ld_acq(&P.q->tail) - ld_acq(&P.q->head));
+        atomicMin(&P.q->low_water, free_now > 0 ? (uint32_t)free_now : 0u);
+    } else atomicMin(&P.q->low_water, 0u);
+    return ch;
+}
 // the read is over: its chunks go back to the pool
 __device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
     const uint32_t n_chunks = (T.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
@@ -274,12 +283,12 @@ static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_m
             uint32_t ch0 = SCHED_EMPTY, ch1 = SCHED_EMPTY;
             if (lane == 0) {
                 if (a0 % CHUNK_NODES == 0u) {
-                    ch0 = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
+                    ch0 = pool_pop(M.pool);
                     if (ch0 != SCHED_EMPTY) gst(M.sb, M.off_chunks + (c0 << 2), ch0);
                 } else ch0 = gld<uint32_t>(M.sb, M.off_chunks + (c0 << 2));
                 if (c1 == c0) ch1 = ch0;
                 else if (ch0 != SCHED_EMPTY) {
-                    ch1 = sched_pop(M.pool.q, M.pool.cells, M.pool.cap_mask);
+                    ch1 = pool_pop(M.pool);
                     if (ch1 != SCHED_EMPTY) gst(M.sb, M.off_chunks + (c1 << 2), ch1);
                 }
             }

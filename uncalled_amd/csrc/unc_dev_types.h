@@ -103,7 +103,9 @@ struct alignas(16) SlotState {
 // instead of a few of them keeping single wavefronts busy long after the queue has drained.
 // Both queues are bounded multi-producer/multi-consumer rings of slot ids with a sequence number per cell.
 struct SchedCell { uint32_t seq, val; };
-struct alignas(64) SchedQueue { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1[15]; };
+// low_water (node pool only): the fewest free ids the ring has held since it was initialised -- the pool's high-water mark of chunks
+// out at once is n_chunks - low_water (unc_mapper_pool_usage: the pool is sized by it, not by a share of the free HBM)
+struct alignas(64) SchedQueue { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t low_water; uint32_t pad1[14]; };
 struct alignas(64) SchedCtl {
     uint32_t next_read, pad0[15];
     SchedQueue freeq, parkq;

@@ -466,6 +466,10 @@ struct unc_mapper {
     float wall_khz = 0;            // device wall clock rate (ticks per ms)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
     DevPool pool{};                // nodes of the seed-cluster grids, shared by every read in flight
+    // the pool is sized by NEED: created by a rule of thumb, then kept at twice the most chunks that were ever out at once
+    // (unc_mapper_pool_usage); a caller who named pool_chunks keeps that number
+    bool pool_auto = false;
+    uint32_t pool_floor = 16, pool_hw_last = 0, pool_hw_max = 0, pool_resizes = 0;
     DevScratch big{};              // scratch with a larger node allowance for the reads that outgrew a slot's (kept between batches)
     uint64_t big_cap = 0;
     size_t big_slots = 0;
@@ -642,6 +646,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         // index rows and more, where a read touches thousands of buckets and off-target reads collect hundreds of thousands
         // of clusters; at most 60% of what is left of the HBM.  k_map stops taking up new reads while the pool is nearly
         // empty; a read that still finds it dry is mapped again after the batch (below).
+        // That rule sizes the pool for the FIRST batch only: after every batch the pool is kept at twice the high-water mark of
+        // chunks out at once (never below one chunk per slot), see pool_fit below.
         uint32_t n_chunks = opts ? opts->pool_chunks : 0;
         if (n_chunks == 0) {
             size_t free_b = 0, total_b = 0;
@@ -649,6 +655,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
             const size_t chunk_bytes = POOL_CHUNK_BYTES;
             const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 26) ? 64 : 8);
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
+            m->pool_auto = true;
+            m->pool_floor = std::max<uint32_t>(16, std::min<uint32_t>(n_slots, n_chunks));
         }
         int rc2 = alloc_pool(m->pool, n_chunks, &bytes);
         if (rc2) return rc2;
@@ -695,7 +703,7 @@ static int ensure_batch(unc_mapper *m, uint32_t n_reads, uint64_t total_samples,
         HIPCHK(hipMalloc((void **)&m->d_results, (size_t)n_reads * sizeof(DevResult)));
         m->reads_cap = n_reads;
     }
-    const uint64_t means_need = total_samples + 16ull * n_reads + 16;
+    const uint64_t means_need = total_samples / 8 * 5 + 24ull * n_reads + 16;      // (see means_room)
     if (means_need > m->means_cap) {
         if (m->d_means) (void)hipFree(m->d_means);
         m->d_means = nullptr;
@@ -717,7 +725,15 @@ static int stage_batch(unc_mapper *m, uint32_t n_reads, const int16_t *raw, cons
     int rc = ensure_batch(m, n_reads, total, !on_device);
     if (rc) return rc;
     m->h_moff.resize((size_t)n_reads + 1);
-    for (uint32_t i = 0; i <= n_reads; ++i) m->h_moff[i] = (offsets[i] - base) + 16ull * i;   // capacity n_i + 16 per read
+    // a read's room for its kept event means: 5/8 of its samples + 16.  Neither peak detector can fire on consecutive samples (after a
+    // peak it needs one sample to find the next candidate and one to see it fall, event_detector.cpp:221-279) and the short one masks the
+    // long one for three samples, so n / 2 bounds the events; k_events checks the room and reports a read that overran it
+    // (unc_evt_info_t.pad), which fails the call below.  (Rounds 1-4: n + 16 floats per read, 32 GB for 250 k reads.)
+    {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < n_reads; ++i) { m->h_moff[i] = acc; acc += (offsets[i + 1] - offsets[i]) / 8 * 5 + 16; }
+        m->h_moff[n_reads] = acc;
+    }
     HIPCHK(hipMemcpyAsync(m->d_offsets, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(m->d_moff, m->h_moff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(m->d_calib, calib, (size_t)n_reads * sizeof(unc_calib_t), hipMemcpyHostToDevice, st));
@@ -782,6 +798,52 @@ static void fill_hit(const unc_index *ix, const unc_params_t &P, const DevResult
     }
 }
 
+// chunks that were out at once in the launches since the pool was last initialised (SchedQueue::low_water)
+static int pool_note_high_water(unc_mapper *m, hipStream_t st) {
+    uint32_t lw = m->pool.n_chunks;
+    HIPCHK(hipMemcpyAsync(&lw, &m->pool.q->low_water, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t hw = m->pool.n_chunks - std::min(lw, m->pool.n_chunks);
+    m->pool_hw_last = std::max(m->pool_hw_last, hw);
+    m->pool_hw_max = std::max(m->pool_hw_max, hw);
+    return UNC_OK;
+}
+
+// After a batch (the pool is idle): keep the pool at twice the most chunks that were ever out at once.  A pool that went dry
+// doubles (the reads concerned were mapped again, correctly but late); one that is more than a third larger than need shrinks.
+static int pool_fit(unc_mapper *m, bool went_dry) {
+    if (!m->pool_auto) return UNC_OK;
+    const uint64_t cur = m->pool.n_chunks;
+    uint64_t target = cur;
+    if (went_dry) target = cur * 2;
+    else {
+        const uint64_t need = std::max<uint64_t>(m->pool_floor, 2ull * m->pool_hw_max);
+        if (need * 4 < cur * 3) target = need;
+    }
+    if (target > cur) {     // growing: at most 60 % of what would be free without the pool
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t most = (free_b + cur * (uint64_t)POOL_CHUNK_BYTES) / 5 * 3 / POOL_CHUNK_BYTES;
+        target = std::max(cur, std::min(target, most));
+    }
+    if (target == cur) return UNC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    m->device_bytes -= (uint64_t)cur * POOL_CHUNK_BYTES;
+    free_pool(m->pool);
+    size_t bytes = 0;
+    int rc = alloc_pool(m->pool, (uint32_t)target, &bytes);
+    if (rc) return rc;
+    m->device_bytes += (uint64_t)target * POOL_CHUNK_BYTES;
+    m->pool_resizes++;
+    return UNC_OK;
+}
+
+extern "C" int unc_mapper_pool_usage(const unc_mapper_t *m, uint32_t *out4) {
+    if (!m || !out4) return fail(UNC_ERR_ARG, "null argument");
+    out4[0] = m->pool.n_chunks; out4[1] = m->pool_hw_last; out4[2] = m->pool_hw_max; out4[3] = m->pool_resizes;
+    return UNC_OK;
+}
+
 extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
                              const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits) {
     if (!m || !raw || !offsets || !calib || !hits) return fail(UNC_ERR_ARG, "null argument");
@@ -825,6 +887,12 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));
     HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
+    for (uint32_t i = 0; i < n_reads; ++i)
+        if (m->h_info[i].pad) return fail(UNC_ERR_OVERFLOW, "read %u: more events than the room for event means holds (5/8 of its samples + 16)", i);
+    m->pool_hw_last = 0;
+    rc = pool_note_high_water(m, st);
+    if (rc) return rc;
+    bool pool_went_dry = false;
     {
         unsigned long long ticks = 0;
         int khz = 0;
@@ -849,6 +917,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         if (subset) { for (uint32_t i : *subset) classify(i); }
         else { for (uint32_t i = 0; i < n_reads; ++i) classify(i); }
         m->remap_reads += (uint32_t)(dry.size() + full.size());
+        if (!dry.empty()) pool_went_dry = true;
         const auto t_redo = std::chrono::steady_clock::now();
         uint64_t cap = m->sc.max_clusters;
         size_t limit = m->n_waves;
@@ -871,6 +940,7 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
             const uint32_t lo = *std::min_element(work.begin(), work.end()), hi = *std::max_element(work.begin(), work.end());
             HIPCHK(hipMemcpyAsync(m->h_results.data() + lo, m->d_results + lo, (size_t)(hi - lo + 1) * sizeof(DevResult), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (int rc3 = pool_note_high_water(m, st)) return rc3;
             for (uint32_t i : work) classify(i);
             work.clear();
             return UNC_OK;
@@ -935,20 +1005,24 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         std::map<uint32_t, Flags> assumed;     // read -> flags its current result started from (absent: none)
         Flags f0; memcpy(f0.data(), m->carry_flags, sizeof f0);
         if (f0 != zero) assumed[0] = f0;
+        // (a read that is reported with an overflow status has no valid run behind it: it hands NO flags on -- round-4 advice; the
+        // rows of all flagged reads are fetched together, one synchronisation per call)
         auto fetch_left = [&](const std::vector<uint32_t> &reads) -> int {
+            std::vector<uint32_t> rows;
             for (uint32_t i : reads) {
                 left.erase(i);
-                if (!(m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT)) continue;
-                Flags f;
-                HIPCHK(hipMemcpyAsync(f.data(), m->d_flags_out + (size_t)i * FW, sizeof f, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                left[i] = f;
+                if (m->h_results[i].status == 0 && (m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT)) rows.push_back(i);
             }
+            std::vector<Flags> got(rows.size());
+            for (size_t k = 0; k < rows.size(); ++k)
+                HIPCHK(hipMemcpyAsync(got[k].data(), m->d_flags_out + (size_t)rows[k] * FW, sizeof(Flags), hipMemcpyDeviceToHost, st));
+            if (!rows.empty()) HIPCHK(hipStreamSynchronize(st));
+            for (size_t k = 0; k < rows.size(); ++k) left[rows[k]] = got[k];
             return UNC_OK;
         };
         {
             std::vector<uint32_t> flagged;
-            for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT) flagged.push_back(i);
+            for (uint32_t i = 0; i < n_reads; ++i) if (m->h_results[i].status == 0 && (m->h_results[i].notes & UNC_NOTE_FLAGS_LEFT)) flagged.push_back(i);
             rc = fetch_left(flagged);
             if (rc) return rc;
         }
@@ -999,6 +1073,8 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
         fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i], m->wall_khz);
         if (hits[i].status) worst = UNC_ERR_OVERFLOW;
     }
+    rc = pool_fit(m, pool_went_dry);
+    if (rc) return rc;
     if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise pool_chunks / max_clusters / max_seed_paths");
     return UNC_OK;
 }
@@ -1065,6 +1141,8 @@ extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_
     HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));     // unc_mapper_last_timing: k_events alone
     m->ms_map = 0;
     uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_reads; ++i)
+        if (info[i].pad) return fail(UNC_ERR_OVERFLOW, "read %u: more events than the room for event means holds (5/8 of its samples + 16)", i);
     for (uint32_t i = 0; i < n_reads; ++i) { means_offsets[i] = tot; tot += info[i].n_events; }
     means_offsets[n_reads] = tot;
     if (tot > means_cap) return fail(UNC_ERR_ARG, "means buffer too small: need %llu", (unsigned long long)tot);
@@ -1354,7 +1432,16 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     { const char *e = getenv("UNC_RT_PROFILE"); rt->profile = e && e[0] == '1'; }
     // wavefronts per channel (k_map_team): 8 unless UNC_RT_TEAM says 1 (the one-wavefront kernel), 2 or 4.  512 channels x 8 = the
     // 4096 wavefronts the chip holds; measured on E. coli thresholds, ms per round of 512 chunks: 110 / 102 / 90 / 84 with 1 / 2 / 4 / 8
-    { const char *e = getenv("UNC_RT_TEAM"); const long v = e ? atol(e) : 8; rt->team = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u; }
+    {
+        const char *e = getenv("UNC_RT_TEAM");
+#ifdef LANESIM
+        // the emulator suite's default (teams of 2: 512 fibers per emulated workgroup are three times the run time) is a variable only
+        // the emulator build reads, so that it cannot change what the gfx950 library does in the same process (round-4 advice)
+        if (!e) e = getenv("UNC_SIM_RT_TEAM");
+#endif
+        const long v = e ? atol(e) : 8;
+        rt->team = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u;
+    }
     const size_t S = n_channels;
     size_t bytes = 0;
     {
