@@ -29,11 +29,12 @@ def repeat_rich_masked(total, seed, n_contigs=3):
     codes = codes.copy()
     rng = np.random.default_rng(seed)
     q = total // 8
-    codes[q:q + 30000] = codes[3 * q:3 * q + 30000]                      # exact repeat, 30 kb
-    codes[5 * q:5 * q + 12000] = 3 - codes[2 * q:2 * q + 12000][::-1]    # inverted repeat
+    rep, inv, tan, hom = min(30000, q // 2), min(12000, q // 2), min(300, q // 2 // 53), min(5000, q // 4)
+    codes[q:q + rep] = codes[3 * q:3 * q + rep]                          # exact repeat (30 kb on the 2 Mb reference)
+    codes[5 * q:5 * q + inv] = 3 - codes[2 * q:2 * q + inv][::-1]        # inverted repeat
     unit = rng.integers(0, 4, 53).astype(np.uint8)
-    codes[6 * q:6 * q + 53 * 300] = np.tile(unit, 300)                   # tandem repeat
-    codes[7 * q:7 * q + 5000] = 0                                        # poly-A
+    codes[6 * q:6 * q + 53 * tan] = np.tile(unit, tan)                   # tandem repeat
+    codes[7 * q:7 * q + hom] = 0                                         # poly-A
     return names, lens, codes, holes, n_ambs
 
 

@@ -26,6 +26,10 @@ def test_events_and_normaliser(hip_lib, oracle_lib, example, goldens):
     pc.case_events_and_normaliser(hip_lib, oracle_lib, example, goldens)
 
 
+def test_events_of_the_reads_the_sweep_found_wrong(hip_lib, oracle_lib, example):
+    pc.case_events_sweep_reads(hip_lib, oracle_lib, example)
+
+
 def test_events_edge_cases(hip_lib, oracle_lib, example, goldens):
     pc.case_events_edge_cases(hip_lib, oracle_lib, example, goldens)
 

@@ -37,6 +37,42 @@ def smi():
         return {"smi_error": repr(e)[:80]}
 
 
+class Sampler:
+    """GPU clock / power / temperature from the hwmon files of card 0 every 0.25 s while a launch runs (a thread: no subprocess)."""
+    def __init__(self):
+        import glob
+        self.files = {}
+        for pat, key in (("freq1_input", "sclk_hz"), ("freq2_input", "mclk_hz"), ("power1_average", "power_uw"), ("power1_input", "power_uw"),
+                         ("temp2_input", "junction_mC"), ("temp1_input", "edge_mC")):
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/" + pat))[:1]:
+                self.files.setdefault(key, f)
+        self.rows, self.stop = [], False
+    def read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                out[k] = int(open(f).read().strip())
+            except Exception:      # noqa
+                pass
+        return out
+    def run(self):
+        import threading
+        self.rows, self.stop = [], False
+        def loop():
+            while not self.stop:
+                self.rows.append(self.read()); time.sleep(0.25)
+        self.t = threading.Thread(target=loop, daemon=True); self.t.start()
+    def end(self):
+        self.stop = True; self.t.join()
+        out = {"samples": len(self.rows)}
+        for k in self.files:
+            v = [r[k] for r in self.rows if k in r]
+            if v:
+                out[k] = {"mean": round(float(np.mean(v)), 1), "min": int(np.min(v)), "max": int(np.max(v))}
+        return out
+
+
+sampler = Sampler()
 pre, codes, lens = bench.ensure_index(Path("/tmp/uncalled_amd_bench"), 0, lambda: None, workload, "cuda:0")
 ix = capi.Index(pre)
 torch.cuda.empty_cache()
@@ -45,9 +81,11 @@ del codes
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 out = {"workload": workload, "reads": n, "legs": {}}
 first = None
-legs = [("pool_by_need", {})]
-if not os.environ.get("SPREAD_ONLY_NEED"):
-    legs.insert(0, ("pool_60pct_of_free", None))
+# SPREAD_LEGS: comma list of leg names; "fixed" = pool named explicitly (rounds 1-4's size), "auto" = sized by need, "fixed2" = a second
+# mapper with the named pool created after the first was freed (same process: does a mapper's PLACE in memory decide its speed?)
+legs = []
+for name in os.environ.get("SPREAD_LEGS", "fixed,auto").split(","):
+    legs.append((name, {} if name.startswith("auto") else None))
 for leg, kw in legs:
     torch.cuda.empty_cache()
     if kw is None:
@@ -60,12 +98,14 @@ for leg, kw in legs:
     m = capi.Mapper(ix, **kw)
     rows = []
     for i in range(launches):
+        sampler.run()
         t0 = time.perf_counter()
         hits = m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
         wall = time.perf_counter() - t0
+        during = sampler.end()
         free_b, tot_b = torch.cuda.mem_get_info()
-        row = {"launch": i, "k_map_ms": round(m.last_timing()[1], 1), "wall_s": round(wall, 2), "pool": m.pool_usage(), "remap": m.last_remap()[0],
-               "free_gb": round(free_b / 1e9, 1), "used_gb": round((tot_b - free_b) / 1e9, 1), "smi": smi()}
+        row = {"launch": i, "k_map_ms": round(m.last_timing()[1], 1), "wall_s": round(wall, 2), "wave_busy": round(m.last_wave_busy(), 4), "pool": m.pool_usage(), "remap": m.last_remap()[0], "during": during,
+               "free_gb": round(free_b / 1e9, 1), "used_gb": round((tot_b - free_b) / 1e9, 1), "smi": smi() if i == 0 else {}}
         if first is None:
             first = hits.copy()
             row["hits"] = "ref"

@@ -29,6 +29,20 @@ template <class P> __device__ __forceinline__ uint64_t ld8(P p) {
     return v;
 }
 
+// L2[c] for a per-lane c (0..4).  The table is five numbers that are the same for every lane (a kernel argument: scalar loads):
+// the lane's value is put together from guarded differences.  Indexing the table with the lane's c -- `ix.L2[c]` -- is a vector load
+// from the argument block, and the wide FM step did three of those ONE AFTER THE OTHER around its block loads (round 5, from the
+// ISA: global_load + s_waitcnt vmcnt(0) twice before the block words were even requested).
+template <class IX> __device__ __forceinline__ uint64_t fm_L2(const IX &ix, uint32_t c) {
+    const uint64_t l0 = ix.L2[0], l1 = ix.L2[1], l2 = ix.L2[2], l3 = ix.L2[3], l4 = ix.L2[4];
+    uint64_t v = l0;
+    v += c >= 1u ? l1 - l0 : 0ull;
+    v += c >= 2u ? l2 - l1 : 0ull;
+    v += c >= 3u ? l3 - l2 : 0ull;
+    v += c >= 4u ? l4 - l3 : 0ull;
+    return v;
+}
+
 struct FmBlock { uint4 q0, q1, q2, q3; };  // counts A,C | counts G,T | symbols 0..63 | symbols 64..127
 
 template <class IX> __device__ __forceinline__ FmBlock fm_load_block(const IX &ix, uint64_t kk) {
@@ -62,7 +76,7 @@ __device__ __forceinline__ uint32_t fm_block_rank(const FmBlock &b, uint64_t kk,
 
 // bwt_occ: occurrences of c in BWT rows [0..k] of the matrix that includes the sentinel row
 template <class IX> __device__ __forceinline__ uint64_t fm_occ(const IX &ix, uint64_t k, uint32_t c) {
-    if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
+    if (k == ix.seq_len) return fm_L2(ix, c + 1u) - fm_L2(ix, c);
     if (k == ~0ull) return 0;
     uint64_t kk = k - (k >= ix.primary ? 1 : 0);
     FmBlock b = fm_load_block(ix, kk);
@@ -124,7 +138,8 @@ template <class IX> __device__ __forceinline__ FmNbr fm_nbr_issue(const IX &ix, 
     q.c = c;
     q.k_plain = k != ix.seq_len && k != ~0ull; q.l_plain = l != ix.seq_len && l != ~0ull;
     q.kk = k - (k >= ix.primary ? 1 : 0); q.ll = l - (l >= ix.primary ? 1 : 0);
-    q.ok = k == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0; q.ol = l == ix.seq_len ? ix.L2[c + 1] - ix.L2[c] : 0;
+    const uint64_t nc = fm_L2(ix, c + 1u) - fm_L2(ix, c);      // occurrences of c in the whole text
+    q.ok = k == ix.seq_len ? nc : 0; q.ol = l == ix.seq_len ? nc : 0;
     q.shared = q.k_plain && q.l_plain && q.kk <= q.ll && (q.kk >> 7) == (q.ll >> 7);   // the words loaded for l serve k
     q.bl.cnt = 0; q.bl.lo = q.bl.hi = make_uint4(0u, 0u, 0u, 0u);
     q.bk = q.bl;
@@ -142,8 +157,9 @@ template <class IX> __device__ __forceinline__ void fm_nbr_finish(const IX &ix, 
         pk.hi = q.shared ? q.bl.hi : q.bk.hi;
         ok = fm_part_rank(pk, q.kk, q.c);
     }
-    *os = ix.L2[q.c] + ok + 1;
-    *oe = ix.L2[q.c] + ol;
+    const uint64_t l2c = fm_L2(ix, q.c);
+    *os = l2c + ok + 1;
+    *oe = l2c + ol;
 }
 template <class IX> __device__ __forceinline__ void fm_get_neighbor(const IX &ix, uint64_t s, uint64_t e, uint32_t c,
                                                 uint64_t *os, uint64_t *oe) {
@@ -184,6 +200,27 @@ template <class IX> __device__ __forceinline__ void fm32_get_neighbor(const IX &
     *oe = fm32_rank(cl, pl, xh, xl, ll);
 }
 
+// the same step in two halves, so that a caller can have two look-ups in flight (phase E: a pass with more than 64 candidates)
+struct Fm32Q { uint32_t cl, ck, kk, ll; uint4 pl, pk; };
+template <class IX> __device__ __forceinline__ Fm32Q fm32_nbr_issue(const IX &ix, uint32_t s, uint32_t e, uint32_t c) {
+    Fm32Q q;
+    const uint32_t primary = (uint32_t)ix.primary;
+    const uint32_t k = s - 1u, l = e;
+    q.kk = k - (k >= primary ? 1u : 0u); q.ll = l - (l >= primary ? 1u : 0u);
+    const uint32_t bk = q.kk >> 6, bl = q.ll >> 6;
+    const auto w = ix.fm32;
+    q.cl = w[(bl << 3) + c];
+    q.pl = ld16(w + (bl << 3) + 4u);
+    q.ck = q.cl; q.pk = q.pl;
+    if (bk != bl) { q.ck = w[(bk << 3) + c]; q.pk = ld16(w + (bk << 3) + 4u); }
+    return q;
+}
+__device__ __forceinline__ void fm32_nbr_finish(const Fm32Q &q, uint32_t c, uint32_t *os, uint32_t *oe) {
+    const uint32_t xh = (c & 2u) ? 0u : ~0u, xl = (c & 1u) ? 0u : ~0u;
+    *os = fm32_rank(q.ck, q.pk, xh, xl, q.kk) + 1u;
+    *oe = fm32_rank(q.cl, q.pl, xh, xl, q.ll);
+}
+
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps
 template <class IX> __device__ __forceinline__ uint64_t fm_sa(const IX &ix, uint64_t k, uint32_t *steps) {
     uint32_t n = 0;
@@ -196,7 +233,7 @@ template <class IX> __device__ __forceinline__ uint64_t fm_sa(const IX &ix, uint
         uint32_t word = j < 64 ? (j < 32 ? (j < 16 ? b.q2.x : b.q2.y) : (j < 48 ? b.q2.z : b.q2.w))
                                : (j < 96 ? (j < 80 ? b.q3.x : b.q3.y) : (j < 112 ? b.q3.z : b.q3.w));
         uint32_t c = (word >> ((~j & 15) << 1)) & 3;
-        k = ix.L2[c] + fm_block_count(b, c) + fm_block_rank(b, kk, c);
+        k = fm_L2(ix, c) + fm_block_count(b, c) + fm_block_rank(b, kk, c);
     }
     *steps = n;
     return (uint64_t)n + ix.sa[k >> 5];

@@ -70,6 +70,13 @@ __device__ __forceinline__ bool peak_detect(Detector &det, Detector *long_det, f
     return trk && b_emit;
 }
 
+// sqrt of a float, CORRECTLY ROUNDED (the reference's sqrt resolves to the float overload = one sqrtss, event_detector.cpp:218).
+// hipcc's __fsqrt_rn is NOT that unless OCML_BASIC_ROUNDED_OPERATIONS is defined: it is __ocml_native_sqrt_f32, the bare v_sqrt_f32 with
+// its 1 ulp of error (clang's __clang_hip_math.h) -- rounds 1-4 used it, and one read in seven thousand came out with an event more or
+// less than the reference detects (found by the 10 240-read parity sweeps of round 5: tests/dev/parity_sweep.py; pinned by
+// tests/golden/sweep_reads_r05.npz).  sqrtf() is lowered to v_sqrt_f32 + a two-FMA correction that is exact.
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+
 // ---- x / 3 and x / 6, correctly rounded, in three operations instead of the division sequence (a dozen dependent FP64
 // operations for a double).  With y = RN(1 / d):  q = RN(x * y);  r = x - d * q (one FMA: exact, q is within 2 ulp of x / d and r a
 // small multiple of ulp(q));  q' = RN(q + r * y).  The real number q + r * y differs from x / d by |r * y * eps| < 2^-50 ulp, and
@@ -130,7 +137,7 @@ __device__ __forceinline__ float tstat_ring(const double *sum, const double *sum
     float combined_var = (float)(((div_w<W, FAST>(sumsq1, bad) - (double)m1sq) + (double)q2) - (double)m2sq);
     combined_var = fmaxf(combined_var, FLT_MIN);
     float delta_mean = __fsub_rn(mean2, mean1);
-    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(div_w<W, FAST>(combined_var, bad)));
+    return __fdiv_rn(fabsf(delta_mean), sqrt_rn(div_w<W, FAST>(combined_var, bad)));
 }
 template <uint32_t W>
 __device__ __forceinline__ float tstat(const double *sum, const double *sumsq, int lane, uint32_t t, uint32_t buf_mid) {
@@ -161,7 +168,7 @@ __device__ __forceinline__ float tstat_win(const double *C, const double *Q, int
     float combined_var = (float)(((div_w<W, FAST>(sumsq1, bad) - (double)m1sq) + (double)q2) - (double)m2sq);
     combined_var = fmaxf(combined_var, FLT_MIN);
     float delta_mean = __fsub_rn(mean2, mean1);
-    return __fdiv_rn(fabsf(delta_mean), __fsqrt_rn(div_w<W, FAST>(combined_var, bad)));
+    return __fdiv_rn(fabsf(delta_mean), sqrt_rn(div_w<W, FAST>(combined_var, bad)));
 }
 
 struct EvRun {                        // what EventDetector carries from sample to sample

@@ -89,6 +89,9 @@ __device__ __forceinline__ void write_source(gptr_t buf, uint32_t idx, uint64_t 
 }
 
 
+#ifndef UNC_V_FM2
+#define UNC_V_FM2 0     // experiment switch (tools/dev/build_variants.py)
+#endif
 #ifndef UNC_LB
 #define UNC_LB 4     // wavefronts per SIMD: 128 VGPRs and under 10 KB of LDS each -> 16 per CU (12 -> 16: -12.6 % on 50 k E. coli reads)
 #endif
@@ -252,17 +255,21 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     // parent index list and record headers are fetched one / two passes ahead of their use
     uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
     uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
-    uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
+    u32x4_t q0c = {1u, 0u, 1u, 0u}, q1c = {0u, 0u, 0u, 0u};
     if ((uint32_t)lane < n_parents) {
-        q0c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
+        q0c = gld<u32x4_t>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<u32x4_t>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
     }
+    // (waited for HERE, once per event, and in every pass right behind the FM look-ups' wait -- where nothing else is in flight -- so
+    // that the top of a pass does not wait for the previous pass's stores to be acknowledged: wave_prims.h, mem_retire)
+    mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c);
+    uint32_t pend_cs = 0, pend_lo = 1, pend_hi = 1;     // narrow keys: a one-row child whose boundary test is still open (rows are >= 1)
     for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
         const uint32_t pi = base + (uint32_t)lane;
         const bool have = pi < n_parents;
-        const uint4 q0 = q0c, q1 = q1c;
+        const u32x4_t q0 = q0c, q1 = q1c;
         phys_cur = phys_nxt;
         if (pi + WAVE < n_parents) {
-            q0c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
+            q0c = gld<u32x4_t>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<u32x4_t>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
         }
         if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * WAVE) << 2));
         uint32_t pmoves = 0, pmeta = 0;
@@ -280,8 +287,8 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
         const bool pfull = plen == (uint32_t)SEED_LEN;
         const uint32_t okmer = (uint32_t)phist & KMASK;
-        float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
-        if (pfull) { const float4 row = g_load(model4 + okmer); o_mu = row.x; o_v2 = row.y; o_ld = row.z; }
+        // (requested by every lane, used by the full-window parents only: a load inside `if (pfull)` is waited for on the spot)
+        f32x4_t orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);
         const Row plen_fm = pend - pstart + 1;
         {
             // the merge of the children's keys relies on the survivors being in ascending (start, length) order: checked here
@@ -318,6 +325,24 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         wave_sync();
         clk.end(8, lane);
         // FM look-ups, every lane busy
+#if UNC_V_FM2
+        if (NARROW && ctot > (uint32_t)WAVE) {
+            if constexpr (NARROW) {
+                // more than 64 candidates (one pass in three): the look-ups of two rounds are requested together -- one memory round
+                // trip for up to 128 candidates instead of two in a row
+                for (uint32_t c0 = 0; c0 < ctot; c0 += 2 * WAVE) {
+                    const uint32_t ci0 = c0 + (uint32_t)lane, ci1 = ci0 + WAVE;
+                    const bool h0 = ci0 < ctot, h1 = ci1 < ctot;
+                    const uint32_t cd0 = h0 ? s_cand[ci0] : 0u, cd1 = h1 ? s_cand[ci1] : 0u;
+                    Fm32Q q0, q1;
+                    if (h0) q0 = fm32_nbr_issue(ix, s_pstart[cd0 >> 2], s_pend[cd0 >> 2], cd0 & 3u);
+                    if (h1) q1 = fm32_nbr_issue(ix, s_pstart[cd1 >> 2], s_pend[cd1 >> 2], cd1 & 3u);
+                    if (h0) { uint32_t ns, ne; fm32_nbr_finish(q0, cd0 & 3u, &ns, &ne); s_res[cd0] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull; }
+                    if (h1) { uint32_t ns, ne; fm32_nbr_finish(q1, cd1 & 3u, &ns, &ne); s_res[cd1] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull; }
+                }
+            }
+        } else
+#endif
         for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
             const uint32_t ci = c0 + (uint32_t)lane;
             if (ci < ctot) {
@@ -334,6 +359,8 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
             }
         }
         wave_sync();
+        // the FM look-ups have been waited for: everything requested before them has arrived as well
+        mem_retire(q0c); mem_retire(q1c); mem_retire(phys_nxt); mem_retire(orow);
         clk.end(9, lane);
         // children per parent, in the reference's order: stay, then bases 0..3
         // bit b: the step with base b was asked for and left a non-empty range (a lane's four result slots; the slots of
@@ -430,9 +457,9 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
             float subc = psub;
             uint64_t hist = phist;
             if (pfull) {
-                const float d = __fsub_rn(level_old, o_mu);
-                const double q = -((double)d * (double)d) / (double)o_v2;
-                subc = __fadd_rn(psub, (float)(q - (double)o_ld));
+                const float d = __fsub_rn(level_old, orow.x);
+                const double q = -((double)d * (double)d) / (double)orow.y;
+                subc = __fadd_rn(psub, (float)(q - (double)orow.z));
                 if ((pmoves >> (SEED_LEN - 2)) & 1u) {
                     const uint32_t cnt = (uint32_t)__popc(pmoves & ((1u << (SEED_LEN - 1)) - 1u));       // bases queued (>= 1 here)
                     const uint32_t pos = 2u * (cnt - 1u);
@@ -489,6 +516,17 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                     else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
                     ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
                 }
+                // narrow keys: the k-mer's own range, for the boundary test (see the sort): a one-row child on its first / last row.
+                // Requested before the child's stores and tested when this lane writes its NEXT child (or after the last pass): by then
+                // the load has long arrived, and no wait sits behind the four stores below
+                if constexpr (NARROW) {
+                    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;
+                    // (two 4-byte loads of exactly the words that are compared: with one 16-byte load the two unused registers of
+                    // the tuple are handed to the next instruction that needs one, which then has to wait for the load)
+                    pend_cs = cs == ce ? (uint32_t)cs : 0u;
+                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ck));
+                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ck) + 2);
+                }
                 SortKey key;
                 const uint32_t gi = nchild + li;
                 const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
@@ -500,11 +538,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                     const uint32_t run = (d >> 9) ? 5u : type;
                     gst(sb, str_off + run * run_bytes + ((uint32_t)s_ckpos[li] << 3), key.a);
                     gst(sb, info_off + (gi << 3), key.b);
-                    // the k-mer's own range, for the boundary test (see the sort): a one-row child on its first / last row
-                    if (cs == ce) {
-                        const ulonglong2 kr = g_load(kmer_ranges + ck);
-                        if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
-                    }
                 } else {
                     const bool csrc = base + pl >= n_surv_par;
                     const uint64_t wm = type == 0u ? wm0 : type == 1u ? wm1 : type == 2u ? wm2 : type == 3u ? wm3 : wm4;
@@ -521,6 +554,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     clk.end(1, lane);
     uint32_t tst = 0;
     if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
+    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;      // the last open boundary test
     const uint32_t anyb = __any(bchild) ? 1u : 0u;
     if (lane == 0) {
         s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.bchild = anyb; s_w.tstatus |= tst; s_w.par_unsorted = par_bad ? 1u : 0u;
@@ -570,10 +604,12 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
             const uint32_t x_off = str_off + 5u * run_bytes;
             uint32_t nviol = 0;
             SortClock sclk;
-            if (scnt1 > 1) { const uint32_t v = repair_run(sb, str_off + run_bytes, scnt1, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt1 -= v; nx += v; } }
-            if (scnt2 > 1) { const uint32_t v = repair_run(sb, str_off + 2u * run_bytes, scnt2, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt2 -= v; nx += v; } }
-            if (scnt3 > 1) { const uint32_t v = repair_run(sb, str_off + 3u * run_bytes, scnt3, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt3 -= v; nx += v; } }
-            if (scnt4 > 1) { const uint32_t v = repair_run(sb, str_off + 4u * run_bytes, scnt4, x_off, nx, lane); nviol += v; if constexpr (MERGE_REPAIR) { scnt4 -= v; nx += v; } }
+            if (scnt1 > 1 || scnt2 > 1 || scnt3 > 1 || scnt4 > 1) {
+                const uint64_t v4 = repair_runs4(sb, str_off, run_bytes, scnt1, scnt2, scnt3, scnt4, x_off, nx, lane);
+                const uint32_t v1 = (uint32_t)v4 & 0xFFFFu, v2 = (uint32_t)(v4 >> 16) & 0xFFFFu, v3 = (uint32_t)(v4 >> 32) & 0xFFFFu, v4r = (uint32_t)(v4 >> 48);
+                nviol = v1 + v2 + v3 + v4r;
+                if constexpr (MERGE_REPAIR) { scnt1 -= v1; scnt2 -= v2; scnt3 -= v3; scnt4 -= v4r; nx += nviol; }
+            }
             wave_sync();
             sclk.end(8, lane);
             if (MERGE_REPAIR || nviol == 0) {       // (test build without the repair: an event with such a pair takes the network below)

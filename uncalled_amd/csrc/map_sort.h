@@ -214,11 +214,18 @@ template <int R> struct KeyArr {
     uint32_t cum[R];    // first index of run r (cum[0] = 0)
     uint32_t n;
 };
-template <int R> __device__ __forceinline__ uint64_t ka_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
+// byte offset of element i: adj of the run it falls into.  Written as a sum of guarded DIFFERENCES on purpose.  The natural form
+// (a = i >= cum[r] ? adj[r] : a) is turned by the optimiser into a load of adj[selected index]: the array then lives in scratch
+// memory, every key load is preceded by a scratch load + s_waitcnt vmcnt(0), and the nine loads that stage a merge tile -- meant to
+// be ONE memory round trip -- became nine in a row (round 5, read off the ISA: 10-11 scratch loads in each merge function).
+template <int R> __device__ __forceinline__ uint32_t ka_adj(const KeyArr<R> &K, uint32_t i) {
     uint32_t a = K.adj[0];
 #pragma unroll
-    for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
-    return gld<uint64_t>(sb, a + (i << 3));
+    for (int r = 1; r < R; ++r) a += i >= K.cum[r] ? K.adj[r] - K.adj[r - 1] : 0u;
+    return a;
+}
+template <int R> __device__ __forceinline__ uint64_t ka_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
+    return gld<uint64_t>(sb, ka_adj(K, i) + (i << 3));
 }
 template <int R> __device__ __forceinline__ KeyArr<R> ka_uniform(const KeyArr<R> &K) {
     KeyArr<R> U;
@@ -518,6 +525,64 @@ static __device__ __noinline__ uint32_t repair_run(gptr_t sb_, uint32_t run_off_
         wave_sync();
     }
     return shift;
+}
+
+// The four runs of moves repaired TOGETHER: chunk j of every run is requested before any of them is looked at, so that the repair
+// costs one memory round trip per 64 keys of the LONGEST run instead of one per 64 keys of every run, one run after the other
+// (repair_run above, called four times, was 12 dependent round trips for four runs of 180 keys: 3 % of k_map).  Per run the logic is
+// repair_run's; the misfits of all runs go to the unsorted run in whatever order the chunks come (it is sorted afterwards).
+// Returns the number of keys taken out of run r in bits 16 (r - 1) .. 16 r - 1 (r = 1..4).
+static __device__ __noinline__ uint64_t repair_runs4(gptr_t sb_, uint32_t str_off_, uint32_t run_bytes_, uint32_t n1_, uint32_t n2_, uint32_t n3_, uint32_t n4_,
+                                                     uint32_t x_off_, uint32_t nx_, int lane) {
+    const gptr_t sb = uniform_ptr(sb_);
+    const uint32_t str_off = uniform32(str_off_), run_bytes = uniform32(run_bytes_), x_off = uniform32(x_off_);
+    const uint32_t n[4] = {uniform32(n1_), uniform32(n2_), uniform32(n3_), uniform32(n4_)};
+    uint32_t nx = uniform32(nx_);
+    uint32_t shift[4] = {0, 0, 0, 0};
+    uint64_t carry[4] = {0, 0, 0, 0};          // the largest key of the run so far (keys are > 0)
+    uint32_t nmax = n[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) nmax = n[r] > nmax ? n[r] : nmax;
+    for (uint32_t c0 = 0; c0 < nmax; c0 += WAVE) {
+        const uint32_t i = c0 + (uint32_t)lane;
+        uint64_t kk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)          // (a run of one key needs no repair, and is not touched)
+            kk[r] = (n[r] > 1u && i < n[r]) ? gld<uint64_t>(sb, str_off + (uint32_t)(r + 1) * run_bytes + (i << 3)) : 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n[r] <= 1u || c0 >= n[r]) continue;
+            const uint32_t run_off = str_off + (uint32_t)(r + 1) * run_bytes;
+            const bool have = i < n[r];
+            const uint64_t k = kk[r];
+            uint64_t pk = (uint64_t)__shfl_up((unsigned long long)k, 1);
+            if (lane == 0) pk = carry[r];
+            bool viol = have && k < pk;
+            const uint32_t nvalid = n[r] - c0 < (uint32_t)WAVE ? n[r] - c0 : (uint32_t)WAVE;
+            if (__any(viol)) {
+                const uint64_t inc = seg_incl_max64(k, lane == 0);
+                uint64_t ex = (uint64_t)__shfl_up((unsigned long long)inc, 1);
+                if (lane == 0) ex = 0;
+                if (ex < carry[r]) ex = carry[r];
+                viol = have && k < ex;
+                const uint64_t top = bcast64(inc, WAVE - 1);
+                if (top > carry[r]) carry[r] = top;
+            } else carry[r] = bcast64(k, (int)nvalid - 1);
+            const uint64_t vm = __ballot(viol);
+            if (vm == 0 && shift[r] == 0) continue;
+            if constexpr (!MERGE_REPAIR) { shift[r] += (uint32_t)__popcll(vm); continue; }      // (test build: count, leave in place)
+            wave_sync();
+            const uint32_t before = (uint32_t)prefix_popc(vm);
+            if (have) {
+                if (viol) gst(sb, x_off + ((nx + before) << 3), k);
+                else gst(sb, run_off + ((i - shift[r] - before) << 3), k);      // (below what the next chunk of this run reads)
+            }
+            const uint32_t nv = (uint32_t)__popcll(vm);
+            shift[r] += nv; nx += nv;
+            wave_sync();
+        }
+    }
+    return (uint64_t)shift[0] | ((uint64_t)shift[1] << 16) | ((uint64_t)shift[2] << 32) | ((uint64_t)shift[3] << 48);
 }
 
 }  // namespace unc

@@ -152,6 +152,33 @@ __device__ __forceinline__ uint64_t xor_lane64(uint64_t v, uint32_t d) {
     return (uint64_t)__shfl_xor((unsigned long long)v, (int)d);
 }
 
+// ---- where the wavefront waits for memory.  The compiler places s_waitcnt at the first USE of a loaded register, and when the number
+// of memory operations issued since the load is not known at compile time (a loop, a branch around another load or store) the wait
+// it emits is vmcnt(0): for EVERYTHING outstanding, the stores just issued included (a store's acknowledgement takes as long as a
+// load).  Read off the ISA in round 5: the "prefetched" parent records of phase E, the info words of the walk and the staged merge
+// tiles were each waited for with vmcnt(0) at a point where fresh loads or stores were in flight, so that every pass paid three or
+// four memory round trips in a row instead of one.  mem_retire() is an empty asm statement that USES the value: put where the
+// memory counter is zero anyway (right after a wait that cannot be avoided), it tells the compiler's bookkeeping that the value has
+// arrived, and the later use costs no wait.  No instruction is emitted.  (The emulator needs none of it.)
+// (16-byte values as ONE register tuple: an asm operand per component makes the compiler copy the components out of the tuple right
+// behind the load, which is a use, which is a wait)
+#ifdef LANESIM
+typedef uint4 u32x4_t;
+typedef float4 f32x4_t;
+template <class T> __device__ __forceinline__ void mem_retire(T &) {}
+#else
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mem_retire(u32x4_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void mem_retire(f32x4_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void mem_retire(uint32_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void mem_retire(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void mem_retire(uint64_t &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void mem_retire(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void mem_retire(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void mem_retire(ulonglong2 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+#endif
+
 // Address spaces are spelled out wherever a pointer travels through a function call: a generic pointer that the compiler
 // cannot trace to its origin costs FLAT instructions (no scalar base, both memory counters), a kernel argument read through
 // a generic pointer costs vector loads.  (The CPU emulator of tests/ defines both markers empty.)
