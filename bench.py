@@ -289,8 +289,10 @@ def a_reads(a, workload):
 def measured_traffic(a, workload):
     """HBM bytes per launch of k_map from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected
     from inside this process): used only when they were taken on this workload and batch size, else null."""
-    pmc = ROOT / "profiles" / f"r04_pmc_k_map_{workload}.json"
-    if not pmc.exists():
+    # the newest committed pass of this workload: round 5 (E. coli: the kernel of this round), else round 4 (chr20 / GRCh38: the passes
+    # cost six index builds; records, keys and info words -- what the traffic consists of -- are unchanged since)
+    pmc = next((f for f in (ROOT / "profiles" / f"r05_pmc_k_map_{workload}.json", ROOT / "profiles" / f"r04_pmc_k_map_{workload}.json") if f.exists()), None)
+    if pmc is None:
         return None, "no PMC pass committed for this kernel"
     d = json.loads(pmc.read_text())
     if d.get("workload") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload):
@@ -304,8 +306,8 @@ def measured_traffic(a, workload):
 def issue_roofline(a, workload, launch_ms, clock_hz):
     """Issue side of k_map: wave-instructions of one launch (SQ_INSTS of the committed rocprofv3 pass on this workload and batch
     size -- the count is a property of kernel + batch, the duration is this run's) / (1024 SIMDs x clock x launch time)."""
-    sq = ROOT / "profiles" / f"r04_pmc_sq_summary_{workload}.json"
-    if not sq.exists():
+    sq = next((f for f in (ROOT / "profiles" / f"r05_pmc_sq_summary_{workload}.json", ROOT / "profiles" / f"r04_pmc_sq_summary_{workload}.json") if f.exists()), None)
+    if sq is None:
         return None
     d = json.loads(sq.read_text())
     insts = d.get("counters", {}).get("SQ_INSTS")
@@ -319,6 +321,9 @@ def issue_roofline(a, workload, launch_ms, clock_hz):
            "per_read": {k[:-9]: round(v) for k, v in d.get("derived", {}).items() if k.endswith("_per_read")}}
     if c.get("SQ_INSTS_VALU"):
         out["valu_utilisation"] = c["SQ_INSTS_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
+    if c.get("SQ_ACTIVE_INST_VALU"):
+        # a wave64 VALU instruction holds its SIMD for 4 cycles and SQ_ACTIVE_INST_VALU counts those quad-cycles: how busy the vector ALUs are
+        out["valu_pipe_busy"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
     return out
 
 

@@ -216,8 +216,9 @@ void unc_mapper_set_profile(unc_mapper_t *m, int on);
 void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5);
 /* The seed-cluster node pool is sized by need.  The reference's SeedTracker is an unbounded std::set per Mapper
  * (src/seed_tracker.hpp:97-110); here its nodes come from ONE pool per mapper.  unc_mapper_create sizes the pool by a rule of
- * thumb for the first batch; after every batch the library keeps it at twice the most chunks (192 KB each) that were ever out at
- * once, never below one chunk per slot, doubling it when a batch found it dry (unless unc_mapper_opts_t.pool_chunks named a size).
+ * thumb for the first batch; after a batch that used less than an eighth of it the library shrinks it to four times the most chunks
+ * (192 KB each) that were ever out at once, never below one chunk per slot, and doubles it when a batch found it dry (unless
+ * unc_mapper_opts_t.pool_chunks named a size).
  * out4: [0] chunks the pool holds now, [1] high-water mark of the last batch, [2] of all batches, [3] times it was resized. */
 int unc_mapper_pool_usage(const unc_mapper_t *m, uint32_t *out4);
 /* reads of the last batch that found the seed-cluster node pool dry (or used up their own allowance) and were mapped again

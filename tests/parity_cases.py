@@ -611,16 +611,19 @@ def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2,
     assert u["chunks"] == pool_chunks and u["resizes"] == 0 and u["high_water_ever"] == pool_chunks          # it ran dry: every chunk was out
     u3 = m3.pool_usage()
     assert u3["chunks"] == 64 and 0 < u3["high_water_last_batch"] <= 3 * n_waves and u3["resizes"] == 0      # at most a chunk per read in flight here
-    # ... the default starts from the rule of thumb and is then kept at twice the most chunks that were out at once (never below
-    # one per slot / 16): the first batch shrinks it, the second finds it sized and leaves it; answers unchanged
+    # ... the default starts from the rule of thumb and is then cut to four times the most chunks that were out at once when it holds more than eight times that (never below
+    # one per slot / 16; four times, since round 5 saw one batch's peak move by tens of per cent between launches): the first batch shrinks it, the second finds it sized and leaves it; answers unchanged
     m5 = capi.Mapper(dev_index, n_slots=3 * n_waves, n_waves=n_waves, slice_events=60)
     before = m5.geometry()["pool_chunks"]
     hits5 = m5.map_batch(raw, off, cal)
     u5 = m5.pool_usage()
-    assert before > 16 and u5["chunks"] == max(16, 2 * u5["high_water_ever"]) and u5["resizes"] == 1 and m5.last_remap()[0] == 0
+    need = max(16, 4 * u5["high_water_ever"])
+    shrunk = 2 * need < before
+    assert before > 16 and u5["chunks"] == (need if shrunk else before) and u5["resizes"] == (1 if shrunk else 0) and m5.last_remap()[0] == 0
+    assert shrunk or n_waves == 1                    # (the smallest geometry starts below twice its need and stays as it is)
     assert u5["high_water_last_batch"] == u3["high_water_last_batch"]
     hits6 = m5.map_batch(raw, off, cal)
-    assert m5.pool_usage()["resizes"] == 1 and m5.pool_usage()["chunks"] == u5["chunks"] and m5.last_remap()[0] == 0
+    assert m5.pool_usage()["resizes"] == u5["resizes"] and m5.pool_usage()["chunks"] == u5["chunks"] and m5.last_remap()[0] == 0
     for name in capi.RESULT_FIELDS:
         assert np.array_equal(hits[name], hits5[name]) and np.array_equal(hits[name], hits6[name]), name
 

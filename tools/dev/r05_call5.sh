@@ -1,0 +1,4 @@
+#!/bin/bash
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r05; mkdir -p $OUT
+V=uncalled_amd/variants
+AB_NOPROF=1 AB_RUNS=3 timeout 1500 python tools/dev/ab_libs.py 50000:grch38 $V/libunc_base.so uncalled_amd/libuncalled_hip.so $V/libunc_l2tab.so $V/libunc_mwold.so $V/libunc_jit.so uncalled_amd/libuncalled_hip.so@0@768 $V/libunc_base.so > $OUT/ab_grch38_2.log 2>&1; grep -v "^{" $OUT/ab_grch38_2.log | tail -9

@@ -41,15 +41,28 @@ g = tot.get
 der = {}
 if g("SQ_WAVE_CYCLES"):
     wc = g("SQ_WAVE_CYCLES")
-    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS"):
+    # (SQ_ACTIVE_INST_VMEM read 0.0 in every pass of rounds 3-4 -- a dead counter on this build -- and is no longer reported)
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):
         if g(k) is not None:
             der["wave_cycle_share_" + k[3:].lower()] = g(k) / wc
+    if g("SQ_INST_LEVEL_VMEM") is not None:
+        # vector-memory instructions in flight, summed over cycles: per wave-cycle = how many a wavefront has outstanding on average
+        # while it is resident -- the direct witness of "waiting on memory" (SQ_WAIT_ANY counts every kind of wait)
+        der["vmem_in_flight_per_wave_cycle"] = g("SQ_INST_LEVEL_VMEM") / (4.0 * wc)
+        der["vmem_in_flight_note"] = "SQ_INST_LEVEL_VMEM / (4 x SQ_WAVE_CYCLES): the level counts per cycle, the wave cycles per quad-cycle"
 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_FLAT",
           "SQ_INSTS_BRANCH", "SQ_INSTS", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"):
     if g(k) is not None:
         der[k[3:].lower() + "_per_read"] = g(k) / reads
 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INST_CYCLES_VALU"):
     der["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INST_CYCLES_VALU"))
+# how busy the vector ALUs are: a wave64 VALU instruction occupies its SIMD for 4 cycles, and SQ_ACTIVE_INST_VALU counts exactly
+# those quad-cycles -- so VALU-busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clock x duration).  (Round 5: this, not the 22 % of
+# "issue slots", is the number that says how far k_map is from being ALU-bound.)
+for name, p in passes.items():
+    if "SQ_ACTIVE_INST_VALU" in p["counters"] and p["k_map_ms_under_pmc"]:
+        ms = sum(p["k_map_ms_under_pmc"])
+        der["valu_pipe_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (1024 * 2.4e9 * ms * 1e-3)
 # issue utilisation: wave-instructions / (1024 SIMDs x clock x k_map's duration in the pass that counted them); the clock is
 # the 2.4 GHz peak engine clock (MI355X_MICROARCH.md), so this is a lower bound on the share of issue slots used
 CLOCK_HZ, SIMDS = 2.4e9, 1024

@@ -328,7 +328,7 @@ class Mapper:
 
     def pool_usage(self):
         """Seed-cluster node pool: chunks (192 KB each) held now, high-water mark of chunks out at once in the last batch / ever,
-        times the library resized it (the pool is kept at twice the high-water mark; include/uncalled_hip.h)."""
+        times the library resized it (cut to four times the high-water mark when it holds more than eight times that, doubled when found dry; include/uncalled_hip.h)."""
         if not hasattr(self.L, "unc_mapper_pool_usage"):
             return None
         out = np.zeros(4, dtype=np.uint32)

@@ -29,19 +29,11 @@ template <class P> __device__ __forceinline__ uint64_t ld8(P p) {
     return v;
 }
 
-// L2[c] for a per-lane c (0..4).  The table is five numbers that are the same for every lane (a kernel argument: scalar loads):
-// the lane's value is put together from guarded differences.  Indexing the table with the lane's c -- `ix.L2[c]` -- is a vector load
-// from the argument block, and the wide FM step did three of those ONE AFTER THE OTHER around its block loads (round 5, from the
-// ISA: global_load + s_waitcnt vmcnt(0) twice before the block words were even requested).
-template <class IX> __device__ __forceinline__ uint64_t fm_L2(const IX &ix, uint32_t c) {
-    const uint64_t l0 = ix.L2[0], l1 = ix.L2[1], l2 = ix.L2[2], l3 = ix.L2[3], l4 = ix.L2[4];
-    uint64_t v = l0;
-    v += c >= 1u ? l1 - l0 : 0ull;
-    v += c >= 2u ? l2 - l1 : 0ull;
-    v += c >= 3u ? l3 - l2 : 0ull;
-    v += c >= 4u ? l4 - l3 : 0ull;
-    return v;
-}
+// L2[c] for a per-lane c (0..4): a vector load from the kernel's argument block (the table is five numbers).  Round 5 tried the value
+// put together from guarded differences of five scalars instead -- no load, so that the wide FM step does not wait for the table
+// before it requests its blocks -- and measured it 2.6 % SLOWER on GRCh38 (profiles/r05_ab_grch38_wide_variants.log): the table is
+// L1-resident, the sixteen extra 64-bit selects per call are not free in a kernel whose vector ALUs are half busy.
+template <class IX> __device__ __forceinline__ uint64_t fm_L2(const IX &ix, uint32_t c) { return ix.L2[c]; }
 
 struct FmBlock { uint4 q0, q1, q2, q3; };  // counts A,C | counts G,T | symbols 0..63 | symbols 64..127
 
@@ -198,27 +190,6 @@ template <class IX> __device__ __forceinline__ void fm32_get_neighbor(const IX &
     const uint32_t xh = (c & 2u) ? 0u : ~0u, xl = (c & 1u) ? 0u : ~0u;     // plane word ^ x: bit set where the symbol's bit equals c's
     *os = fm32_rank(ck, pk, xh, xl, kk) + 1u;
     *oe = fm32_rank(cl, pl, xh, xl, ll);
-}
-
-// the same step in two halves, so that a caller can have two look-ups in flight (phase E: a pass with more than 64 candidates)
-struct Fm32Q { uint32_t cl, ck, kk, ll; uint4 pl, pk; };
-template <class IX> __device__ __forceinline__ Fm32Q fm32_nbr_issue(const IX &ix, uint32_t s, uint32_t e, uint32_t c) {
-    Fm32Q q;
-    const uint32_t primary = (uint32_t)ix.primary;
-    const uint32_t k = s - 1u, l = e;
-    q.kk = k - (k >= primary ? 1u : 0u); q.ll = l - (l >= primary ? 1u : 0u);
-    const uint32_t bk = q.kk >> 6, bl = q.ll >> 6;
-    const auto w = ix.fm32;
-    q.cl = w[(bl << 3) + c];
-    q.pl = ld16(w + (bl << 3) + 4u);
-    q.ck = q.cl; q.pk = q.pl;
-    if (bk != bl) { q.ck = w[(bk << 3) + c]; q.pk = ld16(w + (bk << 3) + 4u); }
-    return q;
-}
-__device__ __forceinline__ void fm32_nbr_finish(const Fm32Q &q, uint32_t c, uint32_t *os, uint32_t *oe) {
-    const uint32_t xh = (c & 2u) ? 0u : ~0u, xl = (c & 1u) ? 0u : ~0u;
-    *os = fm32_rank(q.ck, q.pk, xh, xl, q.kk) + 1u;
-    *oe = fm32_rank(q.cl, q.pl, xh, xl, q.ll);
 }
 
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps

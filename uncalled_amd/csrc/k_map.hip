@@ -89,9 +89,6 @@ __device__ __forceinline__ void write_source(gptr_t buf, uint32_t idx, uint64_t 
 }
 
 
-#ifndef UNC_V_FM2
-#define UNC_V_FM2 0     // experiment switch (tools/dev/build_variants.py)
-#endif
 #ifndef UNC_LB
 #define UNC_LB 4     // wavefronts per SIMD: 128 VGPRs and under 10 KB of LDS each -> 16 per CU (12 -> 16: -12.6 % on 50 k E. coli reads)
 #endif
@@ -255,21 +252,23 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     // parent index list and record headers are fetched one / two passes ahead of their use
     uint32_t phys_cur = (uint32_t)lane < n_parents ? gld<uint32_t>(sb, pord_off + ((uint32_t)lane << 2)) : 0u;
     uint32_t phys_nxt = (uint32_t)lane + WAVE < n_parents ? gld<uint32_t>(sb, pord_off + (((uint32_t)lane + WAVE) << 2)) : 0u;
-    u32x4_t q0c = {1u, 0u, 1u, 0u}, q1c = {0u, 0u, 0u, 0u};
+    using Q4 = std::conditional_t<NARROW, u32x4_t, uint4>;     // (one register tuple for mem_retire; the wide instantiation as it was)
+    Q4 q0c = Q4{1u, 0u, 1u, 0u}, q1c = Q4{0u, 0u, 0u, 0u};
     if ((uint32_t)lane < n_parents) {
-        q0c = gld<u32x4_t>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<u32x4_t>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
+        q0c = gld<Q4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<Q4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
     }
     // (waited for HERE, once per event, and in every pass right behind the FM look-ups' wait -- where nothing else is in flight -- so
-    // that the top of a pass does not wait for the previous pass's stores to be acknowledged: wave_prims.h, mem_retire)
-    mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c);
+    // that the top of a pass does not wait for the previous pass's stores to be acknowledged: wave_prims.h, mem_retire.  Narrow keys
+    // only: the wide instantiation sits at its register limit, and the same changes cost it 7 % on GRCh38, r05_ab_grch38_3.log)
+    if constexpr (NARROW) { mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c); }
     uint32_t pend_cs = 0, pend_lo = 1, pend_hi = 1;     // narrow keys: a one-row child whose boundary test is still open (rows are >= 1)
     for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
         const uint32_t pi = base + (uint32_t)lane;
         const bool have = pi < n_parents;
-        const u32x4_t q0 = q0c, q1 = q1c;
+        const Q4 q0 = q0c, q1 = q1c;
         phys_cur = phys_nxt;
         if (pi + WAVE < n_parents) {
-            q0c = gld<u32x4_t>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<u32x4_t>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
+            q0c = gld<Q4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<Q4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
         }
         if (pi + 2 * WAVE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * WAVE) << 2));
         uint32_t pmoves = 0, pmeta = 0;
@@ -287,8 +286,11 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
         const bool pfull = plen == (uint32_t)SEED_LEN;
         const uint32_t okmer = (uint32_t)phist & KMASK;
-        // (requested by every lane, used by the full-window parents only: a load inside `if (pfull)` is waited for on the spot)
-        f32x4_t orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);
+        // (requested by every lane -- a load inside `if (pfull)` is waited for on the spot -- but the lanes that do not need a row all
+        // ask for row 0: one address, one request)
+        f32x4_t orow = {0.f, 1.f, 0.f, 0.f};
+        if constexpr (NARROW) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + (pfull ? okmer : 0u));
+        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see below)
         const Row plen_fm = pend - pstart + 1;
         {
             // the merge of the children's keys relies on the survivors being in ascending (start, length) order: checked here
@@ -325,24 +327,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         wave_sync();
         clk.end(8, lane);
         // FM look-ups, every lane busy
-#if UNC_V_FM2
-        if (NARROW && ctot > (uint32_t)WAVE) {
-            if constexpr (NARROW) {
-                // more than 64 candidates (one pass in three): the look-ups of two rounds are requested together -- one memory round
-                // trip for up to 128 candidates instead of two in a row
-                for (uint32_t c0 = 0; c0 < ctot; c0 += 2 * WAVE) {
-                    const uint32_t ci0 = c0 + (uint32_t)lane, ci1 = ci0 + WAVE;
-                    const bool h0 = ci0 < ctot, h1 = ci1 < ctot;
-                    const uint32_t cd0 = h0 ? s_cand[ci0] : 0u, cd1 = h1 ? s_cand[ci1] : 0u;
-                    Fm32Q q0, q1;
-                    if (h0) q0 = fm32_nbr_issue(ix, s_pstart[cd0 >> 2], s_pend[cd0 >> 2], cd0 & 3u);
-                    if (h1) q1 = fm32_nbr_issue(ix, s_pstart[cd1 >> 2], s_pend[cd1 >> 2], cd1 & 3u);
-                    if (h0) { uint32_t ns, ne; fm32_nbr_finish(q0, cd0 & 3u, &ns, &ne); s_res[cd0] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull; }
-                    if (h1) { uint32_t ns, ne; fm32_nbr_finish(q1, cd1 & 3u, &ns, &ne); s_res[cd1] = ns <= ne ? ((uint64_t)(ne - ns + 1u) << 32) | ns : 0ull; }
-                }
-            }
-        } else
-#endif
         for (uint32_t c0 = 0; c0 < ctot; c0 += WAVE) {
             const uint32_t ci = c0 + (uint32_t)lane;
             if (ci < ctot) {
@@ -360,7 +344,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         }
         wave_sync();
         // the FM look-ups have been waited for: everything requested before them has arrived as well
-        mem_retire(q0c); mem_retire(q1c); mem_retire(phys_nxt); mem_retire(orow);
+        if constexpr (NARROW) { mem_retire(q0c); mem_retire(q1c); mem_retire(phys_nxt); mem_retire(orow); }
         clk.end(9, lane);
         // children per parent, in the reference's order: stay, then bases 0..3
         // bit b: the step with base b was asked for and left a non-empty range (a lane's four result slots; the slots of
@@ -524,8 +508,9 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                     // (two 4-byte loads of exactly the words that are compared: with one 16-byte load the two unused registers of
                     // the tuple are handed to the next instruction that needs one, which then has to wait for the load)
                     pend_cs = cs == ce ? (uint32_t)cs : 0u;
-                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ck));
-                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ck) + 2);
+                    const uint32_t ckq = cs == ce ? ck : 0u;           // (the others all ask for entry 0: one address, one request)
+                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq));
+                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq) + 2);
                 }
                 SortKey key;
                 const uint32_t gi = nchild + li;
@@ -1626,19 +1611,23 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
     const uint32_t pi0 = (uint32_t)wave * WAVE + (uint32_t)lane;
     uint32_t phys_cur = pi0 < n_parents ? gld<uint32_t>(sb, pord_off + (pi0 << 2)) : 0u;
     uint32_t phys_nxt = pi0 + PSTRIDE < n_parents ? gld<uint32_t>(sb, pord_off + ((pi0 + PSTRIDE) << 2)) : 0u;
-    uint4 q0c = make_uint4(1u, 0u, 1u, 0u), q1c = make_uint4(0u, 0u, 0u, 0u);
+    using Q4 = std::conditional_t<NARROW, u32x4_t, uint4>;     // (one register tuple for mem_retire; the wide instantiation as it was)
+    Q4 q0c = Q4{1u, 0u, 1u, 0u}, q1c = Q4{0u, 0u, 0u, 0u};
     if (pi0 < n_parents) {
-        q0c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
+        q0c = gld<Q4>(sb, par_off + (phys_cur << PATH_SHIFT)); q1c = gld<Q4>(sb, par_off + (phys_cur << PATH_SHIFT) + 16u);
     }
+    // (where the waits of a round sit: see phase_E and wave_prims.h, mem_retire)
+    if constexpr (NARROW) { mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c); }
+    uint32_t pend_cs = 0, pend_lo = 1, pend_hi = 1;     // narrow keys: a one-row child whose boundary test is still open
     PhaseClock<PROF> clk;       // (the leader's view of a round: 8 parents + candidates, 9 FM, 10 slots, 11 the wait at the exchange, 1 children)
     for (uint32_t rbase = 0, rnd = 0; rbase < n_parents && TT.nchild < max_paths; rbase += PSTRIDE, ++rnd) {
         const uint32_t base = rbase + (uint32_t)wave * WAVE;
         const uint32_t pi = base + (uint32_t)lane;
         const bool have = pi < n_parents;
-        const uint4 q0 = q0c, q1 = q1c;
+        const Q4 q0 = q0c, q1 = q1c;
         phys_cur = phys_nxt;
         if (pi + PSTRIDE < n_parents) {
-            q0c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<uint4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
+            q0c = gld<Q4>(sb, par_off + (phys_nxt << PATH_SHIFT)); q1c = gld<Q4>(sb, par_off + (phys_nxt << PATH_SHIFT) + 16u);
         }
         if (pi + 2 * PSTRIDE < n_parents) phys_nxt = gld<uint32_t>(sb, pord_off + ((pi + 2 * PSTRIDE) << 2));
         uint32_t pmoves = 0, pmeta = 0;
@@ -1654,8 +1643,9 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         const uint32_t plen = (pmeta >> META_LEN_SHIFT) & 31u;
         const bool pfull = plen == (uint32_t)SEED_LEN;
         const uint32_t okmer = (uint32_t)phist & KMASK;
-        float o_mu = 0.f, o_v2 = 1.f, o_ld = 0.f;
-        if (pfull) { const float4 row = g_load(model4 + okmer); o_mu = row.x; o_v2 = row.y; o_ld = row.z; }
+        f32x4_t orow = {0.f, 1.f, 0.f, 0.f};
+        if constexpr (NARROW) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + (pfull ? okmer : 0u));
+        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see below)
         const Row plen_fm = pend - pstart + 1;
         // the merge of the children's keys relies on the survivors being in ascending (start, length) order: inside the pass here,
         // across passes after the exchange
@@ -1703,6 +1693,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             }
         }
         wave_sync();
+        if constexpr (NARROW) { mem_retire(q0c); mem_retire(q1c); mem_retire(phys_nxt); mem_retire(orow); }      // (behind the FM look-ups' wait: arrived)
         if (wave == 0) clk.end(9, lane);
         // ---- the pass's children as if nothing were cut off: who, where in the pass, where among the pass's keys of its run
         const uint32_t rb = (uint32_t)lane << 2;
@@ -1755,9 +1746,9 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
             float subc = psub;
             uint64_t hist = phist;
             if (pfull) {
-                const float d = __fsub_rn(level_old, o_mu);
-                const double q = -((double)d * (double)d) / (double)o_v2;
-                subc = __fadd_rn(psub, (float)(q - (double)o_ld));
+                const float d = __fsub_rn(level_old, orow.x);
+                const double q = -((double)d * (double)d) / (double)orow.y;
+                subc = __fadd_rn(psub, (float)(q - (double)orow.z));
                 if ((pmoves >> (SEED_LEN - 2)) & 1u) {
                     const uint32_t cnt = (uint32_t)__popc(pmoves & ((1u << (SEED_LEN - 1)) - 1u));
                     const uint32_t pos = 2u * (cnt - 1u);
@@ -1872,6 +1863,13 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                     else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
                     ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
                 }
+                if constexpr (NARROW) {      // the boundary test of this lane's previous one-row child; this child's k-mer range requested
+                    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;
+                    pend_cs = cs == ce ? (uint32_t)cs : 0u;
+                    const uint32_t ckq = cs == ce ? ck : 0u;           // (the others all ask for entry 0: one address, one request)
+                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq));
+                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq) + 2);
+                }
                 SortKey key;
                 const uint32_t gi = b_child + li;
                 const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
@@ -1884,10 +1882,6 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                     const uint32_t kb = run == 0u ? b_m[0] : run == 1u ? b_m[1] : run == 2u ? b_m[2] : run == 3u ? b_m[3] : run == 4u ? b_m[4] : b_x;
                     gst(sb, str_off + run * run_bytes + ((kb + (uint32_t)s_ckpos[li]) << 3), key.a);
                     gst(sb, info_off + (gi << 3), key.b);
-                    if (cs == ce) {
-                        const ulonglong2 kr = g_load(kmer_ranges + ck);
-                        if (cs == (uint32_t)kr.x || cs == (uint32_t)kr.y) bchild = true;
-                    }
                 } else {
                     // wide keys: no room for a position per child in the staging -- from the masks, and for the children of sources
                     // (the tail of the pass in creation order) from where that tail begins
@@ -1934,6 +1928,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         if (wave == 0) clk.end(1, lane);
     }
     // what the leader needs of the followers: flags, their share of the work counter
+    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;      // the last open boundary test
     const uint32_t fl = (__any(bchild) ? 1u : 0u) | (par_bad ? 2u : 0u) | (__any(seed_over) ? 4u : 0u);
     if (wave != 0) {
         const uint64_t tot = wave_sum64((uint64_t)c_nbr);

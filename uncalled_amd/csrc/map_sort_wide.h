@@ -13,7 +13,12 @@ __device__ __forceinline__ SortKey wk_bcast(const SortKey &k, int src) { SortKey
 
 // a sequence of R runs of 16-byte keys back to back (adj: byte offset of run r inside the slot minus 16 * its first index)
 template <int R> __device__ __forceinline__ SortKey kaw_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
-    return gld<SortKey>(sb, ka_adj(K, i) + (i << 4));
+    // (the select chain of rounds 3-4, NOT map_sort.h's ka_adj: the optimiser keeps `adj` in scratch memory for it, and yet every attempt of
+    // round 5 to take scratch accesses or table loads out of the wide instantiation made GRCh38 slower -- the narrow one gained 11 %)
+    uint32_t a = K.adj[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
+    return gld<SortKey>(sb, a + (i << 4));
 }
 __device__ __forceinline__ KeyArr<1> kaw_single(uint32_t off, uint32_t n) { KeyArr<1> K; K.adj[0] = off; K.cum[0] = 0; K.n = n; return K; }
 
@@ -50,22 +55,19 @@ __device__ __forceinline__ void mergew_tile(SortKey *tile, uint32_t na, uint32_t
         }
     }
     uint32_t ia = lo, ib = d - lo;
-    // (field by field on purpose: `o[c] = ta ? va : vb` on the 16-byte struct becomes a copy from a SELECTED ADDRESS, which keeps va, vb
-    // and o in scratch memory -- 17 scratch stores and 11 scratch loads per tile in mergew_runs, each followed by a full memory wait)
-    uint64_t va_a = ~0ull, va_b = ~0ull, vb_a = ~0ull, vb_b = ~0ull;
-    if (ia < na) { const SortKey t = tile[ia]; va_a = t.a; va_b = t.b; }
-    if (ib < nb) { const SortKey t = tile[na + ib]; vb_a = t.a; vb_b = t.b; }
+    // (round 5 tried this loop field by field -- the struct selects below keep va, vb and o in scratch memory in mergew_runs, 17 scratch
+    // stores and 11 scratch loads per tile -- and measured it 3 % SLOWER on GRCh38, profiles/r05_ab_grch38_wide_variants.log: kept as it was)
+    SortKey va = ia < na ? tile[ia] : wk_max(), vb = ib < nb ? tile[na + ib] : wk_max();
 #pragma unroll
     for (uint32_t c = 0; c < MERGEW_C; ++c) {
-        const bool ta = va_a < vb_a || (va_a == vb_a && va_b < vb_b);
-        o[c].a = ta ? va_a : vb_a; o[c].b = ta ? va_b : vb_b;
+        const bool ta = wk_lt(va, vb);
+        o[c] = ta ? va : vb;
         if (ta) ++ia; else ++ib;
         const uint32_t idx = ta ? ia : na + ib;
         const bool ok = ta ? ia < na : ib < nb;
-        uint64_t x_a = ~0ull, x_b = ~0ull;
-        if (ok && c + 1u < cnt) { const SortKey t = tile[idx]; x_a = t.a; x_b = t.b; }
-        va_a = ta ? x_a : va_a; va_b = ta ? x_b : va_b;
-        vb_a = ta ? vb_a : x_a; vb_b = ta ? vb_b : x_b;
+        SortKey x = wk_max();
+        if (ok && c + 1u < cnt) x = tile[idx];
+        if (ta) va = x; else vb = x;
     }
 }
 

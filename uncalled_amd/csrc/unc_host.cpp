@@ -809,16 +809,19 @@ static int pool_note_high_water(unc_mapper *m, hipStream_t st) {
     return UNC_OK;
 }
 
-// After a batch (the pool is idle): keep the pool at twice the most chunks that were ever out at once.  A pool that went dry
-// doubles (the reads concerned were mapped again, correctly but late); one that is more than a third larger than need shrinks.
+// After a batch (the pool is idle): a pool that went dry doubles (the reads concerned were mapped again, correctly but late); one
+// that holds more than eight times the most chunks that were ever out at once shrinks to four times that.
 static int pool_fit(unc_mapper *m, bool went_dry) {
     if (!m->pool_auto) return UNC_OK;
     const uint64_t cur = m->pool.n_chunks;
     uint64_t target = cur;
     if (went_dry) target = cur * 2;
     else {
-        const uint64_t need = std::max<uint64_t>(m->pool_floor, 2ull * m->pool_hw_max);
-        if (need * 4 < cur * 3) target = need;
+        // four times the most chunks ever out at once, and only when the pool is more than twice that: the peak of ONE batch moves by
+        // tens of per cent from launch to launch (which reads are deep in their forests at the same time is a matter of scheduling),
+        // and a pool cut to twice one launch's peak was found dry by a later launch of the same batch (15 reads mapped again)
+        const uint64_t need = std::max<uint64_t>(m->pool_floor, 4ull * m->pool_hw_max);
+        if (need * 2 < cur) target = need;
     }
     if (target > cur) {     // growing: at most 60 % of what would be free without the pool
         size_t free_b = 0, total_b = 0;
