@@ -298,6 +298,14 @@ typedef struct {
 } unc_rt_tap_t;
 int unc_rt_tap_channel(unc_rt_t *rt, uint32_t channel, unc_rt_tap_t *out, float *ring);
 
+/* ---- index building (`uncalled index`; replaces the suffix sort inside bwa_idx_build, src/bwa_index.hpp:92-101)
+ * Stable LSD radix sort of n (key, value) pairs of 64 bits each, ascending by the low key_bits bits of the key (1..64; the bits
+ * above must be zero), on device memory: keys / vals are sorted in place, tmp_keys / tmp_vals (n words each) are scratch.
+ * iota != 0: the values are taken to be 0 .. n - 1 (vals need not be initialised): vals returns the sorting permutation.
+ * n < 2^32.  stream: a hipStream_t or NULL. */
+int unc_sort_pairs_u64(int device, uint64_t n, uint64_t *keys, uint64_t *vals, uint64_t *tmp_keys, uint64_t *tmp_vals, int key_bits,
+                       int iota, void *stream);
+
 /* ---- measurement aid: `reps` launches that write, then `reps` that read, n_records (made odd) scattered 64-byte records with
  * one lane per record and four 16-byte accesses per lane -- k_map's access shape with an exactly known byte count, for
  * calibrating the HBM traffic counters of rocprofv3 (tools/dev/pmc_calib.py, profiles/r02_pmc_k_map.json) */

@@ -65,6 +65,23 @@ def case_events_and_normaliser(lib, oracle_lib, example, goldens):
     assert np.array_equal(dev_index.match_probs(lv[:64]), goldens["ex_probs"])
 
 
+def case_radix_sort(lib, big=False):
+    rng = np.random.default_rng(1)
+    sizes = [(1, 64), (63, 8), (64, 16), (2048, 24), (2049, 64), (5000, 62), (70001, 40)] + ([(3_000_001, 63), (1 << 22, 33)] if big else [(300000, 33)])
+    for n, bits in sizes:
+        keys = rng.integers(0, 2 ** min(bits, 63), size=n, dtype=np.uint64)
+        if bits == 64:
+            keys = keys * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        if n > 100:
+            keys[::7] = keys[3]          # ties: a seventh of the keys are equal
+        want = np.argsort(keys, kind="stable").astype(np.uint64)
+        sk, perm = capi.sort_pairs(keys, None, bits, lib=lib)
+        assert np.array_equal(perm, want) and np.array_equal(sk, keys[want]), (n, bits)
+        vals = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)
+        sk2, sv = capi.sort_pairs(keys, vals, bits, lib=lib)
+        assert np.array_equal(sk2, sk) and np.array_equal(sv, vals[want]), (n, bits)
+
+
 def case_events_sweep_reads(lib, oracle_lib, example):
     """Reads the round-5 parity sweeps (10 240 reads each of the chr20 and GRCh38 bench batches against the reference's object code,
     tests/dev/parity_sweep.py) found the device WRONG on: one event too many, because the t-statistic's square root was hipcc's

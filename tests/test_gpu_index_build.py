@@ -44,13 +44,23 @@ def test_device_builders_equal_the_numpy_builder_byte_for_byte(tmp_path):
     names, lens, codes, holes, n_ambs = repeat_rich_masked(2_000_003, seed=11)
     annos = [""] * len(names)
     small.build_from_codes(tmp_path / "cpu", names, annos, lens, codes, holes, n_ambs, uncl_text=None)                       # numpy
-    small.build_from_codes(tmp_path / "dev", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda")     # torch sorts on the GPU
+    small.build_from_codes(tmp_path / "dev", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda")     # k_sort.hip (default)
+    small.build_from_codes(tmp_path / "devt", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda", sorter="torch")
+    big.build_from_codes_big(tmp_path / "bigh", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda", chunk=1 << 18, piece=1 << 17,
+                             sorter="hip")                                                                                      # the big builder on k_sort.hip
     # chunk / piece far below the defaults: dozens of chunk and piece boundaries on 4 M symbols, as 6.2 G symbols have with the defaults
     big.build_from_codes_big(tmp_path / "big", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda", chunk=1 << 18, piece=1 << 17)
     big.build_from_codes_big(tmp_path / "bigd", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda")     # defaults: one chunk
-    for other in ("dev", "big", "bigd"):
+    for other in ("dev", "devt", "big", "bigh", "bigd"):
         for suf in SUFS:
             assert filecmp.cmp(tmp_path / ("cpu" + suf), tmp_path / (other + suf), shallow=False), (other, suf)
+
+
+def test_radix_sort_against_numpy(hip_lib):
+    """unc_sort_pairs_u64 (k_sort.hip), the sort under the device builders: stable, any number of key bits, values carried or generated
+    (argsort), ties by the thousand, sizes around the 2 048-pair tiles and a few million pairs -- against numpy's stable argsort."""
+    from tests.parity_cases import case_radix_sort
+    case_radix_sort(hip_lib, big=True)
 
 
 def test_device_built_suffix_array_against_naive(tmp_path, hip_lib, oracle_lib):

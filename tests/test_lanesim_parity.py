@@ -20,6 +20,10 @@ def test_events_and_normaliser(sim_lib, oracle_lib, example, goldens):
     pc.case_events_and_normaliser(sim_lib, oracle_lib, example, goldens)
 
 
+def test_radix_sort_of_the_index_builders(sim_lib):
+    pc.case_radix_sort(sim_lib)
+
+
 def test_events_of_the_reads_the_sweep_found_wrong(sim_lib, oracle_lib, example):
     pc.case_events_sweep_reads(sim_lib, oracle_lib, example)
 

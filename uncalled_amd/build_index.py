@@ -140,12 +140,40 @@ def suffix_array(t):
     return sa
 
 
-def suffix_array_torch(t, device="cuda"):
-    """Same prefix-doubling construction with the sorts on the GPU (torch): seconds for 10^8 symbols."""
+DEFAULT_GPU_SORTER = "torch"      # "hip" once tools/dev/check_sorter.py has seen the chr20-sized build come out identical on the GPU
+
+
+def default_sorter(dev):
+    """"hip": the hand-written LSD radix sort of uncalled_amd/csrc/k_sort.hip through the C ABI (unc_sort_pairs_u64) -- what a GPU build
+    uses; "torch": torch.sort (rocPRIM on the GPU; the only choice on the CPU, where the tests run this code).  UNC_INDEX_SORTER overrides."""
+    import os
+    want = os.environ.get("UNC_INDEX_SORTER")
+    if want in ("hip", "torch"):
+        return want if dev.type == "cuda" else "torch"
+    return DEFAULT_GPU_SORTER if dev.type == "cuda" else "torch"
+
+
+def device_argsort(key, key_bits, sorter):
+    """(sorted keys, sorting permutation) of a non-negative int64 tensor, stable.  sorter "hip": in place, through unc_sort_pairs_u64
+    (the permutation starts as 0 .. n - 1 inside the kernel); "torch": torch.sort."""
+    import torch
+    if sorter == "hip" and key.is_cuda and key.numel() > 0:
+        from . import capi
+        order, tk, tv = torch.empty_like(key), torch.empty_like(key), torch.empty_like(key)
+        capi.sort_pairs_device(key.data_ptr(), order.data_ptr(), tk.data_ptr(), tv.data_ptr(), key.numel(), key_bits, True,
+                               key.device.index or 0, torch.cuda.current_stream(key.device).cuda_stream)
+        return key, order
+    return torch.sort(key, stable=True)
+
+
+def suffix_array_torch(t, device="cuda", sorter=None):
+    """Same prefix-doubling construction with the sorts on the GPU: seconds for 10^8 symbols.  The sorts are the radix sort of
+    k_sort.hip (`sorter` "hip", the default on a GPU) or torch.sort; everything between them (ranks, group flags) is torch."""
     import torch
     n = int(t.size)
     assert n < (1 << 31)
     dev = torch.device(device)
+    sorter = sorter or default_sorter(dev)
     K0 = 21
     sym = torch.zeros(n + K0, dtype=torch.int64, device=dev)
     sym[:n] = torch.as_tensor(t, device=dev).to(torch.int64) + 1
@@ -155,15 +183,15 @@ def suffix_array_torch(t, device="cuda"):
     del sym
     rank = torch.empty(n, dtype=torch.int64, device=dev)
 
-    def rerank(key):
-        sk, order = torch.sort(key)
+    def rerank(key, key_bits):
+        sk, order = device_argsort(key, key_bits, sorter)
         newgrp = torch.ones(n, dtype=torch.int64, device=dev)
         newgrp[1:] = (sk[1:] != sk[:-1]).to(torch.int64)
         del sk
         rank[order] = torch.cumsum(newgrp, 0) - 1
         del order, newgrp
 
-    rerank(key)
+    rerank(key, 3 * K0)
     del key
     k = K0
     while int(rank.max().item()) + 1 < n:
@@ -172,7 +200,7 @@ def suffix_array_torch(t, device="cuda"):
             nxt[:n - k] = rank[k:] + 1
         key = rank * (n + 1) + nxt      # < 2^62 for n < 2^31
         del nxt
-        rerank(key)
+        rerank(key, ((n + 1) * (n + 1)).bit_length())
         del key
         k *= 2
     sa = torch.empty(n, dtype=torch.int64, device=dev)
@@ -180,7 +208,8 @@ def suffix_array_torch(t, device="cuda"):
     return sa.cpu().numpy()
 
 
-def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, verbose=False, sa_device=None):
+def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, verbose=False, sa_device=None,
+                     sorter=None):
     prefix = str(prefix)
     l_pac = int(codes.size)
     assert sum(lens) == l_pac
@@ -211,7 +240,7 @@ def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, u
     n = t.size
     if verbose:
         print(f"[build_index] suffix array of {n} symbols ...", file=sys.stderr)
-    sa = suffix_array_torch(t, sa_device) if sa_device else suffix_array(t)
+    sa = suffix_array_torch(t, sa_device, sorter) if sa_device else suffix_array(t)
     # full matrix rows: row 0 is the sentinel suffix (SA = n)
     sa_full = np.concatenate((np.array([n], dtype=np.int64), sa))
     del sa

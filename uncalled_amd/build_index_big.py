@@ -15,6 +15,7 @@ bundled example and on repeat-rich synthetic genomes); the difference is how the
 torch does the sorting (device "cuda" on the GPU box, "cpu" in the tests).  Working set for GRCh38 (n = 6.2e9) with the
 default chunk of 2^28: 6.2 GB text + 6.2 GB BWT + about 12 GB per chunk.
 """
+import os
 import sys
 from pathlib import Path
 
@@ -43,11 +44,13 @@ def _key(t, pos, n, depth, width=K):
     return key
 
 
-def _sort_chunk(t, pos, n):
-    """positions of one chunk -> the same positions in suffix order"""
+def _sort_chunk(t, pos, n, sorter="torch"):
+    """positions of one chunk -> the same positions in suffix order.  sorter: build_index.device_argsort's ("hip": the radix sort of
+    k_sort.hip; the default here stays torch.sort -- chunks of 2^28 keys were not measured with the hand-written sort)"""
     import torch
+    from .build_index import device_argsort
     key = _key(t, pos, n, 0)
-    key, order = torch.sort(key)
+    key, order = device_argsort(key, 3 * K, sorter)
     pos = pos[order]
     del order
     m = pos.numel()
@@ -70,9 +73,9 @@ def _sort_chunk(t, pos, n):
         del grp, tied, size, start
         k2 = _key(t, sub_pos, n, depth)
         # order by (run, next key): stable sort by the key, then by the run
-        k2s, o1 = torch.sort(k2, stable=True)
+        k2s, o1 = device_argsort(k2, 3 * K, sorter)
         g1 = sub_grp[o1]
-        g2, o2 = torch.sort(g1, stable=True)
+        g2, o2 = device_argsort(g1, max(1, int(m).bit_length()), sorter)
         perm = o1[o2]
         k2f = k2s[o2]
         pos[idx] = sub_pos[perm]          # the tied slots of a run are contiguous and ascending: refill in the new order
@@ -83,7 +86,7 @@ def _sort_chunk(t, pos, n):
         del sub_pos, sub_grp, k2, k2s, o1, g1, g2, o2, perm, k2f, brk, idx
 
 
-def suffix_rows(t_in, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False):
+def suffix_rows(t_in, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False, sorter=None):
     """Generator over the suffix array of t (uint8 codes 0..3 -- ndarray or tensor --, '$'-terminated order) in order, one
     chunk (int64 tensor of text positions, on `device`) at a time; the text tensor comes along with every item."""
     import torch
@@ -120,7 +123,7 @@ def suffix_rows(t_in, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False
         del parts
         if verbose:
             print(f"[build_index_big] chunk {ci + 1}/{len(bounds)}: {pos.numel()} suffixes", file=sys.stderr, flush=True)
-        pos = _sort_chunk(t, pos, n)
+        pos = _sort_chunk(t, pos, n, sorter or os.environ.get("UNC_INDEX_SORTER_BIG", "torch"))
         yield t, pos
         done += pos.numel()
     assert done == n, (done, n)
@@ -159,7 +162,7 @@ def big_masked_genome(n_contigs, total_len, seed, masked_frac=0.30, mean_run=500
 
 
 def build_from_codes_big(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, device="cuda",
-                         chunk=1 << 28, piece=1 << 27, verbose=False):
+                         chunk=1 << 28, piece=1 << 27, verbose=False, sorter=None):
     """Drop-in for build_index.build_from_codes with the chunked suffix sort; writes .pac .ann .amb .bwt .sa (.uncl)."""
     import torch
     prefix = str(prefix)
@@ -203,7 +206,7 @@ def build_from_codes_big(prefix, names, annos, lens, codes, holes=(), n_ambs=Non
     primary = None
     row = 1                                             # matrix row of the next suffix (row 0 = sentinel)
     t = None
-    for t, pos in suffix_rows(t_all, device, chunk, piece, verbose):
+    for t, pos in suffix_rows(t_all, device, chunk, piece, verbose, sorter):
         m = pos.numel()
         rows = torch.arange(row, row + m, dtype=torch.int64, device=dev)
         zero = torch.nonzero(pos == 0).flatten()

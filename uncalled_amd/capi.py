@@ -51,6 +51,35 @@ ORDER_INDEPENDENT, ORDER_T1 = 0, 1           # unc_mapper_set_read_order
 RESULT_FIELDS = tuple(n for n in HIT.names if n != "map_ms")
 
 
+def sort_pairs_device(keys_ptr, vals_ptr, tmp_keys_ptr, tmp_vals_ptr, n, key_bits=64, iota=False, device=0, stream=None, lib=None):
+    """unc_sort_pairs_u64 on device pointers (the index builders pass torch tensors' data_ptr): stable LSD radix sort of n (key, value)
+    pairs of 64 bits by the low key_bits of the key, in place; iota: the values are 0 .. n - 1, so `vals` returns the permutation."""
+    L = lib or load()
+    _check(L, L.unc_sort_pairs_u64(int(device), int(n), keys_ptr, vals_ptr, tmp_keys_ptr, tmp_vals_ptr, int(key_bits), 1 if iota else 0, stream))
+
+
+def sort_pairs(keys, vals=None, key_bits=64, lib=None, device=0):
+    """The same sort on host arrays (tests): staged in page-locked host memory, which the kernels read and write directly.
+    -> (sorted keys uint64, values uint64); vals None = the sorting permutation."""
+    L = lib or load()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = int(k.size)
+    if n == 0:
+        return k.copy(), np.zeros(0, np.uint64)
+    buf = L.unc_host_alloc(4 * n * 8)
+    if not buf:
+        raise UncalledHipError("unc_host_alloc failed")
+    try:
+        a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint64)), shape=(4 * n,))
+        a[:n] = k
+        if vals is not None:
+            a[n:2 * n] = np.ascontiguousarray(vals, dtype=np.uint64)
+        sort_pairs_device(buf, buf + 8 * n, buf + 16 * n, buf + 24 * n, n, key_bits, vals is None, device, None, L)
+        return a[:n].copy(), a[n:2 * n].copy()
+    finally:
+        L.unc_host_free(buf)
+
+
 def hits_digest(hits):
     """sha256 over the result fields of a hit array (map_ms, a wall-clock measurement, zeroed)."""
     import hashlib
@@ -128,6 +157,9 @@ def load(path=None):
     L.unc_mapper_kernel_info.restype = i32
     L.unc_mapper_geometry.argtypes = [vp, vp]
     L.unc_mapper_geometry.restype = None
+    if hasattr(L, "unc_sort_pairs_u64"):
+        L.unc_sort_pairs_u64.argtypes = [i32, u64, vp, vp, vp, vp, i32, i32, vp]
+        L.unc_sort_pairs_u64.restype = C.c_int
     if hasattr(L, "unc_mapper_pool_usage"):           # (older builds under uncalled_amd/variants/ lack it)
         L.unc_mapper_pool_usage.argtypes = [vp, vp]
         L.unc_mapper_pool_usage.restype = C.c_int

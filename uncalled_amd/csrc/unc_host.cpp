@@ -1155,6 +1155,36 @@ extern "C" int unc_detect_events(unc_mapper_t *m, uint32_t n_reads, const int16_
     return UNC_OK;
 }
 
+// ------------------------------------------------------------------ radix sort of the index builders (k_sort.hip)
+extern "C" int unc_sort_pairs_u64(int device, uint64_t n, uint64_t *keys, uint64_t *vals, uint64_t *tmp_keys, uint64_t *tmp_vals,
+                                  int key_bits, int iota, void *stream) {
+    if (!keys || !vals || !tmp_keys || !tmp_vals) return fail(UNC_ERR_ARG, "null argument");
+    if (key_bits < 1 || key_bits > 64) return fail(UNC_ERR_ARG, "key_bits must be in 1..64");
+    if (n >= (1ull << 32)) return fail(UNC_ERR_ARG, "at most 2^32 - 1 pairs");
+    if (n == 0) return UNC_OK;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t ntiles = (n + rsort_tile() - 1) / rsort_tile(), m = 256 * ntiles, nsums = (m + rsort_tile() - 1) / rsort_tile();
+    uint32_t *counts = nullptr, *sums = nullptr;
+    HIPCHK(hipMalloc((void **)&counts, m * 4));
+    if (hipMalloc((void **)&sums, nsums * 4) != hipSuccess) { (void)hipFree(counts); return fail(UNC_ERR_HIP, "hipMalloc failed"); }
+    uint64_t *ki = keys, *vi = vals, *ko = tmp_keys, *vo = tmp_vals;
+    const int passes = (key_bits + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+        launch_rsort_pass(ki, vi, ko, vo, n, (uint32_t)(8 * p), (iota && p == 0) ? 1u : 0u, counts, sums, st);
+        std::swap(ki, ko); std::swap(vi, vo);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && ki != keys) {      // an odd number of passes: the result sits in the scratch arrays
+        e = hipMemcpyAsync(keys, ki, n * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(vals, vi, n * 8, hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(counts); (void)hipFree(sums);
+    if (e != hipSuccess) return fail(UNC_ERR_HIP, "radix sort: %s", hipGetErrorString(e));
+    return UNC_OK;
+}
+
 // Known-byte traffic in k_map's access shape, for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/dev/pmc_calib.py):
 // `reps` passes that write n_records scattered 64-byte records (one lane each, 4 x 16 B), then `reps` passes that read them.
 extern "C" int unc_calib_traffic(int device, uint64_t n_records, int reps) {
