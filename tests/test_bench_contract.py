@@ -90,6 +90,48 @@ def test_round4_bench_line():
     assert abs(avg_ms - under["roofline"]["launch_ms"]) / avg_ms < 0.03
 
 
+def test_round5_bench_line():
+    """The committed round-5 line (profiles/r05_bench_default_final.json: the driver's command in the round's final gpurun call) as the
+    driver sees it: compact, strictly parseable, contract fields, the roofline arithmetic, counter-backed traffic with writes below
+    reads, the PAF checks, the three timed steps of the secondary blocks, the realtime SLA -- and the rocprofv3 summary of the same
+    command agreeing with the HIP events of the line produced under it."""
+    txt = (ROOT / "profiles" / "r05_bench_default_final.json").read_text().strip()
+    assert "\n" not in txt
+    b = strict_line(txt)
+    assert len(txt) < 6144
+    assert b["metric"] == "reads_mapped_per_sec" and b["unit"] == "reads/s" and b["n_gpus"] == 1 and b["steps"] == 20 and b["warmup"] == 5
+    assert b["higher_is_better"] is True and b["scaling"] == "weak" and b["vs_baseline"] is None and b["data"] == "synthetic"
+    assert abs(b["value"] - 50000 / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-4 and b["value"] > 19000
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-5 and r["frac"] > 0.30
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-4 * r["achieved"]
+    assert 1.0 < r["traffic_over_algorithmic"] < 1.25
+    pmc = json.loads((ROOT / "profiles" / "r05_pmc_k_map_ecoli.json").read_text())
+    assert abs(pmc["hbm_bytes_per_launch"] - r["traffic"]) < 1e-5 * r["traffic"] and pmc["write_bytes_per_launch"] < pmc["fetch_bytes_per_launch"]
+    c = b["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] == 64 and c["value"] > 100 and c["paf_mismatches_vs_gpu"] == 0 and c["paf_reads_checked"] > 3000
+    assert b["verify"]["all_steps_identical"] and b["verify"]["steps_hashed"] == 20 and b["verify"]["paf_mismatches"] == 0
+    for name, floor in (("chr20", 28000), ("grch38", 9000)):
+        blk = b["secondary"][name]
+        assert blk["steps"] == 3 and blk["value"] > floor and blk["roofline"]["frac"] > 0.29 and blk["verify"]["paf_mismatches"] == 0
+        st = blk["config"]["step_ms"]
+        assert st["min"] <= st["median"] <= st["max"] and blk["config"]["remapped_reads"] == 0
+        assert blk["config"]["node_pool"]["high_water_ever"] < blk["config"]["node_pool"]["chunks"]
+    rt = b["secondary"]["realtime:ecoli"]
+    assert rt["config"]["latency_ms"]["p95"] <= 100.0 and rt["value"] < 77 and rt["verify"]["paf_mismatches"] == 0
+    under = strict_line((ROOT / "profiles" / "r05_bench_under_rocprofv3.json").read_text().strip())
+    import csv
+    rows = list(csv.DictReader((ROOT / "profiles" / "r05_rocprofv3_kernel_stats.csv").open()))
+    row = next(x for x in rows if "k_map<false, true>" in x["Name"])
+    avg_ms = float(row["AverageNs"]) * 1e-6
+    assert int(row["Calls"]) == under["steps"] + under["warmup"]
+    assert abs(avg_ms - under["roofline"]["launch_ms"]) / avg_ms < 0.03
+    # the parity sweeps of the same call: no read that a fresh reference Mapper maps differently
+    for w in ("grch38", "chr20"):
+        sw = json.loads((ROOT / "profiles" / f"r05_parity_sweep_{w}.log").read_text().strip().splitlines()[-1])
+        assert sw["reads_checked"] == 10240 and sw["mismatches_against_a_fresh_reference_mapper"] == 0
+
+
 def _bench_module():
     import importlib.util
     import sys

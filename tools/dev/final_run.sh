@@ -25,10 +25,10 @@ pmc|pmc_chr20|pmc_grch38)
   cp $OUT/pmc_$W/summary.json profiles/r05_pmc_sq_summary_$W.json; cp $OUT/pmc_$W/pmc_k_map.json profiles/r05_pmc_k_map_$W.json
   mkdir -p $OUT/profiles_out; cp profiles/r05_pmc_sq_summary_$W.json profiles/r05_pmc_k_map_$W.json $OUT/profiles_out/ ;;
 bench)
-  timeout 1700 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 400 $OUT/bench_default.json; echo ;;
+  UNC_BENCH_DETAIL=$OUT/bench_detail.json timeout 1700 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 400 $OUT/bench_default.json; echo ;;
 stats)
   cd /tmp; export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r05 -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass --secondary "" > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err
+  UNC_BENCH_DETAIL=$OUT/bench_detail_rocprof.json timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r05 -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass --secondary "" > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err
   cd $ROOT; ls $OUT/stats/*/ 2>/dev/null | head ;;
 e2e)
   timeout 900 python tools/dev/e2e_map.py 200000 > $OUT/e2e_map.json 2> $OUT/e2e_map.err; tail -c 600 $OUT/e2e_map.json; echo ;;

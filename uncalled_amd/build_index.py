@@ -140,7 +140,7 @@ def suffix_array(t):
     return sa
 
 
-DEFAULT_GPU_SORTER = "torch"      # "hip" once tools/dev/check_sorter.py has seen the chr20-sized build come out identical on the GPU
+DEFAULT_GPU_SORTER = "hip"        # tools/dev/check_sorter.py (profiles/r05_check_sorter_chr20.log): the chr20-sized build (129 M symbols) byte-identical with both sorters, 3.4 - 3.7 s vs 3.3 s
 
 
 def default_sorter(dev):
