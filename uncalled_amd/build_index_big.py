@@ -21,7 +21,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .build_index import DEFAULT_UNCL
+from .build_index import DEFAULT_UNCL, default_sorter
 
 K = 21            # symbols per 63-bit key
 B = 8             # symbols of the bucket id
@@ -46,7 +46,8 @@ def _key(t, pos, n, depth, width=K):
 
 def _sort_chunk(t, pos, n, sorter="torch"):
     """positions of one chunk -> the same positions in suffix order.  sorter: build_index.device_argsort's ("hip": the radix sort of
-    k_sort.hip; the default here stays torch.sort -- chunks of 2^28 keys were not measured with the hand-written sort)"""
+    k_sort.hip, the default on a GPU: grch38_syn comes out byte-identical in 61.9 s against 61.0 s with torch.sort,
+    profiles/r05_check_sorter_grch38.log)"""
     import torch
     from .build_index import device_argsort
     key = _key(t, pos, n, 0)
@@ -123,7 +124,7 @@ def suffix_rows(t_in, device="cuda", chunk=1 << 28, piece=1 << 27, verbose=False
         del parts
         if verbose:
             print(f"[build_index_big] chunk {ci + 1}/{len(bounds)}: {pos.numel()} suffixes", file=sys.stderr, flush=True)
-        pos = _sort_chunk(t, pos, n, sorter or os.environ.get("UNC_INDEX_SORTER_BIG", "torch"))
+        pos = _sort_chunk(t, pos, n, sorter or default_sorter(dev))
         yield t, pos
         done += pos.numel()
     assert done == n, (done, n)
