@@ -466,8 +466,9 @@ struct unc_mapper {
     float wall_khz = 0;            // device wall clock rate (ticks per ms)
     bool profile = false;          // launch the instantiation of k_map that counts cycles per phase
     DevPool pool{};                // nodes of the seed-cluster grids, shared by every read in flight
-    // the pool is sized by NEED: created by a rule of thumb, then kept at twice the most chunks that were ever out at once
-    // (unc_mapper_pool_usage); a caller who named pool_chunks keeps that number
+    // the pool is sized by NEED: created by a rule of thumb, cut to four times the most chunks that were ever out at once when it
+    // holds more than eight times that, doubled when found dry (pool_fit, unc_mapper_pool_usage); a caller who named pool_chunks
+    // keeps that number
     bool pool_auto = false;
     uint32_t pool_floor = 16, pool_hw_last = 0, pool_hw_max = 0, pool_resizes = 0;
     DevScratch big{};              // scratch with a larger node allowance for the reads that outgrew a slot's (kept between batches)
@@ -646,8 +647,8 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         // index rows and more, where a read touches thousands of buckets and off-target reads collect hundreds of thousands
         // of clusters; at most 60% of what is left of the HBM.  k_map stops taking up new reads while the pool is nearly
         // empty; a read that still finds it dry is mapped again after the batch (below).
-        // That rule sizes the pool for the FIRST batch only: after every batch the pool is kept at twice the high-water mark of
-        // chunks out at once (never below one chunk per slot), see pool_fit below.
+        // That rule sizes the pool for the FIRST batch only: after every batch pool_fit (below) may cut it to four times the
+        // high-water mark of chunks out at once (never below one chunk per slot) or double it.
         uint32_t n_chunks = opts ? opts->pool_chunks : 0;
         if (n_chunks == 0) {
             size_t free_b = 0, total_b = 0;
@@ -703,7 +704,7 @@ static int ensure_batch(unc_mapper *m, uint32_t n_reads, uint64_t total_samples,
         HIPCHK(hipMalloc((void **)&m->d_results, (size_t)n_reads * sizeof(DevResult)));
         m->reads_cap = n_reads;
     }
-    const uint64_t means_need = total_samples / 8 * 5 + 24ull * n_reads + 16;      // (see means_room)
+    const uint64_t means_need = total_samples / 8 * 5 + 24ull * n_reads + 16;      // (>= the sum of the reads' rooms, stage_batch)
     if (means_need > m->means_cap) {
         if (m->d_means) (void)hipFree(m->d_means);
         m->d_means = nullptr;
