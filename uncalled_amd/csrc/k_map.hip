@@ -290,7 +290,7 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
         // ask for row 0: one address, one request)
         f32x4_t orow = {0.f, 1.f, 0.f, 0.f};
         if constexpr (NARROW) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + (pfull ? okmer : 0u));
-        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see below)
+        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see the note above the loop)
         const Row plen_fm = pend - pstart + 1;
         {
             // the merge of the children's keys relies on the survivors being in ascending (start, length) order: checked here
@@ -1645,7 +1645,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         const uint32_t okmer = (uint32_t)phist & KMASK;
         f32x4_t orow = {0.f, 1.f, 0.f, 0.f};
         if constexpr (NARROW) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + (pfull ? okmer : 0u));
-        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see below)
+        else if (pfull) orow = g_load(reinterpret_cast<const UNC_AS_GLOBAL f32x4_t *>(model4) + okmer);      // (wide keys: as rounds 1-4, see the note above the loop)
         const Row plen_fm = pend - pstart + 1;
         // the merge of the children's keys relies on the survivors being in ascending (start, length) order: inside the pass here,
         // across passes after the exchange
