@@ -317,7 +317,9 @@ def issue_roofline(a, workload, launch_ms, clock_hz):
     util = insts / (1024 * clock_hz * launch_ms * 1e-3)
     out = {"wave_instructions_per_launch": insts, "simds": 1024, "clock_ghz": clock_hz * 1e-9, "utilisation": util,
            "source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_INSTS on this batch) / this run's launch time",
-           "wave_cycle_shares": {k: round(v, 4) for k, v in d.get("derived", {}).items() if k.startswith("wave_cycle_share_")},
+           # (SQ_ACTIVE_INST_VMEM reads 0 on this build: the dead counter of rounds 3-4's summaries is not passed on)
+           "wave_cycle_shares": {k: round(v, 4) for k, v in d.get("derived", {}).items()
+                                 if k.startswith("wave_cycle_share_") and k != "wave_cycle_share_active_inst_vmem"},
            "per_read": {k[:-9]: round(v) for k, v in d.get("derived", {}).items() if k.endswith("_per_read")}}
     if c.get("SQ_INSTS_VALU"):
         out["valu_utilisation"] = c["SQ_INSTS_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
