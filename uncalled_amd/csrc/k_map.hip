@@ -1061,6 +1061,10 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
             const bool have = p < p1;
             const bool has_next = have && p < tn;
             const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+            // the info words of the pass after next are requested BEFORE this pass's work, not behind it: the gather then has a whole pass
+            // to arrive (round 5, hits identical; -2.9 % in one same-call pair, +0.6 % in the next: within what one library's two
+            // regimes differ by, profiles/r05_ab_walk_prefetch.log)
+            const uint64_t bq2 = p + 2 * WAVE <= tn ? infow[s_tile[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
             const uint64_t ki = have ? s_tile[mslot(p)] : ~0ull, kn = has_next ? s_tile[mslot(p + 1u)] : ~0ull;
             const uint64_t bi = bq0;
             uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
@@ -1078,7 +1082,7 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
             bool dup;
             walk_decode_narrow<true>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
             walk_core<true>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, true, krc, nv, lane);
-            bq1 = p + 2 * WAVE <= tn ? infow[s_tile[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
+            bq1 = bq2;
         }
         pend_key = uniform64(s_tile[mslot(tn)]);
         have_pend = true;
@@ -2149,6 +2153,7 @@ static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lan
                     const bool have = p < p1;
                     const bool has_next = have && p < tn;
                     const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+                    const uint64_t bq2 = p + 2 * WAVE <= tn ? infow[wt[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;      // (requested ahead of the pass's work: merge_walk)
                     const uint64_t ki = have ? wt[mslot(p)] : ~0ull, kn = has_next ? wt[mslot(p + 1u)] : ~0ull;
                     const uint64_t bi = bq0;
                     uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
@@ -2166,7 +2171,7 @@ static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lan
                     bool dup;
                     walk_decode_narrow<true>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
                     walk_core<true>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, true, krc, nv, lane);
-                    bq1 = p + 2 * WAVE <= tn ? infow[wt[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
+                    bq1 = bq2;
                 }
                 pend_key = uniform64(wt[mslot(tn)]);
                 have_pend = true;
