@@ -198,6 +198,11 @@ def main():
             n_reads_total += n
             print(f"seed {seed}: {n} reads ok ({kw}, max_paths {p.max_paths}, mapped {int(hits['mapped'].sum())}) [{time.time() - t0:.0f} s]", flush=True)
     print(f"{rounds} rounds, {n_reads_total} reads: device == oracle")
+    try:     # (emulator build only) how often an event's walk was done again on 128-bit keys (k_map.hip: phase_S_wide_redo)
+        import ctypes
+        print("events walked again on wide keys:", ctypes.c_ulonglong.in_dll(L, "unc_sim_wide_redo_count").value)
+    except ValueError:
+        pass
     return 0
 
 

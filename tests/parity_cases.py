@@ -731,3 +731,32 @@ def case_chunked_mid_reference(lib, oracle_lib, tmp_path, n=2, genome=800000, cu
             assert int(h[f]) == int(o[f]), (i, f)
         assert (pool.chunks_used[i], bool(got[i]["ended"])) == fate[i], i
     assert max(int(want[i]["n_nbr"]) / max(int(want[i]["event_i"]), 1) for i in range(n)) > 300      # events well past the merge threshold
+
+
+def case_same_row_two_kmers(lib, oracle_lib, tmp_path, n=3, seed=5):
+    """Two children with the SAME one-row range and DIFFERENT k-mers: BwaIndex::get_base_range starts one row low
+    (bwa_index.hpp:172-174), so neighbouring k-mer ranges share a boundary row; the reference walks such a pair in seed_prob order
+    (mapper.cpp:543-563), which a narrow sort key cannot express.  The narrow-key walk notices the pair, puts sources_added_ back and
+    the event is walked again on 128-bit keys (k_map.hip: WalkState::mixed, phase_S_wide_redo).  On a 3 x 60 kb reference with
+    permissive thresholds about one event in a hundred is such an event (none on the bench references' scale cases, none on the 10 kb
+    example): the emulator build counts them and the case insists that some were seen."""
+    import ctypes
+    from uncalled_amd.build_index import build_from_codes, synthetic_genome
+    from tools.simulate_reads import simulate_reads
+    names, lens, codes = synthetic_genome(3, 60000, seed=77)
+    prefix = tmp_path / "fz"
+    build_from_codes(prefix, names, [""] * 3, lens, codes)
+    (tmp_path / "fz.uncl").write_text("default\t-10.07,-4.6,-4.0,-3.6,-3.3,-3.1\t0.3\t115.000\n")
+    try:
+        cnt = ctypes.c_ulonglong.in_dll(lib, "unc_sim_wide_redo_count")       # (the emulator build only)
+    except ValueError:
+        cnt = None
+    before = cnt.value if cnt is not None else 0
+    dix, oix = capi.Index(prefix, lib=lib), oracle_lib.Index(prefix)
+    cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    for off_target in (0.0, 1.0):
+        sim = simulate_reads(codes, lens, n, seed=seed, read_bases=600, off_target=off_target)
+        hits = capi.Mapper(dix, n_slots=n).map_batch(sim["signal"], sim["offsets"], cal)
+        assert_hits_equal(hits, oracle_hits(oix, sim["signal"], sim["offsets"], cal), "same row, two k-mers (off target %.0f)" % off_target)
+    if cnt is not None:
+        assert cnt.value - before >= 10, "hardly any event took the wide-key redo (%d): the path is untested" % (cnt.value - before)

@@ -36,6 +36,10 @@ def test_example_read_full_path(sim_lib, oracle_lib, example, goldens):
     pc.case_example_read_full_path(sim_lib, oracle_lib, example, goldens)
 
 
+def test_same_row_two_kmers_walked_again_on_wide_keys(sim_lib, oracle_lib, tmp_path):
+    pc.case_same_row_two_kmers(sim_lib, oracle_lib, tmp_path)
+
+
 @pytest.mark.parametrize("max_paths,n_reads", [(10000, 6), (97, 6), (300, 8)])
 def test_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads):
     pc.case_synthetic_batch(sim_lib, oracle_lib, example, goldens, max_paths, n_reads)

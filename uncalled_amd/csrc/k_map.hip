@@ -105,7 +105,7 @@ struct WaveCtx {
     uint32_t event_i, n_parents, cur, n_surv_par;   // the read: next event, the parent list and which buffer holds it (SlotState)
     uint32_t tstatus;                                // UNC_READ_* bits
     uint32_t nchild, n_seedp;                        // this event: children made, seed paths listed
-    uint32_t bchild;                                 // a single-row child on the first / last row of its k-mer's range was made
+    uint32_t mixed;                                  // narrow keys: the walk met two children with the SAME range and DIFFERENT k-mers (see phase_S)
     uint32_t kl;                                     // key mode of this event's sorted keys (0: 128-bit)
     uint32_t scnt[6];                                // narrow keys: keys filed in each run
     uint32_t n_surv, n_src;                          // the walk: survivors, gap sources
@@ -113,6 +113,7 @@ struct WaveCtx {
     uint32_t par_unsorted;                           // narrow keys: the surviving parents were not in ascending range order (never expected)
     uint32_t walked;                                 // phase S walked the keys as it merged them: no separate walk
     uint32_t notes;                                  // UNC_NOTE_* of the read so far
+    uint32_t flags_save[NKMER / 32];                 // narrow keys: sources_added_ as the walk found it (restored when the walk is done again)
 };
 __shared__ WaveCtx s_w;
 __shared__ Tracker s_T;       // SeedTracker's scalars between the events that touch them
@@ -223,7 +224,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     static_assert(CAND_MAX * 2 <= CHILD_MAX * 2 * 2, "candidate list inside the descriptor area");
 
     const FmView ix = fm_view(A);
-    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
     const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
     const uint32_t event_i = ctx_get(s_w.event_i), n_parents = ctx_get(s_w.n_parents), cur = ctx_get(s_w.cur), n_surv_par = ctx_get(s_w.n_surv_par);
     const float thr_lane = A->ix.thresholds[lane];   // lane l keeps prob_threshes_[l]
@@ -242,7 +242,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     PhaseClock<PROF> clk;
     uint32_t c_nbr = 0;
     uint32_t nchild = 0, n_seedp = 0;
-    bool bchild = false;   // a single-row child on the first / last row of its k-mer's range (see the sort)
     // narrow keys: keys filed so far in each run (stays / moves by base of the sorted survivors; children of sources)
     uint32_t scnt0 = 0, scnt1 = 0, scnt2 = 0, scnt3 = 0, scnt4 = 0, scntx = 0;
     uint64_t par_carry = 0;
@@ -261,7 +260,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     // that the top of a pass does not wait for the previous pass's stores to be acknowledged: wave_prims.h, mem_retire.  Narrow keys
     // only: the wide instantiation sits at its register limit, and the same changes cost it 7 % on GRCh38, r05_ab_grch38_3.log)
     if constexpr (NARROW) { mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c); }
-    uint32_t pend_cs = 0, pend_lo = 1, pend_hi = 1;     // narrow keys: a one-row child whose boundary test is still open (rows are >= 1)
     for (uint32_t base = 0; base < n_parents && nchild < max_paths; base += WAVE) {
         const uint32_t pi = base + (uint32_t)lane;
         const bool have = pi < n_parents;
@@ -500,18 +498,6 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
                     else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
                     ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
                 }
-                // narrow keys: the k-mer's own range, for the boundary test (see the sort): a one-row child on its first / last row.
-                // Requested before the child's stores and tested when this lane writes its NEXT child (or after the last pass): by then
-                // the load has long arrived, and no wait sits behind the four stores below
-                if constexpr (NARROW) {
-                    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;
-                    // (two 4-byte loads of exactly the words that are compared: with one 16-byte load the two unused registers of
-                    // the tuple are handed to the next instruction that needs one, which then has to wait for the load)
-                    pend_cs = cs == ce ? (uint32_t)cs : 0u;
-                    const uint32_t ckq = cs == ce ? ck : 0u;           // (the others all ask for entry 0: one address, one request)
-                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq));
-                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq) + 2);
-                }
                 SortKey key;
                 const uint32_t gi = nchild + li;
                 const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
@@ -539,10 +525,8 @@ static __device__ __noinline__ uint32_t phase_E(kargs_t A_, gptr_t sb_, int lane
     clk.end(1, lane);
     uint32_t tst = 0;
     if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
-    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;      // the last open boundary test
-    const uint32_t anyb = __any(bchild) ? 1u : 0u;
     if (lane == 0) {
-        s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.bchild = anyb; s_w.tstatus |= tst; s_w.par_unsorted = par_bad ? 1u : 0u;
+        s_w.nchild = nchild; s_w.n_seedp = n_seedp; s_w.tstatus |= tst; s_w.par_unsorted = par_bad ? 1u : 0u;
         s_w.scnt[0] = scnt0; s_w.scnt[1] = scnt1; s_w.scnt[2] = scnt2; s_w.scnt[3] = scnt3; s_w.scnt[4] = scnt4; s_w.scnt[5] = scntx;
     }
     wave_sync();
@@ -563,14 +547,11 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
     UNC_AS_GLOBAL SortKey *const ukeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + ukeys_off);
     UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + skeys_off);
     uint32_t kl = NARROW ? A->ix.key_len_bits : 0u;     // key mode of THIS event
-    CTX_SET(walked, 0u);
+    if (lane == 0) { s_w.walked = 0u; s_w.mixed = 0u; }
     if constexpr (NARROW) {
-        const UNC_AS_GLOBAL uint64_t *const skeys64 = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(skeys);
-        const UNC_AS_GLOBAL uint64_t *const info = reinterpret_cast<const UNC_AS_GLOBAL uint64_t *>(sb + A->sc.off_info);
         const uint32_t str_off = A->sc.off_streams, sk_off = skeys_off, run_bytes = max_paths << 3;
         uint32_t scnt0 = ctx_get(s_w.scnt[0]), scnt1 = ctx_get(s_w.scnt[1]), scnt2 = ctx_get(s_w.scnt[2]), scnt3 = ctx_get(s_w.scnt[3]),
                  scnt4 = ctx_get(s_w.scnt[4]), nx = ctx_get(s_w.scnt[5]);
-        bool sorted_ok = false;
 #ifdef LANESIM
         {   // emulator only: every key phase E filed names a child of this event, and the runs hold all of them
             const uint32_t cnt[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
@@ -623,23 +604,16 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
                     KB.adj[1] = KB.adj[2] = KB.adj[3] = KB.adj[0];
                 }
                 sclk.end(10, lane);
-                if (!ctx_get(s_w.bchild)) {
-                    merge_walk(A, sb, ka_single(str_off, scnt0), KB, lane);
-                    CTX_SET(kl, kl);
-                    CTX_SET(walked, 1u);
-                    wave_sync();
-                    sclk.end(11, lane);
-                    return;
-                }
-                // (an event with a single-row child on a k-mer's boundary row may need the 128-bit keys, which is decided on the
-                // sorted keys below: its keys go through memory)
-                sorted_ok = merge_runs<1, 4>(sb, ka_single(str_off, scnt0), KB, sk_off, lane, 1u) != 0u;
+                merge_walk(A, sb, ka_single(str_off, scnt0), KB, lane);
+                CTX_SET(kl, kl);
+                CTX_SET(walked, 1u);
                 wave_sync();
                 sclk.end(11, lane);
+                return;
             }
         }
-        if (!sorted_ok) {
-            // few children, or runs that were not ascending after all: the bitonic network over all of them
+        {
+            // few children, or parents that were not in order: the bitonic network over all of them
             KeyArr<6> K6;
             const uint32_t c[6] = {scnt0, scnt1, scnt2, scnt3, scnt4, nx};
             uint32_t cum = 0;
@@ -647,32 +621,6 @@ static __device__ __noinline__ void phase_S(kargs_t A_, gptr_t sb_, int lane) {
             for (uint32_t r = 0; r < 6; ++r) { K6.cum[r] = cum; K6.adj[r] = str_off + r * run_bytes - (cum << 3); cum += c[r]; }
             K6.n = cum;
             sort_any64(sb, K6, sk_off, lane);
-        }
-        // BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can
-        // share a boundary row and two children with the SAME one-row range may carry DIFFERENT k-mers.  The
-        // reference then walks them in seed_prob order (mapper.cpp:543-563 runs per position), which the narrow
-        // key cannot express: such an event (rare) is re-sorted with the full 128-bit keys.
-        if (ctx_get(s_w.bchild)) {
-            wave_sync();
-            bool mixed = false;
-            for (uint32_t base = 0; base + 1 < n; base += WAVE) {
-                const uint32_t i = base + (uint32_t)lane;
-                if (i + 1 < n) {
-                    const uint64_t ki = skeys64[i], kn = skeys64[i + 1];
-                    if ((ki >> 16) == (kn >> 16) && ((info[ki & 0xFFFFu] ^ info[kn & 0xFFFFu]) & META_KMER_MASK)) mixed = true;
-                }
-            }
-            if (__any(mixed)) {
-                for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
-                    const uint64_t k = skeys64[i], ri = k >> 16;
-                    SortKey w;
-                    w.a = ((ri >> kl) << KEY_LEN_BITS) | (ri & ((1ull << kl) - 1ull));
-                    w.b = info[k & 0xFFFFu];
-                    g_store(ukeys + i, w);
-                }
-                kl = 0;
-                wave_sync();
-            }
         }
     }
     if constexpr (!NARROW) {
@@ -759,7 +707,19 @@ template <bool NARROW> struct WalkState {
     uint32_t carry_kmer = NKMER;
     Row carry_U = 0;
     uint64_t carry_range = ~0ull, carry_w = 0;         // narrow keys: range / running info maximum of the run that is open at a pass boundary
+    bool mixed = false;                                // narrow keys: this lane saw two neighbours with equal ranges and different k-mers
 };
+// BwaIndex::get_base_range starts one row low (bwa_index.hpp:172-174), so neighbouring k-mer ranges can share a boundary row and two
+// children with the SAME one-row range may carry DIFFERENT k-mers.  The reference walks them in seed_prob order (mapper.cpp:543-563
+// runs per position), which the narrow key cannot express.  Rounds 1-5 tested every one-row child against its k-mer's first and last
+// row in phase E (two loads per child) and sent such events through memory; now the walk itself notices the pair -- equal keys are
+// neighbours in the sorted order -- and the event's walk is done again on 128-bit keys (walk_begin_narrow / phase_S_wide_redo).  What
+// a narrow walk changes before it notices is put back or overwritten: sources_added_ (saved here), the lists it appends to (started
+// again), the sa_checked_ bits of seed paths (set again by the second walk on every child that survives it; a child that does not is
+// dead).
+__device__ __forceinline__ void walk_begin_narrow(int lane) {
+    if (lane < NKMER / 32) s_w.flags_save[lane] = s_flags[lane];
+}
 template <bool NARROW> __device__ __forceinline__ WalkConst<NARROW> walk_const(kargs_t A, gptr_t sb) {
     WalkConst<NARROW> C;
     const uint32_t cur = ctx_get(s_w.cur), max_paths = A->sc.max_paths;
@@ -772,6 +732,11 @@ template <bool NARROW> __device__ __forceinline__ WalkConst<NARROW> walk_const(k
     return C;
 }
 template <bool NARROW> __device__ __forceinline__ void walk_finish(const WalkConst<NARROW> &C, WalkState<NARROW> &S, int lane) {
+    if (__any(S.mixed)) {        // (narrow keys only) nothing of this walk counts: phase_S_wide_redo + phase_W follow
+        if (lane == 0) s_w.mixed = 1u;
+        wave_sync();
+        return;
+    }
     uint32_t tst = 0;
     if (S.n_seedp > C.max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; S.n_seedp = C.max_seed_paths; }
     if (lane == 0) { s_w.n_surv = S.n_surv; s_w.n_src = S.n_src; s_w.n_seedp = S.n_seedp; s_w.tstatus |= tst; }
@@ -793,6 +758,7 @@ __device__ __forceinline__ void walk_decode_narrow(WalkState<NARROW> &S, uint32_
     kmer = have ? (uint32_t)(bi & META_KMER_MASK) : NKMER + 1u;
     nkmer = has_next ? (uint32_t)(bn & META_KMER_MASK) : NKMER + 2u;
     dup = has_next && rn == ri;
+    if (dup && nkmer != kmer) S.mixed = true;
     uint64_t pr = (uint64_t)__shfl_up((unsigned long long)ri, 1);
     if (lane == 0) pr = S.carry_range;
     const bool rhead = !have || ri != pr;
@@ -896,6 +862,7 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
     // its neighbour lane, the last lane's from the next pass
     uint64_t kq0 = ~0ull, kq1 = ~0ull, bq0 = 0, bq1 = 0;
     if (kl) {
+        walk_begin_narrow(lane);
         if ((uint32_t)lane < n) kq0 = skeys64[lane];
         if ((uint32_t)lane + WAVE < n) kq1 = skeys64[lane + WAVE];
         if ((uint32_t)lane < n) bq0 = infow[kq0 & 0xFFFFu];
@@ -965,6 +932,7 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
     const WalkConst<true> C = walk_const<true>(A, sb);
     WalkState<true> S;
     S.n_seedp = ctx_get(s_w.n_seedp);
+    walk_begin_narrow(lane);
     const uint32_t kl = A->ix.key_len_bits;
     const float source_prob = C.source_prob;
     const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
@@ -1176,6 +1144,41 @@ static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<
     }
     if (bad && lane == 0) s_w.tstatus |= UNC_READ_SORT_FAULT;
     walk_finish<false>(C, S, lane);
+}
+
+// narrow keys, after a walk that met equal ranges with different k-mers (WalkState::mixed): the event's children under their full
+// 128-bit keys -- range from the child's record, info word as phase E filed it -- through the bitonic network; phase_W follows.
+#ifdef LANESIM
+}  // namespace unc
+extern "C" { unsigned long long unc_sim_wide_redo_count = 0; }      // emulator only: how often the suite takes this path (tests assert it does)
+namespace unc {
+#endif
+static __device__ __noinline__ void phase_S_wide_redo(kargs_t A_, gptr_t sb_, int lane) {
+#ifdef LANESIM
+    if (lane == 0) ++unc_sim_wide_redo_count;
+#endif
+    const kargs_t A = uniform_ptr(A_);
+    const gptr_t sb = uniform_ptr(sb_);
+    const uint32_t n = ctx_get(s_w.nchild), cur = ctx_get(s_w.cur), max_paths = A->sc.max_paths;
+    const uint32_t chd_off = A->sc.off_paths + (cur ^ 1u) * (max_paths << PATH_SHIFT), info_off = A->sc.off_info;
+    UNC_AS_GLOBAL SortKey *const ukeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + A->sc.off_keys);
+    UNC_AS_GLOBAL SortKey *const skeys = reinterpret_cast<UNC_AS_GLOBAL SortKey *>(sb + A->sc.off_keys + A->sc.keys_cap * (uint32_t)sizeof(SortKey));
+    if (lane < NKMER / 32) s_flags[lane] = s_w.flags_save[lane];
+    for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+        const uint2 r = gld<uint2>(sb, chd_off + (i << PATH_SHIFT));        // 32-bit rows: start, end
+        SortKey w;
+        w.a = ((uint64_t)r.x << KEY_LEN_BITS) | (uint64_t)(r.y - r.x);
+        w.b = gld<uint64_t>(sb, info_off + (i << 3));
+        g_store(ukeys + i, w);
+    }
+    wave_sync();
+    if (n <= 64) sort_regs<1>(ukeys, skeys, n, lane);
+    else if (n <= 128) sort_regs<2>(ukeys, skeys, n, lane);
+    else if (n <= 256) sort_regs<4>(ukeys, skeys, n, lane);
+    else if (n <= 512) sort_regs<8>(ukeys, skeys, n, lane);
+    else sort_hybrid(ukeys, skeys, n, lane);
+    if (lane == 0) { s_w.kl = 0u; s_w.walked = 0u; s_w.mixed = 0u; }
+    wave_sync();
 }
 
 // ---------------- F: remaining full-range sources, :605-624; the next parent list is complete after it ----------------
@@ -1449,6 +1452,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 phase_S<NARROW>(A, sb, lane);
                 clk.end(2, lane);
                 if (!ctx_get(s_w.walked)) phase_W<NARROW>(A, sb, lane);
+                if constexpr (NARROW) {
+                    if (ctx_get(s_w.mixed)) { phase_S_wide_redo(A, sb, lane); phase_W<NARROW>(A, sb, lane); }
+                }
                 clk.end(3, lane);
             }
             phase_F<NARROW>(A, sb, lane);
@@ -1548,7 +1554,7 @@ struct TeamCnt {
     uint64_t first_pk, last_pk;            // order check of the sorted survivors across passes
 };
 __shared__ TeamCnt s_team_cnt[2][TEAM_MAX];
-__shared__ uint32_t s_team_flags;                  // over the waves of an event: 1 boundary child, 2 parents unsorted, 4 seed list overflow
+__shared__ uint32_t s_team_flags;                  // over the waves of an event: 2 parents unsorted, 4 seed list overflow
 __shared__ unsigned long long s_team_nbr;          // get_neighbor calls counted by the followers
 __shared__ uint32_t s_team_ctl;                    // leader -> followers after an event: 0 go on, 1 / 2 read decided, 3 chunk mapped (park)
 __shared__ __attribute__((aligned(16))) uint64_t s_e_x[TEAM_MAX - 1][S_E_WORDS];   // the followers' staging for phase E
@@ -1591,7 +1597,6 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
     uint16_t *const s_cand = s_cdesc;                                                // (dead before the descriptors are written)
 
     const FmView ix = fm_view(A);
-    const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
     const uint32_t max_paths = A->sc.max_paths, max_seed_paths = A->sc.max_seed_paths;
     const uint32_t event_i = ctx_get(s_w.event_i), n_parents = ctx_get(s_w.n_parents), cur = ctx_get(s_w.cur), n_surv_par = ctx_get(s_w.n_surv_par);
     const float thr_lane = A->ix.thresholds[lane];
@@ -1606,7 +1611,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
     const UNC_AS_GLOBAL float4 *const model4 = (const UNC_AS_GLOBAL float4 *)A->ix.model4;
 
     uint32_t c_nbr = 0;
-    bool bchild = false, par_bad = false, seed_over = false;
+    bool par_bad = false, seed_over = false;
     TT.nchild = 0; TT.n_seedp = 0; TT.scntx = 0; TT.run_last = 0;
 #pragma unroll
     for (int t = 0; t < 5; ++t) TT.scnt[t] = 0;
@@ -1622,7 +1627,6 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
     }
     // (where the waits of a round sit: see phase_E and wave_prims.h, mem_retire)
     if constexpr (NARROW) { mem_retire(phys_nxt); mem_retire(q0c); mem_retire(q1c); }
-    uint32_t pend_cs = 0, pend_lo = 1, pend_hi = 1;     // narrow keys: a one-row child whose boundary test is still open
     PhaseClock<PROF> clk;       // (the leader's view of a round: 8 parents + candidates, 9 FM, 10 slots, 11 the wait at the exchange, 1 children)
     for (uint32_t rbase = 0, rnd = 0; rbase < n_parents && TT.nchild < max_paths; rbase += PSTRIDE, ++rnd) {
         const uint32_t base = rbase + (uint32_t)wave * WAVE;
@@ -1867,13 +1871,6 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
                     else { cs = pr >> RES_BITS; ce = cs + (pr & ((1ull << RES_BITS) - 1ull)) - 1ull; }
                     ck = ((pk << 2) & KMASK) | (type - 1u); mv = 1;
                 }
-                if constexpr (NARROW) {      // the boundary test of this lane's previous one-row child; this child's k-mer range requested
-                    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;
-                    pend_cs = cs == ce ? (uint32_t)cs : 0u;
-                    const uint32_t ckq = cs == ce ? ck : 0u;           // (the others all ask for entry 0: one address, one request)
-                    pend_lo = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq));
-                    pend_hi = g_load(reinterpret_cast<const UNC_AS_GLOBAL uint32_t *>(kmer_ranges + ckq) + 2);
-                }
                 SortKey key;
                 const uint32_t gi = b_child + li;
                 const ChildHdr c = make_child(pmv, pmt, last, subc, hist, cs, ce, ck, s_probs[ck], mv, p_seed_len, p_min_seed_prob, p_max_stay, gi, klb, key);
@@ -1932,8 +1929,7 @@ static __device__ __noinline__ uint32_t phase_E_team(kargs_t A_, gptr_t sb_, int
         if (wave == 0) clk.end(1, lane);
     }
     // what the leader needs of the followers: flags, their share of the work counter
-    if (pend_cs == pend_lo || pend_cs == pend_hi) bchild = true;      // the last open boundary test
-    const uint32_t fl = (__any(bchild) ? 1u : 0u) | (par_bad ? 2u : 0u) | (__any(seed_over) ? 4u : 0u);
+    const uint32_t fl = (par_bad ? 2u : 0u) | (__any(seed_over) ? 4u : 0u);
     if (wave != 0) {
         const uint64_t tot = wave_sum64((uint64_t)c_nbr);
         if (lane == 0) { if (fl) atomicOr(&s_team_flags, fl); if (tot) atomicAdd(&s_team_nbr, (unsigned long long)tot); }
@@ -2011,7 +2007,7 @@ static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lan
     const kargs_t A = uniform_ptr(A_);
     const gptr_t sb = uniform_ptr(sb_);
     const uint32_t n = ctx_get(s_w.nchild);
-    if (!(n > MERGE_MIN) || ctx_get(s_w.par_unsorted) || ctx_get(s_w.bchild) || !MERGE_REPAIR) return false;     // (uniform over the team)
+    if (!(n > MERGE_MIN) || ctx_get(s_w.par_unsorted) || !MERGE_REPAIR) return false;     // (uniform over the team)
     const uint32_t max_paths = A->sc.max_paths;
     const uint32_t str_off = A->sc.off_streams, run_bytes = max_paths << 3, x_off = str_off + 5u * run_bytes;
     uint64_t *const tile = team_stage(wave);
@@ -2096,6 +2092,7 @@ static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lan
     const WalkConst<true> C = walk_const<true>(A, sb);
     WalkState<true> S;
     S.n_seedp = ctx_get(s_w.n_seedp);
+    if (wave == 0) { walk_begin_narrow(lane); if (lane == 0) s_w.mixed = 0u; }
     const uint32_t kl = A->ix.key_len_bits;
     const float source_prob = C.source_prob;
     const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
@@ -2276,7 +2273,7 @@ __global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
             uint32_t n_seedp = TT.n_seedp, tst = 0;
             if (n_seedp > max_seed_paths) { tst = UNC_READ_SEED_OVERFLOW; n_seedp = max_seed_paths; }
             if (lane == 0) {
-                s_w.nchild = TT.nchild; s_w.n_seedp = n_seedp; s_w.bchild = fl & 1u; s_w.tstatus |= tst; s_w.par_unsorted = (fl >> 1) & 1u;
+                s_w.nchild = TT.nchild; s_w.n_seedp = n_seedp; s_w.tstatus |= tst; s_w.par_unsorted = (fl >> 1) & 1u;
                 s_w.scnt[0] = TT.scnt[0]; s_w.scnt[1] = TT.scnt[1]; s_w.scnt[2] = TT.scnt[2]; s_w.scnt[3] = TT.scnt[3]; s_w.scnt[4] = TT.scnt[4];
                 s_w.scnt[5] = TT.scntx;
                 s_w.walked = 0u;
@@ -2297,8 +2294,11 @@ __global__ __launch_bounds__(64 * W, UNC_LB) void k_map_team(MapArgs Aval) {
                 phase_S<NARROW>(A, sb, lane);
                 clk.end(2, lane);
                 if (!ctx_get(s_w.walked)) phase_W<NARROW>(A, sb, lane);
-                clk.end(3, lane);
             }
+            if constexpr (NARROW) {
+                if (ctx_get(s_w.nchild) > 0 && ctx_get(s_w.mixed)) { phase_S_wide_redo(A, sb, lane); phase_W<NARROW>(A, sb, lane); }
+            }
+            if (ctx_get(s_w.nchild) > 0 && !team_sorted) clk.end(3, lane);
             phase_F<NARROW>(A, sb, lane);
             clk.end(4, lane);
             bool conf = false;
