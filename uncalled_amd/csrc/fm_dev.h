@@ -181,15 +181,22 @@ template <class IX> __device__ __forceinline__ void fm32_get_neighbor(const IX &
     const uint32_t kk = k - (k >= primary ? 1u : 0u), ll = l - (l >= primary ? 1u : 0u);
     const uint32_t bk = kk >> 6, bl = ll >> 6;
     const auto w = ix.fm32;
-    // both blocks are requested before either rank is computed; nearly always they are one and the same
+    // both blocks are requested before either rank is computed; nearly always they are one and the same.  (Round 6, off the ISA: written
+    // as `ck = cl; pk = pl; if (bk != bl) { ck = ...; pk = ...; }` the copies were USES of the first block's words: the wavefront waited
+    // for block l before it asked for block k -- two memory round trips in a row in the four passes out of five in which some lane's
+    // range straddles two blocks.  The second block gets registers of its own, preset to constants, and is chosen after both requests.)
     const uint32_t cl = w[(bl << 3) + c];
     const uint4 pl = ld16(w + (bl << 3) + 4u);
-    uint32_t ck = cl;
-    uint4 pk = pl;
-    if (bk != bl) { ck = w[(bk << 3) + c]; pk = ld16(w + (bk << 3) + 4u); }
+    const bool two = bk != bl;
+    uint32_t ck2 = 0u;
+    uint4 pk2 = make_uint4(0u, 0u, 0u, 0u);
+    if (two) { ck2 = w[(bk << 3) + c]; pk2 = ld16(w + (bk << 3) + 4u); }
+    mem_retire(ck2); mem_retire(pk2);      // (values of their own from here on: else the optimiser folds the selects back into the branch)
     const uint32_t xh = (c & 2u) ? 0u : ~0u, xl = (c & 1u) ? 0u : ~0u;     // plane word ^ x: bit set where the symbol's bit equals c's
-    *os = fm32_rank(ck, pk, xh, xl, kk) + 1u;
     *oe = fm32_rank(cl, pl, xh, xl, ll);
+    const uint32_t ck = two ? ck2 : cl;
+    const uint4 pk = make_uint4(two ? pk2.x : pl.x, two ? pk2.y : pl.y, two ? pk2.z : pl.z, two ? pk2.w : pl.w);
+    *os = fm32_rank(ck, pk, xh, xl, kk) + 1u;
 }
 
 // bwt_sa: walk LF until a sampled row (multiple of 32); *steps gets the number of LF steps

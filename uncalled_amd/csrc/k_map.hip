@@ -1013,16 +1013,23 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
 #endif
         // ---- the walk over logical positions [p0, p1): a key's successor sits one position on (none after the last key of all)
         const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
-        uint64_t bq0 = 0, bq1 = 0;
+        // Every load of the walk is issued by EVERY lane in EVERY pass (a lane past the end asks for the tile's last key's word, a lane
+        // whose k-mer starts no source for entry 0): a load inside a branch is one the compiler cannot count, and a wait it cannot
+        // count is vmcnt(0) -- which drained the info words of the pass after next right behind their request (round 6, off the ISA:
+        // each pass of the walk paid a full memory round trip).  With unconditional loads the waits name how many younger requests
+        // may stay in flight.
+        uint64_t bq0, bq1;
         {
             const uint32_t pa = p0 + (uint32_t)lane, pb = pa + WAVE;
-            if (pa <= tn) bq0 = infow[s_tile[mslot(pa)] & 0xFFFFu];
-            if (pb <= tn) bq1 = infow[s_tile[mslot(pb)] & 0xFFFFu];
+            bq0 = infow[s_tile[mslot(pa <= tn ? pa : tn)] & 0xFFFFu];
+            bq1 = infow[s_tile[mslot(pb <= tn ? pb : tn)] & 0xFFFFu];
         }
-        ulonglong2 krq = make_ulonglong2(1ull, 0ull);
-        if (p0 + (uint32_t)lane < p1) {
+        // (the k-mer's range as ONE register tuple that stays whole until it is used: of a 16-byte load whose upper words are dead the
+        // freed registers go to the next instruction that needs one, which then has to wait for the load)
+        u32x4_t krq;
+        {
             const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
-            if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+            krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[km0] >= source_prob ? km0 : 0u));
         }
         for (uint32_t base = p0; base < p1; base += WAVE) {
             const uint32_t p = base + (uint32_t)lane;
@@ -1032,18 +1039,20 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
             // the info words of the pass after next are requested BEFORE this pass's work, not behind it: the gather then has a whole pass
             // to arrive (round 5, hits identical; -2.9 % in one same-call pair, +0.6 % in the next: within what one library's two
             // regimes differ by, profiles/r05_ab_walk_prefetch.log)
-            const uint64_t bq2 = p + 2 * WAVE <= tn ? infow[s_tile[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;
+            const uint64_t bq2 = infow[s_tile[mslot(p + 2 * WAVE <= tn ? p + 2 * WAVE : tn)] & 0xFFFFu];
             const uint64_t ki = have ? s_tile[mslot(p)] : ~0ull, kn = has_next ? s_tile[mslot(p + 1u)] : ~0ull;
             const uint64_t bi = bq0;
             uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
             const uint64_t bf = bcast64(bq1, 0);
             if (lane == WAVE - 1) bn = bf;
             bq0 = bq1;
-            const ulonglong2 krc = krq;
-            krq = make_ulonglong2(1ull, 0ull);
-            if (p + WAVE < p1) {
+            u32x4_t kt = krq;                 // (used only where this lane's k-mer passes source_prob: the entry asked for was its own)
+            mem_retire(kt);                   // requested a pass ago; the info words just asked for stay in flight
+            ulonglong2 krc;
+            krc.x = ((uint64_t)kt.y << 32) | kt.x; krc.y = ((uint64_t)kt.w << 32) | kt.z;
+            {
                 const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
-                if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+                krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[kmn] >= source_prob ? kmn : 0u));
             }
             uint32_t start, end, nstart, kmer, nkmer;
             uint64_t sbw;
