@@ -286,17 +286,52 @@ def a_reads(a, workload):
     return {"ecoli": a.reads, "chr20": a.chr20_reads, "grch38": a.grch38_reads}.get(workload, a.reads)
 
 
+KERNEL_SOURCES = ("k_map.hip", "map_sort.h", "map_sort_wide.h", "map_tracker.h", "map_lds.h", "map_sched.h", "fm_dev.h", "wave_prims.h",
+                  "unc_dev_types.h")
+
+
+def kernel_source_hash(root=None):
+    """sha256 over the sources k_map is compiled from (in a fixed order): what a committed counter pass is keyed by.  The library
+    travels with the tree it was built from, so the sources name the kernel that runs; tools/dev/summarise_pmc.py and
+    summarise_sq.py write the same hash into the records they produce."""
+    import hashlib
+    h = hashlib.sha256()
+    base = Path(root) if root else ROOT / "uncalled_amd" / "csrc"
+    for name in KERNEL_SOURCES:
+        h.update(name.encode() + b"\0" + (base / name).read_bytes() + b"\0")
+    return h.hexdigest()
+
+
+def pmc_record(kind, workload, a, profiles=None):
+    """The newest committed counter record (kind: 'k_map' = FETCH / WRITE_SIZE, 'sq_summary' = SQ counters) of this workload that was
+    taken on THIS kernel and THIS batch size, else (None, why not): a record of another kernel is not a measurement of this one."""
+    profiles = Path(profiles) if profiles else ROOT / "profiles"
+    cands = sorted(profiles.glob(f"r[0-9][0-9]_pmc_{kind}_{workload}.json"), reverse=True)
+    if not cands:
+        return None, "no PMC pass committed for this workload"
+    want = kernel_source_hash()
+    why = []
+    for f in cands:
+        d = json.loads(f.read_text())
+        if d.get("workload", "ecoli") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload):
+            why.append(f"{f.name}: collected on {d.get('workload')} / {d.get('reads_per_launch')} reads")
+            continue
+        if d.get("kernel_source_sha256") != want:
+            why.append(f"{f.name}: taken on another kernel (source hash {str(d.get('kernel_source_sha256'))[:12]}, running {want[:12]})")
+            continue
+        d["_file"] = f.name
+        return d, None
+    return None, "; ".join(why)[:300]
+
+
 def measured_traffic(a, workload):
     """HBM bytes per launch of k_map from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected
-    from inside this process): used only when they were taken on this workload and batch size, else null."""
-    # the newest committed pass of this workload: round 5 (E. coli: the kernel of this round), else round 4 (chr20 / GRCh38: the passes
-    # cost six index builds; records, keys and info words -- what the traffic consists of -- are unchanged since)
-    pmc = next((f for f in (ROOT / "profiles" / f"r05_pmc_k_map_{workload}.json", ROOT / "profiles" / f"r04_pmc_k_map_{workload}.json") if f.exists()), None)
-    if pmc is None:
-        return None, "no PMC pass committed for this kernel"
-    d = json.loads(pmc.read_text())
-    if d.get("workload") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload):
-        return None, f"{pmc.name} was collected on {d.get('workload')} / {d.get('reads_per_launch')} reads"
+    from inside this process): used only when they were taken on this workload, this batch size and THIS kernel (the record carries the
+    hash of the kernel's sources), else null with the reason."""
+    d, why = pmc_record("k_map", workload, a)
+    if d is None:
+        return None, why
+    pmc = Path(d["_file"])
     src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; calibrated, see the file)"
     if d.get("kernel_state"):
         src += "; " + d["kernel_state"]
@@ -304,14 +339,14 @@ def measured_traffic(a, workload):
 
 
 def issue_roofline(a, workload, launch_ms, clock_hz):
-    """Issue side of k_map: wave-instructions of one launch (SQ_INSTS of the committed rocprofv3 pass on this workload and batch
-    size -- the count is a property of kernel + batch, the duration is this run's) / (1024 SIMDs x clock x launch time)."""
-    sq = next((f for f in (ROOT / "profiles" / f"r05_pmc_sq_summary_{workload}.json", ROOT / "profiles" / f"r04_pmc_sq_summary_{workload}.json") if f.exists()), None)
-    if sq is None:
+    """Issue side of k_map: wave-instructions of one launch (SQ_INSTS of the committed rocprofv3 pass on this workload, batch
+    size and kernel -- the count is a property of kernel + batch, the duration is this run's) / (1024 SIMDs x clock x launch time)."""
+    d, _ = pmc_record("sq_summary", workload, a)
+    if d is None:
         return None
-    d = json.loads(sq.read_text())
+    sq = Path(d["_file"])
     insts = d.get("counters", {}).get("SQ_INSTS")
-    if d.get("workload", "ecoli") != workload or int(d.get("reads_per_launch", -1)) != a_reads(a, workload) or not insts:
+    if not insts:
         return None
     c = d["counters"]
     util = insts / (1024 * clock_hz * launch_ms * 1e-3)
@@ -323,9 +358,13 @@ def issue_roofline(a, workload, launch_ms, clock_hz):
            "per_read": {k[:-9]: round(v) for k, v in d.get("derived", {}).items() if k.endswith("_per_read")}}
     if c.get("SQ_INSTS_VALU"):
         out["valu_utilisation"] = c["SQ_INSTS_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
-    if c.get("SQ_ACTIVE_INST_VALU"):
-        # a wave64 VALU instruction holds its SIMD for 4 cycles and SQ_ACTIVE_INST_VALU counts those quad-cycles: how busy the vector ALUs are
-        out["valu_pipe_busy"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
+    if c.get("SQ_INSTS_VALU"):
+        # how busy the vector ALUs are.  Round 5 took 4 cycles per wave64 instruction (SQ_ACTIVE_INST_VALU counts quad-cycles, one per
+        # instruction) and read 55 %.  Measured in round 6 (tools/dev/ubench_valu.hip, profiles/r06_ubench_valu.log): four wavefronts
+        # of independent v_add_u32 / v_fma_f32 on one SIMD retire one instruction per 2.1 - 2.3 cycles (MI355X_MICROARCH.md: SIMD-32,
+        # two cycles per wave64 instruction) -- the quad-cycle counter rounds every instruction up to four.  Two cycles each:
+        out["valu_pipe_busy"] = 2.0 * c["SQ_INSTS_VALU"] / (1024 * clock_hz * launch_ms * 1e-3)
+        out["valu_pipe_busy_note"] = "2 cycles x SQ_INSTS_VALU / (1024 SIMDs x clock x launch): profiles/r06_ubench_valu.log"
     return out
 
 
@@ -363,36 +402,86 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
             return mapper.map_batch_device(raw_ptr, offsets[:nr + 1], calib[:nr], stream=stream)
         return mapper.map_batch(sim["signal"].numpy()[:int(offsets[nr])], offsets[:nr + 1], calib[:nr])
 
+    # Two mappers over the one index, batch k + 1 begun on the second while batch k's last long reads finish on the first
+    # (unc_map_batch_begin / _end, include/uncalled_hip.h): a persistent launch ends with a few wavefronts on a few long reads
+    # (wavefronts alive 94 % of a 50 k-read E. coli launch), and the next batch moves into the compute units as they fall idle.  Every
+    # step is still one whole pass of the path over one batch, each batch's hits are complete when its _end returns, and all K are
+    # collected inside the timed region.  Where a second mapper's scratch does not fit beside the first (GRCh38) the steps run one
+    # after the other as before.
+    mapper2 = None
+    if have_gpu and a.pipeline and steps > 1 and hasattr(mapper.L, "unc_map_batch_begin"):
+        free_b, _tot = torch.cuda.mem_get_info(local_rank)
+        if free_b > 1.25 * mapper.device_bytes():
+            mapper2 = capi.Mapper(ix, **kw)
+    pair = [mapper, mapper2] if mapper2 is not None else [mapper]
+
+    # (the first mapper's stream outranks the second's: two batches begun at the same moment -- the first two of the timed region --
+    # would otherwise share the compute units from the start and end together, tail beside tail; later batches are begun while
+    # the one before holds every wavefront slot, and wait for slots whatever their rank)
+    pstreams = [torch.cuda.Stream(device=local_rank, priority=-1), torch.cuda.Stream(device=local_rank, priority=0)] if mapper2 is not None else []
+
+    def begin(mp, nr=None):
+        nr = n_reads if nr is None else min(nr, n_reads)
+        mp.begin_batch(raw_ptr, offsets[:nr + 1], calib[:nr], on_device=True, stream=pstreams[pair.index(mp)].cuda_stream)
+
     hits = None
     for _ in range(warmup):
-        hits = one_step(warmup_reads)      # (secondary blocks warm up on a prefix of their batch: code, TLBs, first touch)
+        for mp in pair:
+            hits = mp.map_batch_device(raw_ptr, offsets[:min(warmup_reads or n_reads, n_reads) + 1], calib[:min(warmup_reads or n_reads, n_reads)]) \
+                if have_gpu else one_step(warmup_reads)      # (secondary blocks warm up on a prefix of their batch: code, TLBs, first touch)
     sync()
     barrier()
     t0 = time.perf_counter()
-    ms_ev, ms_map, kept, step_ms = [], [], [], []
-    for _ in range(steps):
+    ms_ev, ms_map, kept, step_ms, windows = [], [], [], [], []
+    if mapper2 is None:
+        for _ in range(steps):
+            ts = time.perf_counter()
+            hits = one_step()                  # (returns the hits: the step is complete on the device when it returns)
+            step_ms.append(1e3 * (time.perf_counter() - ts))
+            e, m = mapper.last_timing()
+            ms_ev.append(e)
+            ms_map.append(m)
+            kept.append(hits)
+    else:
         ts = time.perf_counter()
-        hits = one_step()                  # (returns the hits: the step is complete on the device when it returns)
-        step_ms.append(1e3 * (time.perf_counter() - ts))
-        e, m = mapper.last_timing()
-        ms_ev.append(e)
-        ms_map.append(m)
-        kept.append(hits)
+        begin(pair[0])
+        for k in range(steps):
+            if k + 1 < steps:
+                begin(pair[(k + 1) % 2])
+            hits = pair[k % 2].end_batch()     # (batch k complete: its hits are on the host)
+            tn = time.perf_counter()
+            step_ms.append(1e3 * (tn - ts))
+            ts = tn
+            e, m = pair[k % 2].last_timing()
+            ms_ev.append(e)
+            ms_map.append(m)
+            if hasattr(mapper.L, "unc_mapper_last_window"):
+                windows.append(pair[k % 2].last_window())
+            kept.append(hits)
     sync()
     barrier()
     dt = time.perf_counter() - t0
     # self-verification, outside the timed region: every step must have produced the same bytes
     digests = [capi.hits_digest(h) for h in kept]      # (every result field; map_ms is a wall-clock measurement)
     del kept
+    per_rank = None
     if dist is not None:
+        # MAX over ranks is the job's time; every rank's own time goes along (min / median / max): a scaling curve must be able to tell
+        # one slow rank from a slow design
         t = torch.tensor([dt], dtype=torch.float64, device=dev_name if have_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        ts_ = sorted(float(x.item()) for x in allt)
+        per_rank = {"min": 1e3 * ts_[0] / steps, "median": 1e3 * ts_[len(ts_) // 2] / steps, "max": 1e3 * ts_[-1] / steps,
+                    "unit": "ms per step, each rank's own timed region"}
+        dt = ts_[-1]
     assert len(set(digests)) == 1, f"{workload}: hits differ between timed steps: {digests}"
 
     wave_busy = mapper.last_wave_busy()
     remap_n, remap_ms = mapper.last_remap()
     res = {"value": n_reads * world * steps / dt, "ms_per_step": 1e3 * dt / steps, "dt": dt}
+    if per_rank:
+        res["per_rank"] = per_rank
     pcie, phase_share, t1_info = None, None, None
     if extras and rank == 0 and world == 1:
         if have_gpu and workload == "ecoli":
@@ -432,7 +521,26 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
         phase_share = {k: round(v / tot_c, 4) for k, v in pc.items()}
     if rank == 0:
         ev_bytes, map_bytes = algorithmic_bytes(hits, offsets)
-        map_ms = float(np.mean(ms_map))
+        map_ms_each = float(np.mean(ms_map))
+        map_ms = map_ms_each
+        overlap = None
+        if len(windows) == steps and steps > 1:
+            # batches of two mappers in flight at once: the launches overlap (a launch waits for wavefront slots while its predecessor's
+            # last long reads finish, then takes them over), so the time k_map holds the device PER BATCH is the union of the launches'
+            # windows (HIP events on one time axis, unc_mapper_last_window) over the number of batches -- the denominator of a
+            # throughput roofline; the mean length of a window (launch_ms_each: what rocprofv3 lists per dispatch) counts the shared
+            # stretches twice
+            iv = sorted(windows)
+            union, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > cur_e:
+                    union += cur_e - cur_s
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            union += cur_e - cur_s
+            map_ms = union / steps
+            overlap = {"launch_ms_each": map_ms_each, "union_ms": union, "launches": steps, "mean_launches_resident": sum(e_ - s_ for s_, e_ in iv) / union}
         ev_ms = float(np.mean(ms_ev))
         achieved = map_bytes / (map_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(a, workload)
@@ -451,6 +559,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                        "mapped_fraction": float(hits["mapped"].mean()),
                        "mean_events_per_read": float(hits["event_i"].mean()),
                        "kernel_ms": {"k_events": ev_ms, "k_map": map_ms},
+                       "batches_in_flight": len(pair),
                        "step_ms": {"median": float(np.median(step_ms)), "min": float(np.min(step_ms)), "max": float(np.max(step_ms)),
                                    "k_map_min": float(np.min(ms_map)), "k_map_max": float(np.max(ms_map))},
                        "k_map_phase_cycle_share": phase_share,
@@ -471,7 +580,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": (traffic / map_bytes) if traffic else None,
                          "issue": issue, "bound_note": bound_note,
-                         "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms,
+                         "algorithmic_bytes_per_launch": map_bytes, "launch_ms": map_ms, "launch_ms_each": map_ms_each, "overlap": overlap,
                          "whole_path_bytes_per_step": ev_bytes + map_bytes,
                          "k_events": {"algorithmic_bytes_per_launch": ev_bytes, "launch_ms": ev_ms,
                                       "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9 if ev_ms > 0 else None}},
@@ -497,6 +606,8 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
             res["cpu_baseline"]["sample"] += "; reads drawn at random across the batch (seed 12345)"
             res["verify"]["reads_checked_vs_cpu"] = res["cpu_baseline"]["paf_reads_checked"]
             res["verify"]["paf_mismatches"] = res["cpu_baseline"]["paf_mismatches_vs_gpu"]
+    if mapper2 is not None:
+        mapper2.close()
     mapper.close()
     ix.close()
     del sim
@@ -612,7 +723,7 @@ def compact_block(blk, top=True):
         return {k: str(v)[:160] for k, v in blk.items()}
     out = _pick(blk, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")
     cfg = blk.get("config", {})
-    c = _pick(cfg, "reads_per_gpu_per_step", "mapped_fraction", "mean_events_per_read", "chunks_per_sec", "reads_finished")
+    c = _pick(cfg, "reads_per_gpu_per_step", "mapped_fraction", "mean_events_per_read", "chunks_per_sec", "reads_finished", "batches_in_flight")
     if "kernel_ms" in cfg:
         c["kernel_ms"] = {k: _r(v, 5) for k, v in cfg["kernel_ms"].items()}
     if "latency_ms" in cfg:
@@ -625,9 +736,18 @@ def compact_block(blk, top=True):
         c["node_pool"] = cfg["node_pool"]
     out["config"] = c
     if "roofline" in blk:
-        keys = ("achieved", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "launch_ms")
+        keys = ("achieved", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "launch_ms", "launch_ms_each")
         out["roofline"] = _pick(blk["roofline"], *((("bound", "kernel", "peak", "unit") + keys) if top else keys))
         out["roofline"].setdefault("traffic", None)
+        iss = blk["roofline"].get("issue") or {}
+        if iss.get("valu_pipe_busy") is not None:
+            out["roofline"]["valu_pipe_busy"] = _r(iss["valu_pipe_busy"], 3)       # the physically binding side: issue, not bytes
+        if iss.get("wave_cycle_shares", {}).get("wave_cycle_share_wait_any") is not None:
+            out["roofline"]["wave_wait_share"] = _r(iss["wave_cycle_shares"]["wave_cycle_share_wait_any"], 3)
+    if blk.get("ms_per_read"):
+        out["ms_per_read"] = {k: _r(v, 4) for k, v in blk["ms_per_read"].items()}
+    if blk.get("per_rank"):
+        out["per_rank"] = {k: _r(v, 5) for k, v in blk["per_rank"].items() if k != "unit"}
     if "cpu_baseline" in blk:
         out["cpu_baseline"] = _pick(blk["cpu_baseline"], "value", "unit", "cores", "kind", "paf_reads_checked", "paf_mismatches_vs_gpu")
         out["cpu_baseline"]["sample"] = str(blk["cpu_baseline"].get("sample", ""))[:120 if top else 48]
@@ -703,6 +823,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool-chunks", type=int, default=0, help="chunks of the seed-cluster node pool (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed passes (PCIe-inclusive rate, phase cycle shares)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="one mapper, the steps one after the other (default: two mappers, batch k + 1 begun while batch k's tail drains)")
     ap.add_argument("--workload", choices=["ecoli", "chr20", "hs400", "grch38", "realtime", "example"], default="ecoli",
                     help="headline workload (the driver runs the default: BASELINE config 2)")
     ap.add_argument("--secondary", default=os.environ.get("UNC_BENCH_SECONDARY"),
@@ -791,6 +913,13 @@ def main():
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
+        if "per_rank" in head:
+            out["per_rank"] = head["per_rank"]
+        # the metric's second half (BASELINE.json: "+ mean ms/read"; the PAF `mt` tag, README.md:204-217 / mapper.cpp:197): per read, on
+        # the device (residence of a read: first event taken up -> decided) and in the reference on the host cores
+        g = head["config"].get("gpu_ms_per_read") or {}
+        cm = (head.get("cpu_baseline") or {}).get("ms_per_read") or {}
+        out["ms_per_read"] = {"gpu_mean": g.get("mean"), "gpu_median": g.get("median"), "cpu_mean": cm.get("mean"), "cpu_median": cm.get("median")}
         if placement:
             out["config"]["host_placement_rank0"] = placement
     # secondary blocks.  N = 1: config 5 (realtime), config 3 (chr20) and one GPU's share of config 4 (GRCh38, 250 k reads).

@@ -202,8 +202,21 @@ uint64_t unc_mapper_device_bytes(const unc_mapper_t *m);
  * hipStream_t (NULL = the mapper's own stream).  hits (host, n_reads) receives one record per read. */
 int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
                   const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits);
+/* The same batch in two halves (unc_map_batch = the two in a row).  _begin stages the reads and launches the kernels on `stream` (NULL:
+ * the mapper's own stream) and returns at once; _end waits, maps again the few reads that need it and fills hits[0 .. n_reads).  `raw`
+ * (on_device != 0: a device pointer) must stay valid until _end; `offsets` and `calib` are copied by _begin.  One batch per mapper at a
+ * time.  What it is for: the worker loop of MapPool::MapperThread::run (map_pool.cpp:130-158) with TWO mappers over one index -- batch
+ * k + 1 is begun on the second while batch k's last long reads finish on the first, and moves into the compute units as they fall idle
+ * (a persistent launch ends with a few wavefronts on a few long reads: 6 % of a 50 k-read E. coli launch). */
+int unc_map_batch_begin(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                        const unc_calib_t *calib, int on_device, void *stream);
+int unc_map_batch_end(unc_mapper_t *m, unc_hit_t *hits);
 /* wall-clock of the kernels of the last unc_map_batch, from HIP events on the launch stream */
 int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map);
+/* when k_map of the mapper's last batch was submitted and when it ended, in milliseconds on ONE time axis per process (HIP events
+ * against a reference event): with batches of two mappers in flight at once (unc_map_batch_begin) the launches overlap, and the time
+ * the kernel holds the device per batch is the union of these windows over the number of batches, not the mean of their lengths */
+int unc_mapper_last_window(const unc_mapper_t *m, double *start_ms, double *end_ms);
 /* shader-clock cycles summed over the reads of the last batch, per k_map phase:
  * [0] match probs, [1] extension (loop overhead), [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed,
  * [7] rest, [8] E1 parent loads + candidates, [9] E2 FM look-ups, [10] E3 child slots, [11] E4 child records */

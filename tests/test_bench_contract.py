@@ -203,3 +203,62 @@ def test_algorithmic_bytes_formula():
     # k_events 2 S + 4 E_kept + 24; k_map 4 E_popped + 128 N_nbr + 64 N_lf + 8 N_sa + 64
     assert ev == (2 * 1000 + 4 * 10 + 24) + (2 * 2000 + 4 * 20 + 24)
     assert mp == (4 * 5 + 128 * 100 + 64 * 3 + 8 * 1 + 64) + (4 * 20 + 128 * 7 + 0 + 0 + 64)
+
+
+def test_counter_records_are_keyed_by_the_kernel_they_were_taken_on(tmp_path):
+    """roofline.traffic / roofline.issue come from committed rocprofv3 passes (the counters cannot be read from inside bench.py).  A
+    record names the kernel it was taken on by the hash of the kernel's sources (tools/dev/summarise_pmc.py / summarise_sq.py write it);
+    bench.py uses a record only for THAT kernel, workload and batch size and says why not otherwise -- round 5's line carried the
+    traffic of a kernel two revisions old for chr20 without a word.  One flipped character of the hash, or of a source, and the
+    traffic is null."""
+    import argparse
+    mod = _bench_module()
+    a = argparse.Namespace(reads=50000, chr20_reads=200000, grch38_reads=250000)
+    h = mod.kernel_source_hash()
+    assert len(h) == 64 and h == mod.kernel_source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rec = {"workload": "ecoli", "reads_per_launch": 50000, "kernel_source_sha256": h, "hbm_bytes_per_launch": 7.0e12}
+    (prof / "r06_pmc_k_map_ecoli.json").write_text(json.dumps(rec))
+    d, why = mod.pmc_record("k_map", "ecoli", a, profiles=prof)
+    assert d is not None and why is None and d["hbm_bytes_per_launch"] == 7.0e12
+    # one flipped character of the stored hash: the record is of another kernel
+    rec["kernel_source_sha256"] = ("0" if h[0] != "0" else "1") + h[1:]
+    (prof / "r06_pmc_k_map_ecoli.json").write_text(json.dumps(rec))
+    d, why = mod.pmc_record("k_map", "ecoli", a, profiles=prof)
+    assert d is None and "another kernel" in why
+    # one flipped byte of a kernel source: the running kernel is another one
+    src = tmp_path / "csrc"
+    src.mkdir()
+    for name in mod.KERNEL_SOURCES:
+        (src / name).write_bytes((ROOT / "uncalled_amd" / "csrc" / name).read_bytes())
+    assert mod.kernel_source_hash(src) == h
+    b = bytearray((src / "k_map.hip").read_bytes())
+    b[100] ^= 1
+    (src / "k_map.hip").write_bytes(bytes(b))
+    assert mod.kernel_source_hash(src) != h
+    # another batch size, an older record without a hash: both refused, the newest usable one wins
+    rec["kernel_source_sha256"] = h
+    rec["reads_per_launch"] = 12000
+    (prof / "r06_pmc_k_map_ecoli.json").write_text(json.dumps(rec))
+    (prof / "r05_pmc_k_map_ecoli.json").write_text(json.dumps({"workload": "ecoli", "reads_per_launch": 50000, "hbm_bytes_per_launch": 1.0}))
+    d, why = mod.pmc_record("k_map", "ecoli", a, profiles=prof)
+    assert d is None and "12000" in why and "another kernel" in why
+    # the committed tree: whatever measured_traffic returns for the headline is either null with a reason or a record of THIS kernel
+    t, src_txt = mod.measured_traffic(a, "ecoli")
+    assert (t is None and src_txt) or (t > 0 and "profiles/" in src_txt)
+
+
+def test_compact_line_carries_the_second_half_of_the_metric(tmp_path, monkeypatch, capsys):
+    """BASELINE.json's metric is "reads mapped/sec + mean ms/read": the printed line carries ms_per_read (device residence and the
+    reference's per-read time, mean and median), the issue side of the roofline, and at N > 1 every rank's own time."""
+    mod = _bench_module()
+    full = _line("r05_bench_headline_detail.json")
+    full["ms_per_read"] = {"gpu_mean": 279.159, "gpu_median": 84.7351, "cpu_mean": 547.63, "cpu_median": 220.856}
+    full["per_rank"] = {"min": 2400.123456, "median": 2450.0, "max": 2501.0, "unit": "ms per step, each rank's own timed region"}
+    monkeypatch.setenv("UNC_BENCH_DETAIL", str(tmp_path / "bench_detail.json"))
+    b = strict_line(mod.emit(full))
+    capsys.readouterr()
+    assert b["ms_per_read"] == {"gpu_mean": 279.2, "gpu_median": 84.74, "cpu_mean": 547.6, "cpu_median": 220.9}
+    assert b["per_rank"] == {"min": 2400.1, "median": 2450.0, "max": 2501.0}
+    assert 0 < b["roofline"]["valu_pipe_busy"] < 1 and 0 < b["roofline"]["wave_wait_share"] < 1

@@ -17,7 +17,7 @@ def declared_symbols():
 
 def test_header_declares_the_boundary():
     syms = declared_symbols()
-    for must in ("unc_index_load", "unc_mapper_create", "unc_map_batch", "unc_detect_events", "unc_params_default"):
+    for must in ("unc_index_load", "unc_mapper_create", "unc_map_batch", "unc_map_batch_begin", "unc_map_batch_end", "unc_detect_events", "unc_params_default"):
         assert must in syms
 
 

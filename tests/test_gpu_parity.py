@@ -91,6 +91,10 @@ def test_parameter_variants(hip_lib, oracle_lib, example, goldens):
     pc.case_parameter_variants(hip_lib, oracle_lib, example, goldens)
 
 
+def test_batch_in_two_halves(hip_lib, oracle_lib, example, goldens):
+    pc.case_batch_in_two_halves(hip_lib, oracle_lib, example, goldens, n_reads=24)
+
+
 def test_same_row_two_kmers_walked_again_on_wide_keys(hip_lib, oracle_lib, tmp_path):
     pc.case_same_row_two_kmers(hip_lib, oracle_lib, tmp_path)
 

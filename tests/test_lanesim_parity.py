@@ -36,6 +36,10 @@ def test_example_read_full_path(sim_lib, oracle_lib, example, goldens):
     pc.case_example_read_full_path(sim_lib, oracle_lib, example, goldens)
 
 
+def test_batch_in_two_halves(sim_lib, oracle_lib, example, goldens):
+    pc.case_batch_in_two_halves(sim_lib, oracle_lib, example, goldens)
+
+
 def test_same_row_two_kmers_walked_again_on_wide_keys(sim_lib, oracle_lib, tmp_path):
     pc.case_same_row_two_kmers(sim_lib, oracle_lib, tmp_path)
 

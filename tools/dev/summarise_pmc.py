@@ -44,7 +44,9 @@ def durations(dirname, kernel_sub):
     return d
 
 
-res = {"workload": workload, "reads_per_launch": reads,
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import bench  # noqa: E402  (kernel_source_hash: the record is keyed by the kernel it was taken on; bench.py refuses it for another)
+res = {"workload": workload, "reads_per_launch": reads, "kernel_source_sha256": bench.kernel_source_hash(),
        "kernel": "unc::k_map<false, false> (64-bit rows, 128-bit keys)" if workload == "grch38" else "unc::k_map<false, true> (32-bit rows)",
        "command": f"rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python tools/dev/ab_libs.py {reads}:{workload} "
                   "uncalled_amd/libuncalled_hip.so (the bench's batch: same index, same reads, one k_map dispatch; one pass per counter; "

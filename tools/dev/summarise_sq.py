@@ -33,7 +33,9 @@ for d in sorted(p for p in src.iterdir() if p.is_dir()):
             if "k_map" in r.get("Kernel_Name", ""):
                 dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
     passes[d.name] = {"counters": sorted(names), "k_map_dispatches": len(disp), "k_map_ms_under_pmc": dur}
-res = {"workload": workload, "reads_per_launch": reads,
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import bench  # noqa: E402  (kernel_source_hash: the record is keyed by the kernel it was taken on; bench.py refuses it for another)
+res = {"workload": workload, "reads_per_launch": reads, "kernel_source_sha256": bench.kernel_source_hash(),
        "kernel": "unc::k_map<false, false> (64-bit rows, 128-bit keys)" if workload == "grch38" else "unc::k_map<false, true> (32-bit rows)",
        "passes": passes, "counters": tot,
        "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (MI355X_MICROARCH.md); one k_map dispatch per pass"}

@@ -146,6 +146,11 @@ def load(path=None):
     L.unc_mapper_free.argtypes = [vp]
     L.unc_mapper_device_bytes.argtypes = [vp]; L.unc_mapper_device_bytes.restype = u64
     L.unc_map_batch.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp, vp]
+    if hasattr(L, "unc_mapper_last_window"):
+        L.unc_mapper_last_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "unc_map_batch_begin"):
+        L.unc_map_batch_begin.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp]
+        L.unc_map_batch_end.argtypes = [vp, vp]
     L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
     L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
@@ -332,9 +337,35 @@ class Mapper:
                allow=(UNC_ERR_OVERFLOW,) if allow_overflow else ())
         return hits
 
+    def begin_batch(self, raw, offsets_u64, calib, on_device=False, stream=None):
+        """unc_map_batch_begin: stage the reads and launch the kernels (raw: a host int16 array, or with on_device the integer device address
+        of the samples); returns at once.  end_batch() waits and returns HIT[n_reads].  One batch per mapper at a time."""
+        off = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        cal = np.ascontiguousarray(calib, dtype=CALIB)
+        self._pending_n = off.size - 1
+        if on_device:
+            ptr = C.c_void_p(raw)
+        else:
+            self._pending_raw = np.ascontiguousarray(raw, dtype=np.int16)      # (must outlive the call: the copy to the device is asynchronous)
+            ptr = C.c_void_p(self._pending_raw.ctypes.data)
+        _check(self.L, self.L.unc_map_batch_begin(self.h, self._pending_n, ptr, off.ctypes.data, cal.ctypes.data, 1 if on_device else 0,
+                                                  C.c_void_p(stream or 0)))
+
+    def end_batch(self, allow_overflow=False):
+        hits = np.zeros(self._pending_n, dtype=HIT)
+        _check(self.L, self.L.unc_map_batch_end(self.h, hits.ctypes.data), allow=(UNC_ERR_OVERFLOW,) if allow_overflow else ())
+        self._pending_raw = None
+        return hits
+
     def last_timing(self):
         a, b = C.c_float(), C.c_float()
         self.L.unc_mapper_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def last_window(self):
+        """(start, end) of the last batch's k_map in ms on the process-wide time axis (unc_mapper_last_window)"""
+        a, b = C.c_double(), C.c_double()
+        _check(self.L, self.L.unc_mapper_last_window(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def last_remap(self):

@@ -860,19 +860,18 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
     // narrow keys: the sorted keys of the pass after next and the info words (seed_prob, idx, flags, k-mer) they
     // point to for the next pass are fetched while this pass is worked on; a lane's successor comes from
     // its neighbour lane, the last lane's from the next pass
+    // (every lane asks in every pass -- a lane past the end for the last key, a lane whose k-mer starts no source for entry 0 -- so that
+    // the waits can be counted: see merge_walk)
     uint64_t kq0 = ~0ull, kq1 = ~0ull, bq0 = 0, bq1 = 0;
+    u32x4_t krq = {1u, 0u, 0u, 0u};
     if (kl) {
         walk_begin_narrow(lane);
-        if ((uint32_t)lane < n) kq0 = skeys64[lane];
-        if ((uint32_t)lane + WAVE < n) kq1 = skeys64[lane + WAVE];
-        if ((uint32_t)lane < n) bq0 = infow[kq0 & 0xFFFFu];
-        if ((uint32_t)lane + WAVE < n) bq1 = infow[kq1 & 0xFFFFu];
-    }
-    // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
-    ulonglong2 krq = make_ulonglong2(1ull, 0ull);
-    if (kl && (uint32_t)lane < n) {
+        const uint64_t k0 = skeys64[(uint32_t)lane < n ? (uint32_t)lane : n - 1u], k1 = skeys64[(uint32_t)lane + WAVE < n ? (uint32_t)lane + WAVE : n - 1u];
+        bq0 = infow[k0 & 0xFFFFu]; bq1 = infow[k1 & 0xFFFFu];
+        kq0 = (uint32_t)lane < n ? k0 : ~0ull; kq1 = (uint32_t)lane + WAVE < n ? k1 : ~0ull;
+        // ... and so is the k-mer's full range, for the few children whose k-mer may start a source
         const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
-        if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+        krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[km0] >= source_prob ? km0 : 0u));
     }
     for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t i = base + (uint32_t)lane;
@@ -884,6 +883,7 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
         uint32_t kmer, nkmer;
         bool dup;
         ulonglong2 krc = make_ulonglong2(1ull, 0ull);
+        uint32_t kq2i = 0;
         if (kl) {
             const uint64_t ki = kq0, bi = bq0;
             uint64_t kn = (uint64_t)__shfl((unsigned long long)ki, (lane + 1) & 63);
@@ -891,12 +891,17 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
             const uint64_t kf = bcast64(kq1, 0), bf = bcast64(bq1, 0);
             if (lane == WAVE - 1) { kn = kf; bn = bf; }
             kq0 = kq1; bq0 = bq1;
-            kq1 = i + 2 * WAVE < n ? skeys64[i + 2 * WAVE] : ~0ull;
-            krc = krq;
-            krq = make_ulonglong2(1ull, 0ull);
-            if (i + WAVE < n) {
+            {
+                const uint64_t k2 = skeys64[i + 2 * WAVE < n ? i + 2 * WAVE : n - 1u];
+                kq1 = i + 2 * WAVE < n ? k2 : ~0ull;
+                kq2i = (uint32_t)(k2 & 0xFFFFu);
+            }
+            u32x4_t kt = krq;
+            mem_retire(kt);
+            krc.x = ((uint64_t)kt.y << 32) | kt.x; krc.y = ((uint64_t)kt.w << 32) | kt.z;
+            {
                 const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
-                if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+                krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[kmn] >= source_prob ? kmn : 0u));
             }
             walk_decode_narrow<NARROW>(S, kl, ki, kn, bi, bn, have, has_next, nv, lane, start, end, nstart, kmer, nkmer, dup, sbw);
         } else {
@@ -912,7 +917,7 @@ static __device__ __noinline__ void phase_W(kargs_t A_, gptr_t sb_, int lane) {
             sbw = ki.b;                              // sorted by seed_prob inside the run: the last one survives
         }
         walk_core<NARROW>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, sbw, kl != 0, krc, nv, lane);
-        if (kl) bq1 = i + 2 * WAVE < n ? infow[kq1 & 0xFFFFu] : 0ull;
+        if (kl) bq1 = infow[kq2i];
     }
     walk_finish<NARROW>(C, S, lane);
 }
@@ -946,21 +951,7 @@ static __device__ __noinline__ void merge_walk(kargs_t A_, gptr_t sb_, KeyArr<1>
         const uint32_t a1 = last_tile ? KA.n : merge_split(sb, KA, KB, d1, lane);
         const uint32_t b1 = d1 - a1;
         const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
-        {
-            uint64_t v[MERGE_C];
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                v[c] = 0;
-                if (i < na) v[c] = ka_load(sb, KA, a0 + i);
-                else if (i < tn) v[c] = ka_load(sb, KB, b0 + (i - na));
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                if (i < tn) s_tile[mslot(i)] = v[c];
-            }
-        }
+        stage_tile(sb, KA, KB, a0, b0, na, tn, s_tile, lane);
         wave_sync();
         const uint32_t d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
         const uint32_t cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
@@ -1085,28 +1076,13 @@ static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<
     uint32_t a0 = 0, b0 = 0;
     SortKey pend_key; pend_key.a = 0; pend_key.b = 0;      // the previous tile's last key: walked first in this tile
     bool have_pend = false, bad = false;
-    const ulonglong2 no_range = make_ulonglong2(1ull, 0ull);
     for (uint32_t o0 = 0; o0 < n; o0 += MERGEW_TILE) {
         const uint32_t d1 = o0 + MERGEW_TILE < n ? o0 + MERGEW_TILE : n;
         const bool last_tile = d1 == n;
         const uint32_t a1 = last_tile ? KA.n : mergew_split(sb, KA, KB, d1, lane);
         const uint32_t b1 = d1 - a1;
         const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
-        {
-            SortKey v[MERGEW_C];
-#pragma unroll
-            for (uint32_t c = 0; c < MERGEW_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                v[c].a = 0; v[c].b = 0;
-                if (i < na) v[c] = kaw_load(sb, KA, a0 + i);
-                else if (i < tn) v[c] = kaw_load(sb, KB, b0 + (i - na));
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < MERGEW_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                if (i < tn) tile[i] = v[c];
-            }
-        }
+        stagew_tile(sb, KA, KB, a0, b0, na, tn, tile, lane);
         wave_sync();
         SortKey o[MERGEW_C];
         uint32_t d, cnt;
@@ -1131,11 +1107,27 @@ static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<
         if (lane == 0 && have_pend) tile[0] = pend_key;
         wave_sync();
         const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
+        // the k-mer's full range, for the few children whose k-mer may start a source: asked for a pass ahead, by every lane (one
+        // countable request per pass; a lane whose k-mer starts no source asks for entry 0), as in merge_walk
+        const UNC_AS_GLOBAL ulonglong2 *const kmer_ranges2 = (const UNC_AS_GLOBAL ulonglong2 *)A->ix.kmer_ranges;
+        ulonglong2 krq;
+        {
+            const uint32_t pa = p0 + (uint32_t)lane;
+            const uint32_t km0 = (uint32_t)(tile[pa <= tn ? pa : tn].b & META_KMER_MASK);
+            krq = g_load(kmer_ranges2 + (s_probs[km0] >= C.source_prob ? km0 : 0u));
+        }
         for (uint32_t base = p0; base < p1; base += WAVE) {
             const uint32_t p = base + (uint32_t)lane;
             const bool have = p < p1;
             const bool has_next = have && p < tn;
             const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
+            ulonglong2 krc = krq;
+            mem_retire(krc);
+            {
+                const uint32_t pn = p + WAVE;
+                const uint32_t kmn = (uint32_t)(tile[pn <= tn ? pn : tn].b & META_KMER_MASK);
+                krq = g_load(kmer_ranges2 + (s_probs[kmn] >= C.source_prob ? kmn : 0u));
+            }
             SortKey ki, kn;
             ki.a = ~0ull; ki.b = 0; kn.a = ~0ull; kn.b = ~0ull;
             if (have) ki = tile[p];
@@ -1144,7 +1136,7 @@ static __device__ __noinline__ void merge_walk_w(kargs_t A_, gptr_t sb_, KeyArr<
             const uint32_t kmer = have ? (uint32_t)(ki.b & META_KMER_MASK) : NKMER + 1u;
             const uint32_t nkmer = has_next ? (uint32_t)(kn.b & META_KMER_MASK) : NKMER + 2u;
             const bool dup = has_next && kn.a == ki.a;          // equal fm_range_, :569 (sorted by seed_prob inside the run: the last one survives)
-            walk_core<false>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, ki.b, false, no_range, nv, lane);
+            walk_core<false>(C, S, have, has_next, start, end, nstart, kmer, nkmer, dup, ki.b, true, krc, nv, lane);
         }
         pend_key.a = uniform64(tile[tn].a); pend_key.b = uniform64(tile[tn].b);
         have_pend = true;
@@ -1969,21 +1961,7 @@ __device__ __forceinline__ void team_merge_tile(cgptr_t sb, const KeyArr<RA> &A,
     const uint32_t b0 = d0 - a0, b1 = d1 - a1;
     const uint32_t na = a1 - a0, nb = b1 - b0;
     tn = na + nb;
-    {
-        uint64_t v[MERGE_C];
-#pragma unroll
-        for (uint32_t c = 0; c < MERGE_C; ++c) {
-            const uint32_t i = (uint32_t)lane + c * WAVE;
-            v[c] = 0;
-            if (i < na) v[c] = ka_load(sb, A, a0 + i);
-            else if (i < tn) v[c] = ka_load(sb, B, b0 + (i - na));
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < MERGE_C; ++c) {
-            const uint32_t i = (uint32_t)lane + c * WAVE;
-            if (i < tn) tile[mslot(i)] = v[c];
-        }
-    }
+    stage_tile(sb, A, B, a0, b0, na, tn, tile, lane);
     wave_sync();
     d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;
     cnt = tn - d < MERGE_C ? tn - d : MERGE_C;
@@ -2143,34 +2121,36 @@ static __device__ __noinline__ bool phase_S_team(kargs_t A_, gptr_t sb_, int lan
                 }
                 wave_sync();
                 const uint32_t p0 = have_pend ? 0u : 1u, p1 = last_tile ? tn + 1u : tn;
-                uint64_t bq0 = 0, bq1 = 0;
+                uint64_t bq0, bq1;          // (every lane asks in every pass, so that the waits can be counted: see merge_walk)
                 {
                     const uint32_t pa = p0 + (uint32_t)lane, pb = pa + WAVE;
-                    if (pa <= tn) bq0 = infow[wt[mslot(pa)] & 0xFFFFu];
-                    if (pb <= tn) bq1 = infow[wt[mslot(pb)] & 0xFFFFu];
+                    bq0 = infow[wt[mslot(pa <= tn ? pa : tn)] & 0xFFFFu];
+                    bq1 = infow[wt[mslot(pb <= tn ? pb : tn)] & 0xFFFFu];
                 }
-                ulonglong2 krq = make_ulonglong2(1ull, 0ull);
-                if (p0 + (uint32_t)lane < p1) {
+                u32x4_t krq;
+                {
                     const uint32_t km0 = (uint32_t)(bq0 & META_KMER_MASK);
-                    if (s_probs[km0] >= source_prob) krq = g_load(kmer_ranges2 + km0);
+                    krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[km0] >= source_prob ? km0 : 0u));
                 }
                 for (uint32_t base = p0; base < p1; base += WAVE) {
                     const uint32_t p = base + (uint32_t)lane;
                     const bool have = p < p1;
                     const bool has_next = have && p < tn;
                     const uint32_t nv = p1 - base < WAVE ? p1 - base : WAVE;
-                    const uint64_t bq2 = p + 2 * WAVE <= tn ? infow[wt[mslot(p + 2 * WAVE)] & 0xFFFFu] : 0ull;      // (requested ahead of the pass's work: merge_walk)
+                    const uint64_t bq2 = infow[wt[mslot(p + 2 * WAVE <= tn ? p + 2 * WAVE : tn)] & 0xFFFFu];      // (requested ahead of the pass's work: merge_walk)
                     const uint64_t ki = have ? wt[mslot(p)] : ~0ull, kn = has_next ? wt[mslot(p + 1u)] : ~0ull;
                     const uint64_t bi = bq0;
                     uint64_t bn = (uint64_t)__shfl((unsigned long long)bi, (lane + 1) & 63);
                     const uint64_t bf = bcast64(bq1, 0);
                     if (lane == WAVE - 1) bn = bf;
                     bq0 = bq1;
-                    const ulonglong2 krc = krq;
-                    krq = make_ulonglong2(1ull, 0ull);
-                    if (p + WAVE < p1) {
+                    u32x4_t kt = krq;
+                    mem_retire(kt);
+                    ulonglong2 krc;
+                    krc.x = ((uint64_t)kt.y << 32) | kt.x; krc.y = ((uint64_t)kt.w << 32) | kt.z;
+                    {
                         const uint32_t kmn = (uint32_t)(bq0 & META_KMER_MASK);
-                        if (s_probs[kmn] >= source_prob) krq = g_load(kmer_ranges2 + kmn);
+                        krq = g_load(reinterpret_cast<const UNC_AS_GLOBAL u32x4_t *>(kmer_ranges2) + (s_probs[kmn] >= source_prob ? kmn : 0u));
                     }
                     uint32_t start, end, nstart, kmer, nkmer;
                     uint64_t sbw;

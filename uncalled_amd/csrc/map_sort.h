@@ -394,6 +394,28 @@ __device__ __forceinline__ uint32_t merge_split(cgptr_t sb, const KeyArr<RA> &A,
     return lo;
 }
 
+// A tile's share of A (na keys from a0) and of B (from b0) into the tile buffer, tn keys in all (tn > 0).  Nine requests in a row and ONE
+// wait: every lane asks in every round (a lane past the tile's end for the tile's last key) and the address is a select, not a branch --
+// written as `if (i < na) load A; else if (i < tn) load B` each load sat in a block of its own and the compiler drained the memory
+// counter between them (round 6, off the ISA: three round trips in a row where one was meant).
+template <int RA, int RB>
+__device__ __forceinline__ void stage_tile(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t a0, uint32_t b0, uint32_t na, uint32_t tn,
+                                           uint64_t *s_tile, int lane) {
+    uint64_t v[MERGE_C];
+#pragma unroll
+    for (uint32_t c = 0; c < MERGE_C; ++c) {
+        const uint32_t i0 = (uint32_t)lane + c * WAVE, i = i0 < tn ? i0 : tn - 1u;
+        const uint32_t ja = a0 + i, jb = b0 + (i - na);
+        const uint32_t off = i < na ? ka_adj(A, ja) + (ja << 3) : ka_adj(B, jb) + (jb << 3);
+        v[c] = gld<uint64_t>(sb, off);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < MERGE_C; ++c) {
+        const uint32_t i = (uint32_t)lane + c * WAVE;
+        if (i < tn) s_tile[mslot(i)] = v[c];
+    }
+}
+
 template <int RA, int RB>
 static __device__ __noinline__ uint32_t merge_runs(gptr_t sb_, KeyArr<RA> A_, KeyArr<RB> B_, uint32_t out_off_, int lane, uint32_t verify_) {
     const gptr_t sb = uniform_ptr(sb_);
@@ -411,21 +433,7 @@ static __device__ __noinline__ uint32_t merge_runs(gptr_t sb_, KeyArr<RA> A_, Ke
         const uint32_t b1 = d1 - a1;
         const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
         // stage the tile: every load is requested before the first key goes into LDS (one memory round trip, not twelve)
-        {
-            uint64_t v[MERGE_C];
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                v[c] = 0;
-                if (i < na) v[c] = ka_load(sb, A, a0 + i);
-                else if (i < tn) v[c] = ka_load(sb, B, b0 + (i - na));
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < MERGE_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                if (i < tn) s_tile[mslot(i)] = v[c];
-            }
-        }
+        stage_tile(sb, A, B, a0, b0, na, tn, s_tile, lane);
         wave_sync();
         // this lane's outputs [d, d + cnt)
         const uint32_t d = (uint32_t)lane * MERGE_C < tn ? (uint32_t)lane * MERGE_C : tn;

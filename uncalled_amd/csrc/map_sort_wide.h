@@ -13,18 +13,35 @@ __device__ __forceinline__ SortKey wk_bcast(const SortKey &k, int src) { SortKey
 
 // a sequence of R runs of 16-byte keys back to back (adj: byte offset of run r inside the slot minus 16 * its first index)
 template <int R> __device__ __forceinline__ SortKey kaw_load(cgptr_t sb, const KeyArr<R> &K, uint32_t i) {
-    // (the select chain of rounds 3-4, NOT map_sort.h's ka_adj: the optimiser keeps `adj` in scratch memory for it, and yet every attempt of
-    // round 5 to take scratch accesses or table loads out of the wide instantiation made GRCh38 slower -- the narrow one gained 11 %)
-    uint32_t a = K.adj[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) a = i >= K.cum[r] ? K.adj[r] : a;
-    return gld<SortKey>(sb, a + (i << 4));
+    // (map_sort.h's ka_adj: a sum of guarded differences.  Rounds 3-5 kept a select chain here, for which the optimiser holds `adj` in
+    // scratch memory -- every key load behind a scratch load and a full wait; round 5 measured the fix as a loss on GRCh38, on launches
+    // whose times come in 10 % quanta.  Round 6 counts round trips instead: the five loads that stage a tile were five trips in a row.)
+    return gld<SortKey>(sb, ka_adj(K, i) + (i << 4));
 }
 __device__ __forceinline__ KeyArr<1> kaw_single(uint32_t off, uint32_t n) { KeyArr<1> K; K.adj[0] = off; K.cum[0] = 0; K.n = n; return K; }
 
 constexpr uint32_t MERGEW_C = 5;
 constexpr uint32_t MERGEW_TILE = MERGEW_C * WAVE;           // 320 keys = 5 KB of the staging buffer (+ the key that waits for its successor)
 static_assert((MERGEW_TILE + 1) * sizeof(SortKey) <= S_E_WORDS * 8, "wide merge tile must fit the staging buffer");
+
+// a tile's share of A and B into the tile buffer: map_sort.h's stage_tile for 16-byte keys (five requests in a row, one wait)
+template <int RA, int RB>
+__device__ __forceinline__ void stagew_tile(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t a0, uint32_t b0, uint32_t na, uint32_t tn,
+                                            SortKey *tile, int lane) {
+    SortKey v[MERGEW_C];
+#pragma unroll
+    for (uint32_t c = 0; c < MERGEW_C; ++c) {
+        const uint32_t i0 = (uint32_t)lane + c * WAVE, i = i0 < tn ? i0 : tn - 1u;
+        const uint32_t ja = a0 + i, jb = b0 + (i - na);
+        const uint32_t off = i < na ? ka_adj(A, ja) + (ja << 4) : ka_adj(B, jb) + (jb << 4);
+        v[c] = gld<SortKey>(sb, off);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < MERGEW_C; ++c) {
+        const uint32_t i = (uint32_t)lane + c * WAVE;
+        if (i < tn) tile[i] = v[c];
+    }
+}
 
 template <int RA, int RB>
 __device__ __forceinline__ uint32_t mergew_split(cgptr_t sb, const KeyArr<RA> &A, const KeyArr<RB> &B, uint32_t d, int lane) {
@@ -55,19 +72,23 @@ __device__ __forceinline__ void mergew_tile(SortKey *tile, uint32_t na, uint32_t
         }
     }
     uint32_t ia = lo, ib = d - lo;
-    // (round 5 tried this loop field by field -- the struct selects below keep va, vb and o in scratch memory in mergew_runs, 17 scratch
-    // stores and 11 scratch loads per tile -- and measured it 3 % SLOWER on GRCh38, profiles/r05_ab_grch38_wide_variants.log: kept as it was)
-    SortKey va = ia < na ? tile[ia] : wk_max(), vb = ib < nb ? tile[na + ib] : wk_max();
+    // field by field: a select between two STRUCTS is a select between their addresses to the optimiser, which then keeps va, vb and o
+    // in scratch memory (17 scratch stores and 11 scratch loads per tile, each load behind a full wait: round 5 saw it and measured the
+    // fix inside GRCh38's 10 % launch-time quanta; round 6 counts the waits)
+    uint64_t vaa = ~0ull, vab = ~0ull, vba = ~0ull, vbb = ~0ull;
+    if (ia < na) { const SortKey t = tile[ia]; vaa = t.a; vab = t.b; }
+    if (ib < nb) { const SortKey t = tile[na + ib]; vba = t.a; vbb = t.b; }
 #pragma unroll
     for (uint32_t c = 0; c < MERGEW_C; ++c) {
-        const bool ta = wk_lt(va, vb);
-        o[c] = ta ? va : vb;
+        const bool ta = vaa < vba || (vaa == vba && vab < vbb);
+        o[c].a = ta ? vaa : vba; o[c].b = ta ? vab : vbb;
         if (ta) ++ia; else ++ib;
         const uint32_t idx = ta ? ia : na + ib;
         const bool ok = ta ? ia < na : ib < nb;
-        SortKey x = wk_max();
-        if (ok && c + 1u < cnt) x = tile[idx];
-        if (ta) va = x; else vb = x;
+        uint64_t xa = ~0ull, xb = ~0ull;
+        if (ok && c + 1u < cnt) { const SortKey t = tile[idx]; xa = t.a; xb = t.b; }
+        vaa = ta ? xa : vaa; vab = ta ? xb : vab;
+        vba = ta ? vba : xa; vbb = ta ? vbb : xb;
     }
 }
 
@@ -86,21 +107,7 @@ static __device__ __noinline__ void mergew_runs(gptr_t sb_, KeyArr<RA> A_, KeyAr
         const uint32_t a1 = d1 == n ? A.n : mergew_split(sb, A, B, d1, lane);
         const uint32_t b1 = d1 - a1;
         const uint32_t na = a1 - a0, nb = b1 - b0, tn = na + nb;
-        {
-            SortKey v[MERGEW_C];
-#pragma unroll
-            for (uint32_t c = 0; c < MERGEW_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                v[c].a = 0; v[c].b = 0;
-                if (i < na) v[c] = kaw_load(sb, A, a0 + i);
-                else if (i < tn) v[c] = kaw_load(sb, B, b0 + (i - na));
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < MERGEW_C; ++c) {
-                const uint32_t i = (uint32_t)lane + c * WAVE;
-                if (i < tn) tile[i] = v[c];
-            }
-        }
+        stagew_tile(sb, A, B, a0, b0, na, tn, tile, lane);
         wave_sync();
         SortKey o[MERGEW_C];
         uint32_t d, cnt;

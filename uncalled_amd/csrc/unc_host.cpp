@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "r94_model_table.h"
@@ -461,6 +462,7 @@ struct unc_mapper {
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double win_start_ms = 0, win_end_ms = 0;      // k_map of the last batch on the process-wide time axis (unc_mapper_last_window)
     float ms_events = 0, ms_map = 0;
     double wave_busy = 0;          // mean wave lifetime / k_map duration of the last batch (1 = no queue tail)
     float wall_khz = 0;            // device wall clock rate (ticks per ms)
@@ -470,7 +472,16 @@ struct unc_mapper {
     // holds more than eight times that, doubled when found dry (pool_fit, unc_mapper_pool_usage); a caller who named pool_chunks
     // keeps that number
     bool pool_auto = false;
-    uint32_t pool_floor = 16, pool_hw_last = 0, pool_hw_max = 0, pool_resizes = 0;
+    uint32_t pool_floor = 16, pool_created = 0, pool_hw_last = 0, pool_hw_max = 0, pool_resizes = 0;
+    // a batch that unc_map_batch_begin has launched and unc_map_batch_end has not yet collected
+    struct Pending {
+        bool active = false;
+        uint32_t n_reads = 0, grid = 0;
+        hipStream_t st = nullptr;
+        DevReads rd{};
+        bool t1 = false;
+        std::vector<uint64_t> lens;      // samples per read (fill_hit)
+    } pend;
     DevScratch big{};              // scratch with a larger node allowance for the reads that outgrew a slot's (kept between batches)
     uint64_t big_cap = 0;
     size_t big_slots = 0;
@@ -593,6 +604,19 @@ extern "C" void unc_mapper_free(unc_mapper_t *m) {
     delete m;
 }
 
+// one reference event per process: the k_map windows of batches on DIFFERENT mappers (streams) on one time axis
+static hipEvent_t g_ref_event = nullptr;
+static std::mutex g_ref_mutex;
+static int ref_event(hipEvent_t *out) {
+    std::lock_guard<std::mutex> lock(g_ref_mutex);
+    if (!g_ref_event) {
+        HIPCHK(hipEventCreate(&g_ref_event));
+        HIPCHK(hipEventRecord(g_ref_event, nullptr));
+        HIPCHK(hipEventSynchronize(g_ref_event));
+    }
+    *out = g_ref_event;
+    return UNC_OK;
+}
 extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, const unc_mapper_opts_t *opts, unc_mapper_t **out) {
     if (!ix || !p || !out) return fail(UNC_ERR_ARG, "null argument");
     *out = nullptr;
@@ -658,6 +682,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
             m->pool_auto = true;
             m->pool_floor = std::max<uint32_t>(16, std::min<uint32_t>(n_slots, n_chunks));
+            m->pool_created = n_chunks;
         }
         int rc2 = alloc_pool(m->pool, n_chunks, &bytes);
         if (rc2) return rc2;
@@ -679,6 +704,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     }
     HIPCHK(hipStreamCreate(&m->stream));
     for (auto &e : m->ev) HIPCHK(hipEventCreate(&e));
+    { hipEvent_t ref = nullptr; int rcr = ref_event(&ref); if (rcr) return rcr; }      // (before the first batch of any mapper)
     guard.p = nullptr;
     *out = m;
     return UNC_OK;
@@ -812,15 +838,21 @@ static int pool_note_high_water(unc_mapper *m, hipStream_t st) {
 
 // After a batch (the pool is idle): a pool that went dry doubles (the reads concerned were mapped again, correctly but late); one
 // that holds more than eight times the most chunks that were ever out at once shrinks to four times that.
-static int pool_fit(unc_mapper *m, bool went_dry) {
+static int pool_fit(unc_mapper *m, bool went_dry, uint32_t n_reads) {
     if (!m->pool_auto) return UNC_OK;
     const uint64_t cur = m->pool.n_chunks;
     uint64_t target = cur;
-    if (went_dry) target = cur * 2;
-    else {
-        // four times the most chunks ever out at once, and only when the pool is more than twice that: the peak of ONE batch moves by
-        // tens of per cent from launch to launch (which reads are deep in their forests at the same time is a matter of scheduling),
-        // and a pool cut to twice one launch's peak was found dry by a later launch of the same batch (15 reads mapped again)
+    if (went_dry) {
+        // found dry: not one doubling per batch (a pool cut after a small first call took several full batches to recover, each with
+        // reads mapped again one by one: round-5 advice) but straight back to what is known to have been enough -- the size it was
+        // created with -- or to four times the most chunks that were out when it ran dry, whichever is more
+        target = std::max<uint64_t>(std::max<uint64_t>(cur * 2, m->pool_created), 4ull * m->pool_hw_max);
+    } else if (n_reads >= m->n_slots) {
+        // cut only after a batch that FILLED the slots (a warm-up call, a handful of reads or a profiling pass over part of a batch say
+        // nothing about what a full load of reads in flight takes): to four times the most chunks ever out at once, and only when the
+        // pool is more than twice that -- the peak of ONE batch moves by tens of per cent from launch to launch (which reads are deep
+        // in their forests at the same time is a matter of scheduling), and a pool cut to twice one launch's peak was found dry by a
+        // later launch of the same batch (15 reads mapped again)
         const uint64_t need = std::max<uint64_t>(m->pool_floor, 4ull * m->pool_hw_max);
         if (need * 2 < cur) target = need;
     }
@@ -832,13 +864,27 @@ static int pool_fit(unc_mapper *m, bool went_dry) {
     }
     if (target == cur) return UNC_OK;
     HIPCHK(hipDeviceSynchronize());
-    m->device_bytes -= (uint64_t)cur * POOL_CHUNK_BYTES;
-    free_pool(m->pool);
+    // the batch's hits are already filled: a resize that fails must neither fail the call nor leave the mapper without a pool.  A
+    // smaller pool is allocated BEFORE the old one is freed (both fit); a larger one may need the old one's memory, and if it cannot
+    // be had the old size is allocated again.
+    DevPool fresh;
     size_t bytes = 0;
-    int rc = alloc_pool(m->pool, (uint32_t)target, &bytes);
-    if (rc) return rc;
+    if (target < cur) {
+        if (alloc_pool(fresh, (uint32_t)target, &bytes) != UNC_OK) { free_pool(fresh); (void)hipGetLastError(); return UNC_OK; }
+        free_pool(m->pool);
+    } else {
+        free_pool(m->pool);
+        if (alloc_pool(fresh, (uint32_t)target, &bytes) != UNC_OK) {
+            free_pool(fresh); (void)hipGetLastError();
+            target = cur;
+            int rc = alloc_pool(fresh, (uint32_t)cur, &bytes);
+            if (rc) { free_pool(fresh); memset(&m->pool, 0, sizeof m->pool); return rc; }      // (the memory was there a moment ago)
+        }
+    }
+    m->pool = fresh;
     m->device_bytes += (uint64_t)target * POOL_CHUNK_BYTES;
-    m->pool_resizes++;
+    m->device_bytes -= (uint64_t)cur * POOL_CHUNK_BYTES;
+    if (target != cur) m->pool_resizes++;
     return UNC_OK;
 }
 
@@ -848,9 +894,14 @@ extern "C" int unc_mapper_pool_usage(const unc_mapper_t *m, uint32_t *out4) {
     return UNC_OK;
 }
 
-extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
-                             const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits) {
-    if (!m || !raw || !offsets || !calib || !hits) return fail(UNC_ERR_ARG, "null argument");
+// A batch in two halves: _begin stages the reads and launches the kernels on the stream and returns; _end waits for them, maps the few
+// reads again that need it, and fills the hits.  Between the two the host is free -- and so is the GPU's tail: the persistent k_map
+// ends with a few long reads on a few wavefronts (wavefronts alive 94 % of a 50 k-read E. coli launch), and a second mapper's batch,
+// begun on its own stream meanwhile, moves into the compute units as they fall idle.  unc_map_batch = the two in a row.
+extern "C" int unc_map_batch_begin(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                                   const unc_calib_t *calib, int on_device, void *stream) {
+    if (!m || !raw || !offsets || !calib) return fail(UNC_ERR_ARG, "null argument");
+    if (m->pend.active) return fail(UNC_ERR_ARG, "unc_map_batch_begin: the mapper's previous batch has not been collected (unc_map_batch_end)");
     HIPCHK(hipSetDevice(m->ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     DevReads rd;
@@ -884,13 +935,40 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
                nullptr, reinterpret_cast<unsigned long long *>(m->d_next + 2), sliced ? &m->sched : nullptr, m->profile, fl_in, fl_out);
     HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());
+    m->pend.active = true; m->pend.n_reads = n_reads; m->pend.grid = grid; m->pend.st = st; m->pend.rd = rd; m->pend.t1 = t1;
+    m->pend.lens.resize(n_reads);
+    for (uint32_t i = 0; i < n_reads; ++i) m->pend.lens[i] = offsets[i + 1] - offsets[i];
+    return UNC_OK;
+}
+
+extern "C" int unc_map_batch_end(unc_mapper_t *m, unc_hit_t *hits) {
+    if (!m || !hits) return fail(UNC_ERR_ARG, "null argument");
+    if (!m->pend.active) return fail(UNC_ERR_ARG, "unc_map_batch_end: no batch has been begun on this mapper");
+    m->pend.active = false;       // (whatever happens below, the batch is over)
+    HIPCHK(hipSetDevice(m->ix->device));
+    const uint32_t n_reads = m->pend.n_reads, grid = m->pend.grid;
+    hipStream_t st = m->pend.st;
+    const DevReads rd = m->pend.rd;
+    const bool t1 = m->pend.t1;
+    constexpr size_t FW = NKMER / 32;
+    const uint32_t *const fl_in = t1 ? m->d_flags_in : nullptr;
+    uint32_t *const fl_out = t1 ? m->d_flags_out : nullptr;
+    int rc = UNC_OK;
     m->h_info.resize(n_reads);
     m->h_results.resize(n_reads);
+    // (the copies into pageable host memory would hold the host until the kernels are done: they are issued here, not in _begin)
     HIPCHK(hipMemcpyAsync(m->h_info.data(), m->d_info, (size_t)n_reads * sizeof(unc_evt_info_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(m->h_results.data(), m->d_results, (size_t)n_reads * sizeof(DevResult), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&m->ms_events, m->ev[0], m->ev[1]));
     HIPCHK(hipEventElapsedTime(&m->ms_map, m->ev[1], m->ev[2]));
+    {
+        hipEvent_t ref = nullptr;
+        float a = 0, b = 0;
+        if (ref_event(&ref) == UNC_OK && hipEventElapsedTime(&a, ref, m->ev[1]) == hipSuccess && hipEventElapsedTime(&b, ref, m->ev[2]) == hipSuccess) {
+            m->win_start_ms = a; m->win_end_ms = b;
+        } else (void)hipGetLastError();
+    }
     for (uint32_t i = 0; i < n_reads; ++i)
         if (m->h_info[i].pad) return fail(UNC_ERR_OVERFLOW, "read %u: more events than the room for event means holds (5/8 of its samples + 16)", i);
     m->pool_hw_last = 0;
@@ -1074,13 +1152,21 @@ extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *r
     }
     int worst = UNC_OK;
     for (uint32_t i = 0; i < n_reads; ++i) {
-        fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], offsets[i + 1] - offsets[i], &hits[i], m->wall_khz);
+        fill_hit(m->ix, m->P, m->h_results[i], m->h_info[i], m->pend.lens[i], &hits[i], m->wall_khz);
         if (hits[i].status) worst = UNC_ERR_OVERFLOW;
     }
-    rc = pool_fit(m, pool_went_dry);
+    rc = pool_fit(m, pool_went_dry, n_reads);
     if (rc) return rc;
     if (worst) return fail(worst, "device scratch overflow on at least one read (see unc_hit_t.status); raise pool_chunks / max_clusters / max_seed_paths");
     return UNC_OK;
+}
+
+extern "C" int unc_map_batch(unc_mapper_t *m, uint32_t n_reads, const int16_t *raw, const uint64_t *offsets,
+                             const unc_calib_t *calib, int on_device, void *stream, unc_hit_t *hits) {
+    if (!hits) return fail(UNC_ERR_ARG, "null argument");
+    const int rc = unc_map_batch_begin(m, n_reads, raw, offsets, calib, on_device, stream);
+    if (rc) return rc;
+    return unc_map_batch_end(m, hits);
 }
 
 extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out8) {
@@ -1124,6 +1210,12 @@ extern "C" void unc_mapper_last_remap(const unc_mapper_t *m, uint32_t *n_reads, 
 extern "C" int unc_mapper_last_timing(const unc_mapper_t *m, float *ms_events, float *ms_map) {
     if (ms_events) *ms_events = m->ms_events;
     if (ms_map) *ms_map = m->ms_map;
+    return UNC_OK;
+}
+
+extern "C" int unc_mapper_last_window(const unc_mapper_t *m, double *start_ms, double *end_ms) {
+    if (!m || !start_ms || !end_ms) return fail(UNC_ERR_ARG, "null argument");
+    *start_ms = m->win_start_ms; *end_ms = m->win_end_ms;
     return UNC_OK;
 }
 
@@ -1219,7 +1311,11 @@ extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, 
     memset(&s0, 0, sizeof s0);
     s0.max_map.rstart = 1; s0.max_map.evt_st = 1;   // NULL_ALN
     HIPCHK(hipMemcpyAsync(slot_state(m->sc, 0), &s0, sizeof s0, hipMemcpyHostToDevice, st));
+    unc_evt_info_t info0;
+    HIPCHK(hipMemcpyAsync(&info0, m->d_info, sizeof info0, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    // (as the batch path: a read whose events overran the room for their means is reported, never traced on a truncated list)
+    if (info0.pad) return fail(UNC_ERR_OVERFLOW, "traced read: more events than the room for event means holds (5/8 of its samples + 16)");
     m->trace_n = n;
     m->trace_active = true;
     return UNC_OK;
@@ -1412,6 +1508,7 @@ struct unc_rt {
     uint64_t device_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double win_start_ms = 0, win_end_ms = 0;      // k_map of the last batch on the process-wide time axis (unc_mapper_last_window)
     float ms_events = 0, ms_map = 0;
     std::vector<RtHostChan> chans;
     std::vector<SlotState> h_state;
