@@ -616,7 +616,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     return res
 
 
-def realtime_workload(a, ix, prefix, codes, lens, local_rank, ref_label, steps, warmup, verify_channels=24, cpu_budget_s=20.0):
+def realtime_workload(a, ix, prefix, codes, lens, local_rank, ref_label, steps, warmup, verify_channels=24, cpu_budget_s=20.0, reads_per_ch=6):
     """BASELINE config 5: 512 channels x 4000-sample chunks, deterministic MAP_ORD-style scheduling; one step = one
     chunk round (every channel hands over its next chunk, all chunks are mapped completely).  Latency is per round.
     verify: the reads `verify_channels` channels finished during the run, against the CPU chunk path (the reference's own
@@ -626,7 +626,7 @@ def realtime_workload(a, ix, prefix, codes, lens, local_rank, ref_label, steps, 
     from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
     from tools.simulate_reads_torch import simulate_reads_torch
     from uncalled_amd import capi
-    n_ch, reads_per_ch = a.channels, 6
+    n_ch = a.channels
     sim = simulate_reads_torch(codes, lens, n_ch * reads_per_ch, seed=777, device=f"cuda:{local_rank}")
     off = sim["offsets"].astype(np.int64)
     rt = capi.Realtime(ix, n_channels=n_ch)

@@ -24,6 +24,26 @@ from tools.simulate_reads import CAL_DIGITISATION, CAL_OFFSET, CAL_RANGE
 from tools.simulate_reads_torch import simulate_reads_torch
 
 workload = sys.argv[1]
+if workload.startswith("rt:"):
+    # the CHUNKED path at scale: python tests/dev/parity_sweep.py rt:<ecoli | chr20> [reads per channel = 12] [rounds = 90]
+    # 512 channels x reads_per_channel reads through unc_rt_* (bench.py's realtime workload, UNC_RT_TEAM wavefronts per channel), then
+    # EVERY read every channel finished before its list wrapped against the reference's own chunk path (Mapper::new_read(Chunk&) /
+    # add_chunk / process_chunk / map_chunk, one Mapper per channel, same per-channel order): PAF columns.  Round-5 review: the chunked
+    # path -- other event-detector and normaliser code than the batch path -- had been checked on about a hundred reads per run.
+    import argparse
+    ref = workload.partition(":")[2] or "ecoli"
+    rpc = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 90
+    t0 = time.time()
+    pre, codes, lens = bench.ensure_index(Path("/tmp/uncalled_amd_bench"), 0, lambda: None, ref, "cuda:0")
+    ix = capi.Index(pre)
+    a = argparse.Namespace(channels=512)
+    out = bench.realtime_workload(a, ix, pre, codes, lens, 0, ref, rounds, 0, verify_channels=512, cpu_budget_s=1e9, reads_per_ch=rpc)
+    res = {"workload": workload, "team": os.environ.get("UNC_RT_TEAM", "8 (default)"), "channels": 512, "reads_per_channel": rpc, "rounds": rounds,
+           "reads_finished_on_the_gpu": out["config"]["reads_finished"], "round_ms": out["config"]["latency_ms"],
+           "verify": out.get("verify"), "reference": (out.get("cpu_baseline") or {}).get("kind"), "wall_s": round(time.time() - t0, 1)}
+    print(json.dumps(res))
+    sys.exit(1 if (out.get("verify") or {}).get("paf_mismatches", 1) else 0)
 n_chk = int(sys.argv[2]) if len(sys.argv) > 2 else 10240
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else min(64, len(os.sched_getaffinity(0)))
 n = {"ecoli": 50000, "chr20": 200000, "grch38": 250000}[workload]

@@ -45,3 +45,21 @@ def to_oracle_params(p):
     for name, _ in q._fields_:
         setattr(q, name, getattr(p, name))
     return q
+
+
+def oracle_hits_threads(oix, raw, offsets, calib, dev_hits=None, threads=None):
+    """The oracle on all host threads (po.map_batch: every thread ONE Mapper that maps read after read) for batches of thousands
+    of reads.  A thread's Mapper carries sources_added_ from a read that filled max_paths into its next read (mapper.cpp:88,612-623),
+    whichever read that happens to be; the device maps every read as a fresh Mapper does.  So a read that disagrees with `dev_hits`
+    is mapped once more by a FRESH oracle Mapper before it counts (tests/dev/parity_sweep.py does the same against the reference)."""
+    import os
+    threads = threads or max(1, min(offsets.size - 1, len(os.sched_getaffinity(0))))
+    sig = po.calibrate(raw, float(calib["range"][0]), float(calib["offset"][0]), float(calib["digitisation"][0]))
+    want, secs = po.map_batch(oix, sig, offsets, threads)
+    redone = 0
+    if dev_hits is not None:
+        for i in range(offsets.size - 1):
+            if any(int(dev_hits[f][i]) != int(want[f][i]) for f in HIT_INT_FIELDS):
+                want[i] = po.Mapper(oix).map_read(sig[int(offsets[i]):int(offsets[i + 1])])
+                redone += 1
+    return want, secs, redone

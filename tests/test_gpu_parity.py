@@ -121,21 +121,25 @@ def ecoli(tmp_path_factory):
 
 
 def test_ecoli_scale_batch(hip_lib, oracle_lib, ecoli):
-    """192 full-length (3600-base, about 32 k-sample) reads, mapped + off-target, against the oracle: PAF,
-    winning cluster, event counts and work counters bit-exact."""
-    n = 192
-    sim = simulate_reads(ecoli["codes"], ecoli["lens"], n, seed=42)
+    """4 096 full-length (3600-base, about 32 k-sample) reads, mapped + off-target, against the oracle on all host threads: PAF,
+    winning cluster, event counts and work counters bit-exact.  (Rounds 1-5: 192 reads -- a suite that could not see a defect that
+    strikes one read in seven thousand, round-5 review; at 4 096 reads of the headline workload a 1e-3 defect shows with 98 %.)"""
+    from tests.helpers import oracle_hits_threads
+    from tools.simulate_reads_torch import simulate_reads_torch
+    n = 4096
+    sim = simulate_reads_torch(ecoli["codes"], ecoli["lens"], n, seed=42, device="cuda:0")
+    raw = sim["signal"].cpu().numpy()
+    off = sim["offsets"]
     cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     ix = capi.Index(ecoli["prefix"], lib=hip_lib)
     m = capi.Mapper(ix)
     t0 = time.time()
-    hits = m.map_batch(sim["signal"], sim["offsets"], cal)
+    hits = m.map_batch(raw, off, cal)
     t_gpu = time.time() - t0
     oix = oracle_lib.Index(ecoli["prefix"])
-    t0 = time.time()
-    want = oracle_hits(oix, sim["signal"], sim["offsets"], cal)
-    t_cpu = time.time() - t0
+    want, t_cpu, redone = oracle_hits_threads(oix, raw, off, cal, hits)
     assert_hits_equal(hits, want, "ecoli")
+    assert redone <= 4            # (reads that follow a read with sources_added_ left set on their oracle thread: a handful in 50 000)
     mapped = int(hits["mapped"].sum())
     assert mapped >= 0.7 * n
     ok = 0
@@ -144,7 +148,7 @@ def test_ecoli_scale_batch(hip_lib, oracle_lib, ecoli):
                 sim["pos"][i] - 100 <= hits["rf_st"][i] <= sim["pos"][i] + 3700:
             ok += 1
     assert ok >= 0.95 * mapped
-    print(f"ecoli batch: {n} reads, {mapped} mapped, gpu {t_gpu:.2f}s, oracle(1 thread) {t_cpu:.2f}s")
+    print(f"ecoli batch: {n} reads, {mapped} mapped, gpu {t_gpu:.2f}s, oracle (all host threads) {t_cpu:.2f}s, {redone} mapped again by a fresh oracle Mapper")
 
 
 def test_batch_order_and_slot_independence(hip_lib, oracle_lib, example, goldens):
@@ -184,19 +188,23 @@ def chr20(tmp_path_factory):
 
 
 def test_chr20_scale_batch(hip_lib, oracle_lib, chr20):
-    """Config 3's index scale (seq_len 128.9 M: 64 MB of FM blocks + 1 GB dense SA, beyond any L2): 96 reads against
-    the oracle, bit-exact."""
-    n = 96
-    sim = simulate_reads(chr20["codes"], chr20["lens"], n, seed=43)
+    """Config 3's index scale (seq_len 128.9 M: 64 MB of FM blocks + 1 GB dense SA, beyond any L2): 1 024 reads against
+    the oracle on all host threads, bit-exact (rounds 1-5: 96)."""
+    from tests.helpers import oracle_hits_threads
+    from tools.simulate_reads_torch import simulate_reads_torch
+    n = 1024
+    sim = simulate_reads_torch(chr20["codes"], chr20["lens"], n, seed=43, device="cuda:0")
+    raw = sim["signal"].cpu().numpy()
+    off = sim["offsets"]
     cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
     ix = capi.Index(chr20["prefix"], lib=hip_lib)
     assert ix.size == 2 * 64444167
     m = capi.Mapper(ix)
-    hits = m.map_batch(sim["signal"], sim["offsets"], cal)
+    hits = m.map_batch(raw, off, cal)
     oix = oracle_lib.Index(chr20["prefix"])
-    want = oracle_hits(oix, sim["signal"], sim["offsets"], cal)
+    want, _secs, redone = oracle_hits_threads(oix, raw, off, cal, hits)
     assert_hits_equal(hits, want, "chr20")
-    assert int(hits["mapped"].sum()) >= 0.5 * n
+    assert redone <= 2 and int(hits["mapped"].sum()) >= 0.5 * n
 
 
 @pytest.mark.parametrize("max_paths,slice_events,n_slots,n_waves", [(10000, 37, 5, 2), (300, 11, 3, 1), (10000, 200, 9, 4)])

@@ -217,13 +217,26 @@ template <class IX> __device__ __forceinline__ uint64_t fm_sa(const IX &ix, uint
     return (uint64_t)n + ix.sa[k >> 5];
 }
 
-// SA look-up through the dense table built at index load (k_dense_sa): entry = SA value (40 bits) | LF steps the
-// BWA-format walk above would have taken << 40 (kept so that the SURVEY 8(d) work counters stay those of
-// the reference's algorithm).  One 8-byte read instead of ~31 dependent 64-byte reads.
+// SA look-up through the dense table built at index load (k_dense_sa): SIX bytes per row -- SA value (34 bits: seq_len < 2^34 is the
+// library's limit) | LF steps the BWA-format walk above would have taken << 34 (14 bits; kept so that the SURVEY 8(d) work counters
+// stay those of the reference's algorithm.  The walk ends at a row that is a multiple of 32, which each LF step reaches with
+// probability 1/32: the count is geometric -- 13 % of the rows take more than 63 steps -- and 14 bits are beyond it by a margin of
+// e^-500; the load-time self-check refuses a table with a count that does not fit).  One 8-byte read (the two aligned words around
+// the entry) instead of ~31 dependent 64-byte reads.  Rounds 2-5 spent 8 bytes per row: 49.6 GB of GRCh38's 252 GB per GPU, now 37.2.
+constexpr uint64_t SA_ENTRY_BYTES = 6;
+constexpr int SA_STEP_SHIFT = 34;
+constexpr uint32_t SA_STEP_MAX = (1u << 14) - 1u;
+__device__ __forceinline__ uint64_t sa_pack(uint64_t sa, uint32_t steps) { return (sa & ((1ull << SA_STEP_SHIFT) - 1ull)) | ((uint64_t)(steps & SA_STEP_MAX) << SA_STEP_SHIFT); }
+template <class P> __device__ __forceinline__ uint64_t sa_entry_load(P table, uint64_t k) {
+    const uint64_t byte = k * SA_ENTRY_BYTES;
+    const auto w = (const UNC_AS_GLOBAL uint32_t *)table + (byte >> 2);      // (C-style: the table arrives as a generic or a global pointer)
+    const uint64_t two = ((uint64_t)w[1] << 32) | w[0];
+    return (two >> ((byte & 3u) << 3)) & ((1ull << 48) - 1ull);
+}
 template <class IX> __device__ __forceinline__ uint64_t fm_sa_dense(const IX &ix, uint64_t k, uint32_t *steps) {
-    const uint64_t v = ix.sa_dense[k];
-    *steps = (uint32_t)(v >> 40);
-    return v & ((1ull << 40) - 1ull);
+    const uint64_t v = sa_entry_load(ix.sa_dense, k);
+    *steps = (uint32_t)(v >> SA_STEP_SHIFT);
+    return v & ((1ull << SA_STEP_SHIFT) - 1ull);
 }
 
 }  // namespace unc

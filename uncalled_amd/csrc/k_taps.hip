@@ -73,12 +73,25 @@ __global__ void k_self_align(DevIndex ix, const uint8_t *pac, uint32_t n_samples
 
 // Dense SA: every row walks to its sampled row once, at index load (bwt_sa for all rows in parallel).  Grid-stride: a
 // launch of one thread per row would need more than 2^32 threads for GRCh38 (6.2 G rows), which HIP does not dispatch.
-__global__ void k_dense_sa(DevIndex ix, uint64_t *out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= ix.seq_len; k += stride) {
-        uint32_t steps;
-        const uint64_t sa = fm_sa(ix, k, &steps);
-        out[k] = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);   // row 0 (SA = -1) is never looked up
+// (two rows per thread: their 12 bytes are three aligned words)
+__global__ void k_dense_sa(DevIndex ix, uint64_t *out_) {
+    uint32_t *const out = reinterpret_cast<uint32_t *>(out_);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, groups = (ix.seq_len + 2) / 2;      // rows 0 .. seq_len
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        uint64_t v[2];
+        for (int j = 0; j < 2; ++j) {
+            const uint64_t k = 2 * g + (uint64_t)j;
+            v[j] = 0;
+            if (k <= ix.seq_len) {
+                uint32_t steps;
+                const uint64_t sa = fm_sa(ix, k, &steps);      // row 0 (SA = -1) is never looked up
+                v[j] = sa_pack(sa, steps);
+            }
+        }
+        uint32_t *const p = out + 3 * g;
+        p[0] = (uint32_t)v[0];
+        p[1] = (uint32_t)(v[0] >> 32) | (uint32_t)(v[1] << 16);
+        p[2] = (uint32_t)(v[1] >> 16);
     }
 }
 
@@ -91,8 +104,7 @@ __global__ void k_dense_sa_check(DevIndex ix, const uint64_t *dense, uint32_t n,
     if (k == 0) k = 1;
     uint32_t steps;
     const uint64_t sa = fm_sa(ix, k, &steps);
-    const uint64_t want = (sa & ((1ull << 40) - 1ull)) | ((uint64_t)steps << 40);
-    if (dense[k] != want) atomicAdd(bad, 1u);
+    if (sa_entry_load(dense, k) != sa_pack(sa, steps) || steps > SA_STEP_MAX) atomicAdd(bad, 1u);
 }
 
 

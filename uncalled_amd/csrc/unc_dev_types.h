@@ -128,7 +128,7 @@ struct DevSched {
 struct DevIndex {
     const uint32_t *bwt;        // 64-byte blocks: 4 x u64 counts + 8 x u32 of 2-bit BWT (bwa layout)
     const uint64_t *sa;         // sampled SA, interval 32; sa[0] = -1 (bwa layout)
-    const uint64_t *sa_dense;   // [seq_len + 1] full SA | LF-steps << 56, or null (then the sampled walk is used)
+    const uint64_t *sa_dense;   // [seq_len + 1] x 6 bytes: full SA | LF-steps << 34 (fm_dev.h: sa_entry_load), or null (then the sampled walk is used)
     const uint64_t *kmer_ranges;  // [1024][2]
     const float *model;         // [3][1024]: lv_means, lv_vars_x2, lognorm_denoms
     const float *model4;        // [1024][4]: the same, one 16-byte row per k-mer (a lane that needs ONE k-mer's row: one access)

@@ -259,13 +259,13 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     memcpy(d.thresholds, ix->thresholds, sizeof d.thresholds);
 
     d.sa_dense = nullptr;
-    // Dense SA (8 bytes per BWT row; HBM is plentiful: 74 MB for E. coli, ~50 GB for GRCh38): every row walks LF to
+    // Dense SA (6 bytes per BWT row, fm_dev.h: 56 MB for E. coli, 37 GB for GRCh38; 8 bytes in rounds 2-5): every row walks LF to
     // its sampled row once, here, instead of on every seed.  UNC_DENSE_SA=0 keeps the BWA sampling only.
     {
         const char *env = getenv("UNC_DENSE_SA");
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t need = (n + 1) * 8;
+        const size_t need = ((n + 2) / 2) * 12 + 16;      // rows 0 .. n in pairs (12 bytes) + the word a load reads past the last entry
         if (!(env && env[0] == '0') && need < free_b / 2) {
             HIPCHK(hipMalloc((void **)&ix->d_sa_dense, need));
             launch_dense_sa(d, ix->d_sa_dense, nullptr);

@@ -72,9 +72,12 @@ class IndexParameterizer:
             mat[0, i] += dead                                          # ended trajectories count as size 1
         self.fm_path_mat = mat
         pos = np.arange(max_pathlen)
-        self.fm_locs = np.array([np.sum(np.array([i * w for i, w in zip(pos, mat[f] / np.sum(mat[f]))])) for f in range(max_fmexp)])
-        exps = np.arange(max_fmexp)
-        self.loc_fms = np.array([np.sum(np.array([i * w for i, w in zip(exps, mat[:, p] / np.sum(mat[:, p]))])) for p in range(max_pathlen)])
+        # (an empty row is 0 / 0 = nan in the reference as well, index.py:103-106, where numpy says so on stderr in every run: the same
+        # value, without the RuntimeWarning)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            self.fm_locs = np.array([np.sum(np.array([i * w for i, w in zip(pos, mat[f] / np.sum(mat[f]))])) for f in range(max_fmexp)])
+            exps = np.arange(max_fmexp)
+            self.loc_fms = np.array([np.sum(np.array([i * w for i, w in zip(exps, mat[:, p] / np.sum(mat[:, p]))])) for p in range(max_pathlen)])
         self.speed_denom = np.sum(self.loc_fms)
         self.conf_locs = np.arange(np.round(self.fm_locs[0]))
         self.all_locs = np.arange(max_pathlen)
