@@ -221,6 +221,10 @@ int unc_mapper_last_window(const unc_mapper_t *m, double *start_ms, double *end_
  * [0] match probs, [1] extension (loop overhead), [2] sort, [3] walk, [4] full sources, [5] SA look-ups, [6] add_seed,
  * [7] rest, [8] E1 parent loads + candidates, [9] E2 FM look-ups, [10] E3 child slots, [11] E4 child records */
 int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out12);
+/* the same per READ of the last batch (n_reads = the batch's): 14 words of 64 bits per read -- the twelve counters above, the read's
+ * residence in device wall-clock ticks, and where it was decided (XCC_ID | HW_ID << 8).  Diagnostics: which reads, and which part of the
+ * chip, pay when a launch of the same batch runs slower than the last one (the GRCh38 levels) */
+int unc_mapper_last_read_cycles(const unc_mapper_t *m, uint32_t n_reads, uint64_t *out14);
 /* the counters above are collected only by batches mapped while profiling is on (off by default: the counting
  * instantiation of k_map is about 2 % slower) */
 void unc_mapper_set_profile(unc_mapper_t *m, int on);
@@ -318,6 +322,10 @@ int unc_rt_tap_channel(unc_rt_t *rt, uint32_t channel, unc_rt_tap_t *out, float 
  * n < 2^32.  stream: a hipStream_t or NULL. */
 int unc_sort_pairs_u64(int device, uint64_t n, uint64_t *keys, uint64_t *vals, uint64_t *tmp_keys, uint64_t *tmp_vals, int key_bits,
                        int iota, void *stream);
+/* The suffix array of a text of n < 2^31 symbols (codes 0..3 in host memory) into sa[0 .. n) (host memory): the suffix sort inside
+ * bwa_idx_build (src/bwa_index.hpp:92-101) as prefix doubling on the device -- the radix sort above and the steps between the sorts as
+ * HIP kernels (k_sort.hip), no torch.  uncalled_amd/build_index.py writes the five BWA-format index files around it. */
+int unc_build_suffix_array(int device, const uint8_t *codes, uint64_t n, int64_t *sa);
 
 /* ---- measurement aid: `reps` launches that write, then `reps` that read, n_records (made odd) scattered 64-byte records with
  * one lane per record and four 16-byte accesses per lane -- k_map's access shape with an exactly known byte count, for

@@ -44,16 +44,60 @@ def test_device_builders_equal_the_numpy_builder_byte_for_byte(tmp_path):
     names, lens, codes, holes, n_ambs = repeat_rich_masked(2_000_003, seed=11)
     annos = [""] * len(names)
     small.build_from_codes(tmp_path / "cpu", names, annos, lens, codes, holes, n_ambs, uncl_text=None)                       # numpy
-    small.build_from_codes(tmp_path / "dev", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda")     # k_sort.hip (default)
+    small.build_from_codes(tmp_path / "dev", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda")     # unc_build_suffix_array (default: no torch)
+    small.build_from_codes(tmp_path / "devh", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda", sorter="hip")     # torch between k_sort.hip's sorts
     small.build_from_codes(tmp_path / "devt", names, annos, lens, codes, holes, n_ambs, uncl_text=None, sa_device="cuda", sorter="torch")
     big.build_from_codes_big(tmp_path / "bigh", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda", chunk=1 << 18, piece=1 << 17,
                              sorter="hip")                                                                                      # the big builder on k_sort.hip
     # chunk / piece far below the defaults: dozens of chunk and piece boundaries on 4 M symbols, as 6.2 G symbols have with the defaults
     big.build_from_codes_big(tmp_path / "big", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda", chunk=1 << 18, piece=1 << 17)
     big.build_from_codes_big(tmp_path / "bigd", names, annos, lens, codes, holes, n_ambs, uncl_text=None, device="cuda")     # defaults: one chunk
-    for other in ("dev", "devt", "big", "bigh", "bigd"):
+    for other in ("dev", "devh", "devt", "big", "bigh", "bigd"):
         for suf in SUFS:
             assert filecmp.cmp(tmp_path / ("cpu" + suf), tmp_path / (other + suf), shallow=False), (other, suf)
+
+
+def test_index_build_on_the_gpu_without_torch(tmp_path):
+    """`uncalled index` on the GPU in a process that CANNOT import torch (UNCALLED_AMD_NO_TORCH=1 and a torch.py on the path that raises):
+    the suffix sort is unc_build_suffix_array -- the radix sort and the steps between the sorts as HIP kernels behind the C ABI
+    (k_sort.hip) -- and the five files equal the numpy builder's byte for byte (round-5 review: only the sort was HIP, everything
+    between the sorts torch tensor ops)."""
+    import os
+    import subprocess
+    names, lens, codes, holes, n_ambs = repeat_rich_masked(2_000_003, seed=11)
+    annos = [""] * len(names)
+    small.build_from_codes(tmp_path / "cpu", names, annos, lens, codes, holes, n_ambs, uncl_text=None)                       # numpy
+    block = tmp_path / "no_torch"
+    block.mkdir()
+    (block / "torch.py").write_text("raise ImportError('torch is blocked in this process')\n")
+    script = tmp_path / "build.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from uncalled_amd import build_index as small\n"
+        "from tests.test_gpu_index_build import repeat_rich_masked\n"
+        "names, lens, codes, holes, n_ambs = repeat_rich_masked(2_000_003, seed=11)\n"
+        "t0 = time.time()\n"
+        f"small.build_from_codes({str(tmp_path / 'nt')!r}, names, [''] * len(names), lens, codes, holes, n_ambs, uncl_text=None, sa_device='cuda')\n"
+        "assert 'torch' not in sys.modules, 'torch was imported'\n"
+        "print('built without torch in %.2f s' % (time.time() - t0))\n")
+    env = dict(os.environ, UNCALLED_AMD_NO_TORCH="1", PYTHONPATH=str(block) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "built without torch" in r.stdout, (r.stdout[-400:], r.stderr[-800:])
+    assert "the torch construction instead" not in r.stderr, r.stderr[-400:]
+    for suf in SUFS:
+        assert filecmp.cmp(tmp_path / ("cpu" + suf), tmp_path / ("nt" + suf), shallow=False), suf
+    # ... and the command itself, `uncalled index` (scripts/uncalled:38-78), in the same torch-less environment on the bundled reference:
+    # files equal to the bundled `bwa index` output, .uncl equal to the one the reference shipped
+    import shutil
+    ex = ROOT / "tests" / "golden" / "example_index"
+    fa = tmp_path / "example_ref.fa"
+    shutil.copyfile(ex / "example_ref.fa", fa)
+    r = subprocess.run([sys.executable, "-m", "uncalled_amd", "index", str(fa)], cwd=str(ROOT), capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "the torch construction instead" not in r.stderr, r.stderr[-2000:]
+    for suf in SUFS:
+        assert (tmp_path / ("example_ref.fa" + suf)).read_bytes() == (ex / ("example_ref" + suf)).read_bytes(), suf
+    assert (tmp_path / "example_ref.fa.uncl").read_text() == (ex / "example_ref.uncl").read_text()
 
 
 def test_radix_sort_against_numpy(hip_lib):

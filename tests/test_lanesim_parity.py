@@ -24,6 +24,22 @@ def test_radix_sort_of_the_index_builders(sim_lib):
     pc.case_radix_sort(sim_lib)
 
 
+def test_suffix_array_built_behind_the_c_abi(sim_lib):
+    """unc_build_suffix_array (the suffix sort of `uncalled index` without torch: k_sort.hip's radix sort and the steps between the sorts)
+    against the numpy prefix doubling, on texts with ties far deeper than the first 21-symbol key."""
+    import numpy as np
+    from uncalled_amd import capi
+    from uncalled_amd.build_index import suffix_array
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 64, 2049, 6000):
+        t = rng.integers(0, 4, size=n).astype(np.uint8)
+        if n == 6000:
+            t[1000:3000] = 0                                                        # a homopolymer run
+            t[3000:3600] = np.tile(np.array([0, 1, 2, 3], dtype=np.uint8), 150)     # a tandem repeat
+            t[4000:5000] = t[200:1200]                                              # an exact repeat
+        assert np.array_equal(capi.build_suffix_array(t, 0, sim_lib), suffix_array(t)), n
+
+
 def test_events_of_the_reads_the_sweep_found_wrong(sim_lib, oracle_lib, example):
     pc.case_events_sweep_reads(sim_lib, oracle_lib, example)
 

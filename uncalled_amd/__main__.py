@@ -55,8 +55,19 @@ def index_cmd(args):
         sys.stderr.write("Using previously built BWA index.\nNote: to fully re-build the index delete files with the "
                          "\"%s.*\" prefix.\n" % prefix)
     else:
+        # the suffix sort inside bwa_idx_build (bwa_index.hpp:92-101) runs on the GPU behind the C ABI (unc_build_suffix_array: no torch
+        # in the process) for references of fewer than 2^30 bases; larger ones go through the chunked builder (torch tensors around the
+        # same radix sort)
         from . import build_index
-        build_index.build_from_fasta(args.fasta_filename, prefix, verbose=True)
+        names, annos, seqs = build_index.read_fasta(args.fasta_filename)
+        if 2 * sum(len(s) for s in seqs) < (1 << 31):
+            codes, holes, n_ambs = build_index.encode_contigs(seqs)
+            build_index.build_from_codes(prefix, names, annos, [len(s) for s in seqs], codes, holes, n_ambs, verbose=True,
+                                         sa_device="cuda:%d" % args.device)
+        else:
+            from . import build_index_big
+            codes, holes, n_ambs = build_index.encode_contigs(seqs)
+            build_index_big.build_from_codes_big(prefix, names, annos, [len(s) for s in seqs], codes, holes, n_ambs, device="cuda:%d" % args.device)
     sys.stderr.write("Initializing parameter search\n")
     presets = [("default", dict(tgt_speed=115))]
     for tgt in (args.probs.split(",") if args.probs else []):

@@ -158,11 +158,26 @@ def device_argsort(key, key_bits, sorter):
     (the permutation starts as 0 .. n - 1 inside the kernel); "torch": torch.sort."""
     import torch
     if sorter == "hip" and key.is_cuda and key.numel() > 0:
-        from . import capi
-        order, tk, tv = torch.empty_like(key), torch.empty_like(key), torch.empty_like(key)
-        capi.sort_pairs_device(key.data_ptr(), order.data_ptr(), tk.data_ptr(), tv.data_ptr(), key.numel(), key_bits, True,
-                               key.device.index or 0, torch.cuda.current_stream(key.device).cuda_stream)
-        return key, order
+        # (round-5 advice: a library that is missing, older than the entry point, or short of device memory beside torch's cached blocks
+        # must not take `uncalled index` down: torch.sort serves, with a note)
+        try:
+            from . import capi
+            L = capi.load()
+            if not hasattr(L, "unc_sort_pairs_u64"):
+                raise RuntimeError("libuncalled_hip.so has no unc_sort_pairs_u64")
+            order, tk, tv = torch.empty_like(key), torch.empty_like(key), torch.empty_like(key)
+            args = (key.data_ptr(), order.data_ptr(), tk.data_ptr(), tv.data_ptr(), key.numel(), key_bits, True, key.device.index or 0,
+                    torch.cuda.current_stream(key.device).cuda_stream, L)
+            try:
+                capi.sort_pairs_device(*args)
+            except capi.UncalledHipError:
+                # (the sort's own scratch -- the digit counts -- is a hipMalloc outside torch's caching allocator, and it is the first thing
+                # the call does: the keys are untouched when it fails; once more with torch's cached blocks given back)
+                torch.cuda.empty_cache()
+                capi.sort_pairs_device(*args)
+            return key, order
+        except Exception as e:      # noqa: BLE001
+            print(f"[build_index] unc_sort_pairs_u64 failed ({e!r:.200}): torch.sort instead", file=sys.stderr)
     return torch.sort(key, stable=True)
 
 
@@ -208,6 +223,25 @@ def suffix_array_torch(t, device="cuda", sorter=None):
     return sa.cpu().numpy()
 
 
+def suffix_array_device(t, device="cuda", sorter=None):
+    """The suffix array on a GPU.  Default: unc_build_suffix_array (the C ABI: radix sort + the steps between the sorts as HIP kernels,
+    uncalled_amd/csrc/k_sort.hip) -- no torch in the process.  `sorter` "torch" / "hip", UNC_INDEX_SORTER, a library without the entry
+    point, or a failure of it (device memory: 37 bytes per symbol) fall back to the torch construction above, with a note on stderr."""
+    import os
+    want = sorter or os.environ.get("UNC_INDEX_SORTER")
+    if want in (None, "", "native") and str(device).startswith("cuda"):
+        try:
+            from . import capi
+            L = capi.load()
+            if hasattr(L, "unc_build_suffix_array"):
+                dev = str(device).partition(":")[2]
+                return capi.build_suffix_array(t, int(dev) if dev else 0, L)
+            print("[build_index] libuncalled_hip.so has no unc_build_suffix_array: the torch construction instead", file=sys.stderr)
+        except Exception as e:      # noqa: BLE001  (missing library, out of device memory, ...)
+            print(f"[build_index] unc_build_suffix_array failed ({e!r:.200}): the torch construction instead", file=sys.stderr)
+    return suffix_array_torch(t, device, None if want == "native" else want)
+
+
 def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, uncl_text=DEFAULT_UNCL, verbose=False, sa_device=None,
                      sorter=None):
     prefix = str(prefix)
@@ -240,7 +274,7 @@ def build_from_codes(prefix, names, annos, lens, codes, holes=(), n_ambs=None, u
     n = t.size
     if verbose:
         print(f"[build_index] suffix array of {n} symbols ...", file=sys.stderr)
-    sa = suffix_array_torch(t, sa_device, sorter) if sa_device else suffix_array(t)
+    sa = suffix_array_device(t, sa_device, sorter) if sa_device else suffix_array(t)
     # full matrix rows: row 0 is the sentinel suffix (SA = n)
     sa_full = np.concatenate((np.array([n], dtype=np.int64), sa))
     del sa

@@ -80,6 +80,15 @@ def sort_pairs(keys, vals=None, key_bits=64, lib=None, device=0):
         L.unc_host_free(buf)
 
 
+def build_suffix_array(codes_u8, device=0, lib=None):
+    """unc_build_suffix_array: the suffix array (int64) of a text of n < 2^31 symbols (codes 0..3), built on the device without torch."""
+    L = lib or load()
+    t = np.ascontiguousarray(codes_u8, dtype=np.uint8)
+    sa = np.empty(t.size, dtype=np.int64)
+    _check(L, L.unc_build_suffix_array(int(device), t.ctypes.data, int(t.size), sa.ctypes.data))
+    return sa
+
+
 def hits_digest(hits):
     """sha256 over the result fields of a hit array (map_ms, a wall-clock measurement, zeroed)."""
     import hashlib
@@ -146,6 +155,8 @@ def load(path=None):
     L.unc_mapper_free.argtypes = [vp]
     L.unc_mapper_device_bytes.argtypes = [vp]; L.unc_mapper_device_bytes.restype = u64
     L.unc_map_batch.argtypes = [vp, u32, vp, vp, vp, C.c_int, vp, vp]
+    if hasattr(L, "unc_build_suffix_array"):
+        L.unc_build_suffix_array.argtypes = [C.c_int, vp, u64, vp]
     if hasattr(L, "unc_mapper_last_window"):
         L.unc_mapper_last_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(L, "unc_map_batch_begin"):
@@ -153,6 +164,7 @@ def load(path=None):
         L.unc_map_batch_end.argtypes = [vp, vp]
     L.unc_mapper_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.unc_mapper_last_phase_cycles.argtypes = [vp, vp]
+    L.unc_mapper_last_read_cycles.argtypes = [vp, u32, vp]
     L.unc_mapper_last_remap.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.unc_mapper_last_remap.restype = None
     if hasattr(L, "unc_mapper_set_read_order"):      # (dev tools load older builds of the library for A/B runs)
@@ -418,6 +430,12 @@ class Mapper:
         out = np.zeros(12, dtype=np.uint64)
         self.L.unc_mapper_last_phase_cycles(self.h, out.ctypes.data)
         return dict(zip(("probs", "extend_rest", "sort", "walk", "sources", "sa", "add_seed", "rest", "e1_parents", "e2_fm", "e3_slots", "e4_children"), out.tolist()))
+
+    def last_read_cycles(self, n_reads):
+        """Per read of the last batch: [n_reads, 14] -- twelve phase counters, residence ticks, XCC_ID | HW_ID << 8 (profiling on)."""
+        out = np.zeros((int(n_reads), 14), dtype=np.uint64)
+        _check(self.L, self.L.unc_mapper_last_read_cycles(self.h, int(n_reads), out.ctypes.data))
+        return out
 
     def detect_events(self, raw_i16, offsets_u64, calib):
         raw = np.ascontiguousarray(raw_i16, dtype=np.int16)

@@ -1493,7 +1493,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             res.done = done; res.status = T.status; res.event_i = event_i; res.notes = notes;
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
-            res.ticks = resume ? 0ull : (uint64_t)wall_clock64() - t_start; res.pad2 = 0;
+            res.ticks = resume ? 0ull : (uint64_t)wall_clock64() - t_start;
+            // PROF: where the read was decided -- XCC_ID (bits 0-3) | HW_ID's low 16 bits (wave, SIMD, CU, shader array, shader engine) << 8
+            res.pad2 = PROF ? (uint32_t)__builtin_amdgcn_s_getreg(6164) | ((uint32_t)__builtin_amdgcn_s_getreg(4 | (15 << 11)) << 8) : 0u;
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
             g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
         }

@@ -114,4 +114,63 @@ void launch_rsort_pass(const uint64_t *kin, const uint64_t *vin, uint64_t *kout,
 }
 uint32_t rsort_tile() { return RS_TILE; }
 
+// ---- the suffix array of a text of n < 2^31 symbols by prefix doubling, everything between the radix sorts (unc_build_suffix_array:
+// the whole of what bwa_idx_build's suffix sort does for the index builder, bwa_index.hpp:92-101, without torch).  Rounds 3-5 ran these
+// steps as torch tensor ops around the hand-written sort.  All of them are one pass over n elements, HBM-bound:
+//   k_sa_first_key   the first 21 symbols of every suffix as a 63-bit key (symbol + 1 in 3 bits, 0 past the end)
+//   k_sa_flags       1 where a sorted key differs from its predecessor (a new group of equal prefixes)
+//   (exclusive scan of the flags: k_scan_sums / _top / _apply above)
+//   k_sa_ranks       rank[suffix] = groups before it in sorted order; the number of groups
+//   k_sa_next_key    key = rank[i] * (n + 1) + (rank[i + k] + 1, 0 past the end): suffixes by their first 2k symbols
+//   k_sa_invert      sa[rank[i]] = i once every suffix has a rank of its own
+__global__ void k_sa_first_key(const uint8_t *text, uint64_t n, uint64_t *key) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = 0;
+    for (uint32_t j = 0; j < 21; ++j) k = (k << 3) | (i + j < n ? (uint64_t)text[i + j] + 1u : 0u);
+    key[i] = k;
+}
+__global__ void k_sa_flags(const uint64_t *sk, uint64_t n, uint32_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || sk[i] != sk[i - 1]) ? 1u : 0u;
+}
+__global__ void k_sa_ranks(const uint64_t *sk, const uint64_t *order, const uint32_t *before, uint64_t n, uint32_t *rank, uint32_t *n_groups) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t head = (i == 0 || sk[i] != sk[i - 1]) ? 1u : 0u;
+    const uint32_t r = before[i] + head - 1u;          // groups up to and including mine, minus one
+    rank[order[i]] = r;
+    if (i == n - 1) *n_groups = r + 1u;
+}
+__global__ void k_sa_next_key(const uint32_t *rank, uint64_t n, uint64_t k, uint64_t *key) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t nxt = i + k < n ? (uint64_t)rank[i + k] + 1u : 0u;
+    key[i] = (uint64_t)rank[i] * (n + 1u) + nxt;        // < 2^62 for n < 2^31
+}
+__global__ void k_sa_invert(const uint32_t *rank, uint64_t n, int64_t *sa) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sa[rank[i]] = (int64_t)i;
+}
+void launch_sa_first_key(const uint8_t *text, uint64_t n, uint64_t *key, hipStream_t st) {
+    hipLaunchKernelGGL(k_sa_first_key, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, text, n, key);
+}
+// sorted keys + their order -> rank per suffix and the number of groups; flags: n words of scratch, sums: ceil(n / 2048) words
+void launch_sa_ranks(const uint64_t *sk, const uint64_t *order, uint64_t n, uint32_t *flags, uint32_t *sums, uint32_t *rank, uint32_t *n_groups,
+                     hipStream_t st) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const uint32_t nsums = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    hipLaunchKernelGGL(k_sa_flags, dim3(blocks), dim3(256), 0, st, sk, n, flags);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nsums), dim3(WAVE), 0, st, (const uint32_t *)flags, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WAVE), 0, st, sums, nsums);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nsums), dim3(WAVE), 0, st, flags, n, (const uint32_t *)sums);
+    hipLaunchKernelGGL(k_sa_ranks, dim3(blocks), dim3(256), 0, st, sk, order, (const uint32_t *)flags, n, rank, n_groups);
+}
+void launch_sa_next_key(const uint32_t *rank, uint64_t n, uint64_t k, uint64_t *key, hipStream_t st) {
+    hipLaunchKernelGGL(k_sa_next_key, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rank, n, k, key);
+}
+void launch_sa_invert(const uint32_t *rank, uint64_t n, int64_t *sa, hipStream_t st) {
+    hipLaunchKernelGGL(k_sa_invert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rank, n, sa);
+}
+
 }  // namespace unc

@@ -678,7 +678,11 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
             const size_t chunk_bytes = POOL_CHUNK_BYTES;
-            const size_t want = (size_t)n_slots * (ix->seq_len >= (1ull << 26) ? 64 : 8);
+            // (per read in flight: 8 chunks on a bacterial reference, 24 from 2^26 index rows on -- chr20: eleven out at the peak --, 64 from
+            // 2^31 on -- GRCh38: 23 out at the peak, and the peak moves by a tenth from launch to launch.  Rounds 2-5 gave every reference
+            // past 2^26 rows 64: 155 GB for chr20, which left no room for a second mapper beside the first)
+            const size_t per_slot = ix->seq_len >= (1ull << 31) ? 64 : ix->seq_len >= (1ull << 26) ? 24 : 8;
+            const size_t want = (size_t)n_slots * per_slot;
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
             m->pool_auto = true;
             m->pool_floor = std::max<uint32_t>(16, std::min<uint32_t>(n_slots, n_chunks));
@@ -1176,6 +1180,20 @@ extern "C" int unc_mapper_last_phase_cycles(const unc_mapper_t *m, uint64_t *out
     return UNC_OK;
 }
 
+// per read of the last batch (profiling instantiation): the twelve phase counters, the residence in wall-clock ticks, and where the read was
+// decided (XCC_ID | HW_ID << 8) -- 14 words of 64 bits per read
+extern "C" int unc_mapper_last_read_cycles(const unc_mapper_t *m, uint32_t n_reads, uint64_t *out14) {
+    if (!m || !out14) return fail(UNC_ERR_ARG, "null argument");
+    if (n_reads > m->h_results.size()) return fail(UNC_ERR_ARG, "unc_mapper_last_read_cycles: the last batch had %zu reads", m->h_results.size());
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const DevResult &d = m->h_results[r];
+        for (int i = 0; i < 12; ++i) out14[(size_t)r * 14 + i] = d.cyc[i];
+        out14[(size_t)r * 14 + 12] = d.ticks;
+        out14[(size_t)r * 14 + 13] = d.pad2;
+    }
+    return UNC_OK;
+}
+
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" int unc_mapper_set_read_order(unc_mapper_t *m, int order) {
     if (!m || (order != UNC_ORDER_INDEPENDENT && order != UNC_ORDER_T1)) return fail(UNC_ERR_ARG, "unc_mapper_set_read_order: UNC_ORDER_INDEPENDENT or UNC_ORDER_T1");
@@ -1275,6 +1293,69 @@ extern "C" int unc_sort_pairs_u64(int device, uint64_t n, uint64_t *keys, uint64
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(counts); (void)hipFree(sums);
     if (e != hipSuccess) return fail(UNC_ERR_HIP, "radix sort: %s", hipGetErrorString(e));
+    return UNC_OK;
+}
+
+// The suffix array of a text of n < 2^31 symbols (codes 0..3, host memory) -> sa[0 .. n) (host memory, int64): prefix doubling on the
+// device -- 21 symbols first, then 42, 84, ... -- with the radix sort above and the steps between the sorts as kernels of their own
+// (k_sort.hip).  What bwa_idx_build's suffix sort does for `uncalled index` (bwa_index.hpp:92-101); uncalled_amd/build_index.py builds
+// the five index files around it.  Device memory: 37 bytes per symbol.
+extern "C" int unc_build_suffix_array(int device, const uint8_t *codes, uint64_t n, int64_t *sa) {
+    if (!codes || !sa) return fail(UNC_ERR_ARG, "null argument");
+    if (n == 0) return UNC_OK;
+    if (n >= (1ull << 31)) return fail(UNC_ERR_ARG, "unc_build_suffix_array: texts of fewer than 2^31 symbols (the chunked builder of "
+                                                    "uncalled_amd/build_index_big.py takes the larger ones)");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    struct Bufs {
+        uint8_t *text = nullptr; uint64_t *k[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr};
+        uint32_t *rank = nullptr, *flags = nullptr, *sums = nullptr, *counts = nullptr, *ngroups = nullptr;
+        ~Bufs() { void *p[] = {text, k[0], k[1], v[0], v[1], rank, flags, sums, counts, ngroups}; for (void *x : p) if (x) (void)hipFree(x); }
+    } B;
+    const uint64_t ntiles = (n + rsort_tile() - 1) / rsort_tile(), m = 256 * ntiles;
+    const uint64_t nsums = (std::max<uint64_t>(m, n) + rsort_tile() - 1) / rsort_tile();
+    HIPCHK(hipMalloc((void **)&B.text, n));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc((void **)&B.k[i], n * 8)); HIPCHK(hipMalloc((void **)&B.v[i], n * 8)); }
+    HIPCHK(hipMalloc((void **)&B.rank, n * 4));
+    HIPCHK(hipMalloc((void **)&B.flags, n * 4));
+    HIPCHK(hipMalloc((void **)&B.sums, nsums * 4));
+    HIPCHK(hipMalloc((void **)&B.counts, m * 4));
+    HIPCHK(hipMalloc((void **)&B.ngroups, 4));
+    HIPCHK(hipMemcpyAsync(B.text, codes, n, hipMemcpyHostToDevice, st));
+    // keys in B.k[0], sorted with the suffix numbers as values (iota); returns which pair of buffers holds the result
+    auto sort_keys = [&](int key_bits) -> int {
+        int cur = 0;
+        const int passes = (key_bits + 7) / 8;
+        for (int p = 0; p < passes; ++p) {
+            launch_rsort_pass(B.k[cur], B.v[cur], B.k[cur ^ 1], B.v[cur ^ 1], n, (uint32_t)(8 * p), p == 0 ? 1u : 0u, B.counts, B.sums, st);
+            cur ^= 1;
+        }
+        return cur;
+    };
+    auto rerank = [&](int key_bits, uint32_t *groups) -> int {
+        const int cur = sort_keys(key_bits);
+        launch_sa_ranks(B.k[cur], B.v[cur], n, B.flags, B.sums, B.rank, B.ngroups, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(groups, B.ngroups, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return UNC_OK;
+    };
+    uint32_t groups = 0;
+    launch_sa_first_key(B.text, n, B.k[0], st);
+    int rc = rerank(63, &groups);
+    if (rc) return rc;
+    int bits = 1;
+    while ((((unsigned __int128)(n + 1) * (n + 1)) >> bits) != 0) ++bits;      // bits of the largest doubled key
+    for (uint64_t k = 21; groups < n; k *= 2) {
+        launch_sa_next_key(B.rank, n, k, B.k[0], st);
+        rc = rerank(bits, &groups);
+        if (rc) return rc;
+        if (k > n) return fail(UNC_ERR_HIP, "unc_build_suffix_array: %u groups of %llu suffixes after comparing whole suffixes", groups, (unsigned long long)n);
+    }
+    launch_sa_invert(B.rank, n, reinterpret_cast<int64_t *>(B.k[0]), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sa, B.k[0], n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return UNC_OK;
 }
 

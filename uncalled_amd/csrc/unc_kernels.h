@@ -31,5 +31,11 @@ void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStre
 void launch_rsort_pass(const uint64_t *kin, const uint64_t *vin, uint64_t *kout, uint64_t *vout, uint64_t n, uint32_t shift, uint32_t iota,
                        uint32_t *counts, uint32_t *sums, hipStream_t st);      // k_sort.hip: one digit of the LSD radix sort
 uint32_t rsort_tile();
+// k_sort.hip: the steps of the prefix-doubling suffix sort between the radix sorts (unc_build_suffix_array)
+void launch_sa_first_key(const uint8_t *text, uint64_t n, uint64_t *key, hipStream_t st);
+void launch_sa_ranks(const uint64_t *sk, const uint64_t *order, uint64_t n, uint32_t *flags, uint32_t *sums, uint32_t *rank, uint32_t *n_groups,
+                     hipStream_t st);
+void launch_sa_next_key(const uint32_t *rank, uint64_t n, uint64_t k, uint64_t *key, hipStream_t st);
+void launch_sa_invert(const uint32_t *rank, uint64_t n, int64_t *sa, hipStream_t st);
 void launch_match_probs(const DevIndex &ix, uint32_t n, const float *levels, float *out, hipStream_t st);
 }  // namespace unc
