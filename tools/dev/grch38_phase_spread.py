@@ -22,7 +22,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 250000
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 workload = os.environ.get("SPREAD_WORKLOAD", "grch38")
 pre, codes, lens = bench.ensure_index(Path("/tmp/uncalled_amd_bench"), 0, lambda: None, workload, "cuda:0")
-ix = capi.Index(pre)
+# SPREAD_LIB: a variant library (tools/dev/build_variants.py); with dbgseed="-DUNC_DBG_SEED=1" counters 8..11 are add_seeds' own
+# (rounds, nodes walked, cycles inside the pool's ring, longest walk of one seed) and phase E's parts sit in counter 1
+LIB = capi.load(os.environ["SPREAD_LIB"]) if os.environ.get("SPREAD_LIB") else capi.load()
+DBG = "dbgseed" in os.environ.get("SPREAD_LIB", "")
+ix = capi.Index(pre, lib=LIB)
 torch.cuda.empty_cache()
 sim = simulate_reads_torch(codes, lens, n, seed=42, device="cuda:0")
 del codes
@@ -62,8 +66,29 @@ for var in variants:
         print(f"[{var}] launch {i}: k_map {ms:8.1f} ms  wave_busy {m.last_wave_busy():.3f}  pool {u['chunks']} chunks, high-water {u['high_water_last_batch']}, resizes {u['resizes']}  "
               f"remap {m.last_remap()[0]}  hits {'same' if d == first else 'DIFFER'}  "
               + " ".join(f"{k}={v / 1e9:.1f}" for k, v in pc.items()), flush=True)
+        rot = ((per[:, 13] & 0xF).astype(np.int64) - ((per[:, 13] >> 24) & 0xFF).astype(np.int64)) % 8
+        cu = ((per[:, 13] >> 16) & 0xF).astype(np.int64)      # HW_ID bits 11:8
+        print(f"[{var}]    (XCC_ID - workgroup) mod 8 over the reads: " + " ".join(str(int(c)) for c in np.bincount(rot, minlength=8)[:8]), flush=True)
         print(f"[{var}]    add_seed cycles per read decided on XCC 0..7 (10^3): " + " ".join(f"{a / max(1, b) / 1e3:.0f}" for a, b in zip(seed_by_xcc, reads_by_xcc))
               + "   reads decided there: " + " ".join(str(int(b)) for b in reads_by_xcc), flush=True)
+        # the XCDs that decide few reads: which reads are those?
+        few = [x for x in range(8) if reads_by_xcc[x] * 4 < reads_by_xcc.max()]
+        tot = per[:, :12].astype(np.float64).sum(axis=1)
+        for x in few:
+            idx = np.flatnonzero(xcc == x)
+            print(f"[{var}]    XCC {x}: {idx.size} reads decided; read numbers min {idx.min()} p25 {int(np.percentile(idx, 25))} median {int(np.median(idx))} p75 {int(np.percentile(idx, 75))} max {idx.max()}; "
+                  f"events per read median {int(np.median(hits['n_events'][idx]))}, event_i median {int(np.median(hits['event_i'][idx]))}; mapped {float(hits['mapped'][idx].mean()):.2f}; "
+                  f"add_seed / all cycles of these reads {per[idx, 6].sum() / max(1.0, tot[idx].sum()):.3f}; residence ticks median {np.median(per[idx, 12]):.3g} (launch: {ms * 1e-3 * 1e8:.3g} at 100 MHz)", flush=True)
+        if DBG:
+            for name, sel in (("reads decided on the XCDs that decide few", np.isin(xcc, few)), ("all other reads", ~np.isin(xcc, few))):
+                q = per[sel]
+                if q.shape[0]:
+                    print(f"[{var}]    {name}: {q.shape[0]} reads; per read: add_seed cycles {q[:, 6].mean():.3g}, rounds {q[:, 8].mean():.3g}, nodes walked {q[:, 9].mean():.3g}, "
+                          f"cycles inside the pool's ring {q[:, 10].mean():.3g}, longest walk of one seed: median {np.median(q[:, 11]):.0f} max {q[:, 11].max()}; "
+                          f"cycles per node walked {q[:, 6].sum() / max(1, q[:, 9].sum()):.0f}", flush=True)
+        top = np.argsort(per[:, 6])[::-1][:12]
+        print(f"[{var}]    top reads by add_seed cycles: " + "; ".join(f"#{int(i)} xcc {int(xcc[i])} cu {int(cu[i])} seed {per[i, 6] / 1e9:.1f}G all {tot[i] / 1e9:.1f}G ev {int(hits['event_i'][i])} nsa {int(hits['n_sa'][i])} m {int(hits['mapped'][i])}" + (f" rounds {int(per[i, 8])} nodes {int(per[i, 9])} ring {per[i, 10] / 1e9:.2f}G longest {int(per[i, 11])}" if DBG else "") for i in top), flush=True)
+        print(f"[{var}]    all cycles of the reads decided per XCC (10^12): " + " ".join(f"{np.bincount(xcc, weights=tot, minlength=8)[x] / 1e12:.1f}" for x in range(8)), flush=True)
     if len(rows) > 1:
         slow, fast = max(rows, key=lambda r: r[0]), min(rows, key=lambda r: r[0])
         print(f"[{var}] slowest {slow[0]:.0f} ms / fastest {fast[0]:.0f} ms = {slow[0] / fast[0]:.3f}; per phase, cycles of the slowest / the fastest launch:")

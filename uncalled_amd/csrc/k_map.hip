@@ -135,7 +135,7 @@ template <bool PROF> struct PhaseClock {
     __device__ __forceinline__ void reset() { if constexpr (PROF) tk = (uint64_t)clock64(); }
     __device__ __forceinline__ void end(int i, int lane) {
         if constexpr (PROF) {
-            if (UNC_PROF_SORT && i >= 8) i = 1;
+            if ((UNC_PROF_SORT || UNC_DBG_SEED) && i >= 8) i = 1;
             const uint64_t tn = (uint64_t)clock64();
             if (lane == 0) s_cyc[i] += tn - tk;
             tk = tn;
@@ -1258,6 +1258,10 @@ static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane
         T.mm.evt_st = uniform32(v.mm.evt_st); T.mm.evt_en = uniform32(v.mm.evt_en); T.mm.total_len = uniform32(v.mm.total_len);
     }
     const TrackerMem TM = tracker_mem(A, sb);
+#if UNC_DBG_SEED
+    if (lane < 4) s_dbgseed[lane] = 0ull;
+    wave_sync();
+#endif
     for (uint32_t sb0 = 0; sb0 < n_seedp && !T.status; sb0 += WAVE) {
         const uint32_t si = sb0 + (uint32_t)lane;
         SeedPath sp; sp.start = 0; sp.count = 0; sp.evt = 0; sp.ref_len = 0;
@@ -1294,6 +1298,13 @@ static __device__ __noinline__ uint64_t phase_T(kargs_t A_, gptr_t sb_, int lane
         }
         clk.end(6, lane);
     }
+#if UNC_DBG_SEED
+    wave_sync();
+    if (PROF && lane == 0) {
+        s_cyc[8] += s_dbgseed[0]; s_cyc[9] += s_dbgseed[1]; s_cyc[10] += s_dbgseed[2];
+        if (s_dbgseed[3] > s_cyc[11]) s_cyc[11] = s_dbgseed[3];
+    }
+#endif
     // ---------------- G: SeedTracker::get_final + check_map_conf, :129-143,259-262 ----------------
     bool conf = false;
     if (T.mm.total_len >= p_min_map_len && T.n_lens >= 2) {
@@ -1341,10 +1352,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
                 SchedCell *const free_cells = A->sched.free_cells, *const park_cells = A->sched.park_cells;
                 const uint32_t cap_mask = A->sched.cap_mask, n_reads = A->rd.n_reads;
                 for (int tries = 0; tries < 4096 && !kind; ++tries) {
-                    const bool more = ld_acq(&sc->next_read) < n_reads;
+                    const bool more = ld_rlx(&sc->next_read) < n_reads;
                     // admission control: while the pool of cluster nodes is below an eighth, reads in flight go first (they
                     // give their chunks back when they end); a new read is only started when none of them is waiting
-                    const bool low = (int32_t)(ld_acq(&A->pool.q->tail) - ld_acq(&A->pool.q->head)) < (int32_t)(A->pool.n_chunks >> 3);
+                    const bool low = (int32_t)ld_rlx(reinterpret_cast<const uint32_t *>(&A->pool.q->avail)) < (int32_t)(A->pool.n_chunks >> 3);
                     if (more && (!low || tries >= 8)) {
                         const uint32_t fs = sched_pop(&sc->freeq, free_cells, cap_mask);
                         if (fs != SCHED_EMPTY) {
@@ -1494,8 +1505,9 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             res.cluster = T.mm;
             res.n_nbr = t_nbr; res.n_sa = t_sa; res.n_lf = t_lf;
             res.ticks = resume ? 0ull : (uint64_t)wall_clock64() - t_start;
-            // PROF: where the read was decided -- XCC_ID (bits 0-3) | HW_ID's low 16 bits (wave, SIMD, CU, shader array, shader engine) << 8
-            res.pad2 = PROF ? (uint32_t)__builtin_amdgcn_s_getreg(6164) | ((uint32_t)__builtin_amdgcn_s_getreg(4 | (15 << 11)) << 8) : 0u;
+            // PROF: where the read was decided -- XCC_ID (bits 0-3) | HW_ID's low 16 bits (wave, SIMD, CU, shader array, shader engine) << 8 | the
+            // workgroup's number (low 8 bits) << 24: (XCC_ID - workgroup) mod 8 = where the dispatcher started this launch's round over the XCDs
+            res.pad2 = PROF ? (uint32_t)__builtin_amdgcn_s_getreg(6164) | ((uint32_t)__builtin_amdgcn_s_getreg(4 | (15 << 11)) << 8) | ((blockIdx.x & 0xFFu) << 24) : 0u;
             for (int i = 0; i < 12; ++i) res.cyc[i] = PROF ? s_cyc[i] : 0ull;
             g_store((UNC_AS_GLOBAL DevResult *)A->results + r, res);
         }
@@ -2404,8 +2416,9 @@ __global__ void k_pool_init(DevPool B) {
         B.cells[i] = f;
     }
     if (i == 0) {
-        SchedQueue q;
+        PoolQueue q;
         memset(&q, 0, sizeof q);
+        q.avail = (int32_t)B.n_chunks;
         q.tail = B.n_chunks;
         q.low_water = B.n_chunks;
         *B.q = q;

@@ -3,6 +3,16 @@
 
 namespace unc {
 
+// UNC_DBG_SEED (dev build, tools/dev/build_variants.py dbgseed="-DUNC_DBG_SEED=1"): what add_seeds did, through the profiling pass's
+// counters 8..11 (phase E's parts go to counter 1): 8 rounds, 9 nodes walked (all lanes), 10 cycles inside the pool's ring, 11 the
+// longest walk of one seed (a maximum, not a sum).  tools/dev/grch38_phase_spread.py reads them per read.
+#ifndef UNC_DBG_SEED
+#define UNC_DBG_SEED 0
+#endif
+#if UNC_DBG_SEED
+__shared__ unsigned long long s_dbgseed[4];
+#endif
+
 struct Tracker {
     uint32_t n, n_lens, max1, max2, status, n_alloc;      // n_alloc: nodes taken from the read's own chunks so far
     float len_sum;
@@ -28,7 +38,7 @@ static_assert(NODE_COLD_OFF + NODE_K * 32 <= NODE_BYTES, "node layout");
 static_assert(sizeof(ClusterKey) == 16 && sizeof(ClusterCold) == 32, "seed-cluster record layout");
 struct PoolView {          // DevPool with its arrays typed as global memory
     gptr_t nodes;
-    SchedQueue *q;
+    PoolQueue *q;
     SchedCell *cells;
     uint32_t cap_mask;
 };
@@ -41,20 +51,16 @@ struct TrackerMem {
     PoolView pool;         // nodes
 };
 
-// a chunk off the pool's ring (lane 0 only), keeping the ring's low-water mark of free chunks (a pop per 768 nodes: rare)
-__device__ __forceinline__ uint32_t pool_pop(const PoolView &P) {
-    const uint32_t ch = sched_pop(P.q, P.cells, P.cap_mask);
-    if (ch != SCHED_EMPTY) {
-        const int32_t free_now = (int32_t)(ld_acq(&P.q->tail) - ld_acq(&P.q->head));
-        atomicMin(&P.q->low_water, free_now > 0 ? (uint32_t)free_now : 0u);
-    } else atomicMin(&P.q->low_water, 0u);
-    return ch;
-}
-// the read is over: its chunks go back to the pool
+// a chunk off the pool's ring (lane 0 only; a pop per 768 nodes).  Nothing of what the chunk held is read: no acquire
+__device__ __forceinline__ uint32_t pool_pop(const PoolView &P) { return pool_ring_pop(P.q, P.cells, P.cap_mask); }
+// the read is over: its chunks go back to the pool.  The release fence: the next owner of a chunk may sit on another XCD, and lines
+// of the chunk that are still dirty in THIS XCD's L2 must be in memory before that owner's stores are (a later write-back of them
+// would land on top of the new owner's nodes)
 __device__ __forceinline__ void tracker_release(Tracker &T, const TrackerMem &M, int lane) {
     const uint32_t n_chunks = (T.n_alloc + CHUNK_NODES - 1) / CHUNK_NODES;
+    if (n_chunks) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     for (uint32_t i = (uint32_t)lane; i < n_chunks; i += WAVE)
-        sched_push(M.pool.q, M.pool.cells, M.pool.cap_mask, gld<uint32_t>(M.sb, M.off_chunks + (i << 2)));
+        pool_ring_push(M.pool.q, M.pool.cells, M.pool.cap_mask, gld<uint32_t>(M.sb, M.off_chunks + (i << 2)));
     T.n_alloc = 0; T.n = 0;
     wave_sync();
 }
@@ -100,6 +106,7 @@ struct SeedScan {
     uint32_t lb_have, lb_re;                                                // key at lower_bound(seed): the first in set order not before the seed
     uint32_t ins_node, ins_cnt, ins_next;                                   // a node of the seed's own bucket with room (id + 1)
     uint32_t head0;                                                         // head of the seed's own bucket
+    uint32_t walked;                                                        // nodes visited (read by the UNC_DBG_SEED build only)
 };
 
 // the window of one seed, walked by ONE lane: buckets from the seed's own downwards, every node of their chains (header + NODE_K
@@ -110,6 +117,7 @@ __device__ __forceinline__ void seed_scan(const TrackerMem &M, uint64_t r2, uint
     S.f0_found = S.f0_tl = S.f0_node = S.f0_sc = S.f0_next = 0;
     S.f_other = S.exists = S.lb_have = S.lb_re = 0;
     S.ins_node = S.ins_cnt = S.ins_next = 0;
+    S.walked = 0;
     uint32_t node1 = gld<uint32_t>(M.sb, M.off_heads + (b_hi << 2));      // node id + 1
     S.head0 = node1;
     for (uint32_t b = b_hi;;) {
@@ -147,6 +155,7 @@ __device__ __forceinline__ void seed_scan(const TrackerMem &M, uint64_t r2, uint
             }
             if (b == b_hi && !S.ins_node && h.count < NODE_K) { S.ins_node = node1; S.ins_cnt = h.count; S.ins_next = h.next; }
             node1 = h.next;          // on along the chain
+            ++S.walked;
         }
         if (b == b_lo) break;
         --b;
@@ -196,6 +205,9 @@ static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_m
 
     uint64_t pend = __ballot(have);
     while (pend) {
+#if UNC_DBG_SEED
+        if (lane == 0) s_dbgseed[0] += 1ull;
+#endif
         // ---- this round's seeds: pending, and no earlier pending seed's buckets overlap theirs
         bool blocked = false;
         for (uint64_t m = pend; m & (m - 1ull); m &= m - 1ull) {              // (the last pending seed blocks nobody)
@@ -214,6 +226,10 @@ static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_m
         if (ready) {
             SeedScan S;
             seed_scan(M, r2, e2, b_hi, b_lo, S);
+#if UNC_DBG_SEED
+            atomicAdd(&s_dbgseed[1], (unsigned long long)S.walked);
+            atomicMax(&s_dbgseed[3], (unsigned long long)S.walked);
+#endif
             head0 = S.head0;
             // the scan reaches the clusters e2 rows back after all nearer ones, in order of descending evt_en: any of them with
             // evt_en > 0 is out of range and ends it; the one with evt_en 0 is in range (r2 - r1 = e2 - e1) and is taken when it is longer
@@ -281,6 +297,9 @@ static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_m
             if (a0 + k > M.max_nodes) { T.status |= UNC_READ_CLUSTER_OVERFLOW; return; }
             const uint32_t c0 = a0 / CHUNK_NODES, c1 = (a0 + k - 1u) / CHUNK_NODES;
             uint32_t ch0 = SCHED_EMPTY, ch1 = SCHED_EMPTY;
+#if UNC_DBG_SEED
+            const uint64_t dbg_t0 = (uint64_t)clock64();
+#endif
             if (lane == 0) {
                 if (a0 % CHUNK_NODES == 0u) {
                     ch0 = pool_pop(M.pool);
@@ -293,6 +312,9 @@ static __device__ void add_seeds(Tracker &T, const TrackerMem &M, uint32_t min_m
                 }
             }
             ch0 = lane_get32(ch0, 0u); ch1 = lane_get32(ch1, 0u);
+#if UNC_DBG_SEED
+            if (lane == 0) s_dbgseed[2] += (uint64_t)clock64() - dbg_t0;
+#endif
             if (ch0 == SCHED_EMPTY || ch1 == SCHED_EMPTY) {
                 // (a chunk that WAS popped is the read's: n_alloc covers it, so that tracker_release hands it back)
                 if (ch0 != SCHED_EMPTY) T.n_alloc = c1 * CHUNK_NODES;

@@ -101,19 +101,33 @@ struct alignas(16) SlotState {
 // most `slice` events, parks it in its slot and takes the next task: a new read while free slots remain, else the
 // longest-parked one.  Long (off-target) reads are thereby discovered early and share the wavefronts until the end,
 // instead of a few of them keeping single wavefronts busy long after the queue has drained.
-// Both queues are bounded multi-producer/multi-consumer rings of slot ids with a sequence number per cell.
-struct SchedCell { uint32_t seq, val; };
-// low_water (node pool only): the fewest free ids the ring has held since it was initialised -- the pool's high-water mark of chunks
-// out at once is n_chunks - low_water (unc_mapper_pool_usage: the pool is sized by it, not by a share of the free HBM)
-struct alignas(64) SchedQueue { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t low_water; uint32_t pad1[14]; };
-struct alignas(64) SchedCtl {
-    uint32_t next_read, pad0[15];
+// Both queues are bounded multi-producer/multi-consumer rings of slot ids with a sequence number per cell.  A cell is read and written as
+// ONE 64-bit word (sequence number low, value high): value and sequence number can never be seen apart, so the rings need no
+// acquire / release pair per operation -- on this chip an agent-scope acquire is an invalidate of the XCD's whole L2 and a release a
+// write-back of it (`buffer_inv sc1` / `buffer_wbl2 sc1`), and round 6 found a polling loop of acquire loads to be what held whole XCDs
+// up on GRCh38.  The counters sit on lines of their own (128 bytes: the L2's line).
+struct alignas(8) SchedCell { uint32_t seq, val; };
+struct alignas(128) SchedQueue { uint32_t head; uint32_t pad0[31]; uint32_t tail; uint32_t pad1[31]; };
+struct alignas(128) SchedCtl {
+    uint32_t next_read, pad0[31];
     SchedQueue freeq, parkq;
 };
-// The node pool of the seed-cluster grids (see ClusterKey): chunk ids travel through a ring like the scheduler's.
+// The node pool of the seed-cluster grids (see ClusterKey): chunk ids travel through a ring as well, but one that is never polled by a
+// compare-and-swap loop: `avail` counts the chunks that are in the ring (published) and not yet spoken for -- a pop first takes one
+// off that count (or finds the pool dry and puts it back), THEN a ticket off `head`, and waits for that cell's push to be published,
+// which is under way by then; a push takes a ticket off `tail`, writes its cell and adds one to `avail`.  Every operation is a fixed
+// number of atomics whoever else is at the ring.
+// low_water: the fewest chunks `avail` has held since the ring was initialised -- the pool's high-water mark of chunks out at once is
+// n_chunks - low_water (unc_mapper_pool_usage: the pool is sized by it, not by a share of the free HBM)
+struct alignas(128) PoolQueue {
+    int32_t avail; uint32_t pad0[31];
+    uint32_t head; uint32_t pad1[31];
+    uint32_t tail; uint32_t pad2[31];
+    uint32_t low_water; uint32_t pad3[31];
+};
 struct DevPool {
     char *nodes;                // [n_chunks][POOL_CHUNK_BYTES]
-    SchedQueue *q;
+    PoolQueue *q;
     SchedCell *cells;
     uint32_t cap_mask, n_chunks;
 };

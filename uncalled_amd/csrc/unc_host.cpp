@@ -579,7 +579,7 @@ static int alloc_pool(DevPool &p, uint32_t n_chunks, size_t *bytes_out) {
     while (cap < n_chunks) cap <<= 1;
     p.cap_mask = cap - 1; p.n_chunks = n_chunks;
     HIPCHK(hipMalloc((void **)&p.nodes, (size_t)n_chunks * POOL_CHUNK_BYTES));
-    HIPCHK(hipMalloc((void **)&p.q, sizeof(SchedQueue)));
+    HIPCHK(hipMalloc((void **)&p.q, sizeof(PoolQueue)));
     HIPCHK(hipMalloc((void **)&p.cells, (size_t)cap * sizeof(SchedCell)));
     launch_pool_init(p, nullptr);
     HIPCHK(hipGetLastError());
@@ -829,7 +829,7 @@ static void fill_hit(const unc_index *ix, const unc_params_t &P, const DevResult
     }
 }
 
-// chunks that were out at once in the launches since the pool was last initialised (SchedQueue::low_water)
+// chunks that were out at once in the launches since the pool was last initialised (PoolQueue::low_water)
 static int pool_note_high_water(unc_mapper *m, hipStream_t st) {
     uint32_t lw = m->pool.n_chunks;
     HIPCHK(hipMemcpyAsync(&lw, &m->pool.q->low_water, 4, hipMemcpyDeviceToHost, st));
