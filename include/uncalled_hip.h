@@ -186,7 +186,10 @@ typedef struct {
                               * time: chunks in the pool (0 = 8 per slot, 64 per slot for references of 2^26 index rows and more, at
                               * most 60 % of the free HBM); k_map stops admitting reads while the pool is nearly empty, and a read
                               * that still finds it dry is mapped again after the batch */
-    uint32_t reserved_;      /* 0 */
+    uint32_t sched_parts;    /* pairs of scheduler rings (free slots, parked reads): 0 = one per XCD of the device when n_slots divides
+                              * into that many shares of 64 slots or more (a slot then stays with one XCD's wavefronts, whose L2 is
+                              * coherent among them: no L2 write-back / invalidate when a read is parked and resumed), else one;
+                              * 1 = one pair for the whole device */
     uint32_t events_reads_per_wave;   /* k_events: reads (lanes in use) per wavefront, 1..64 (0 = 64; measured on 50 k reads:
                               * 64 -> 27 ms, 32 -> 36 ms: the kernel is bound by instruction issue) */
 } unc_mapper_opts_t;
@@ -231,6 +234,8 @@ void unc_mapper_set_profile(unc_mapper_t *m, int on);
 /* what unc_mapper_create settled on: [0] resident wavefronts, [1] reads in flight (slots), [2] events per time slice
  * (0: one read per wavefront until it is done), [3] chunks in the seed-cluster node pool, [4] max_clusters (a read's allowance x 4) */
 void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5);
+/* pairs of scheduler rings the mapper settled on (unc_mapper_opts_t.sched_parts); 0: no time slicing (one slot per wavefront) */
+uint32_t unc_mapper_sched_parts(const unc_mapper_t *m);
 /* The seed-cluster node pool is sized by need.  The reference's SeedTracker is an unbounded std::set per Mapper
  * (src/seed_tracker.hpp:97-110); here its nodes come from ONE pool per mapper.  unc_mapper_create sizes the pool by a rule of
  * thumb for the first batch; after a batch that used less than an eighth of it the library shrinks it to four times the most chunks

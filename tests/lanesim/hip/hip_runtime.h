@@ -120,7 +120,7 @@ static inline int __lanesim_lane() { return (int)(threadIdx.x & 63); }
 static inline void __syncthreads() { lanesim::block_barrier(); }
 static inline void __builtin_amdgcn_wave_barrier() { lanesim::wave_exchange(0); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
-static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }      // (hardware id registers: XCC 0, CU 0)
+static inline unsigned __builtin_amdgcn_s_getreg(int r) { return r == 6164 ? (blockIdx.x + 3u) & 7u : 0u; }      // (hardware id registers: eight XCDs dealt round-robin from XCD 3 on, CU 0)
 static inline void __threadfence() {}
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 

@@ -594,6 +594,36 @@ def case_sliced_scheduler(lib, oracle_lib, example, goldens, max_paths=10000, sl
     assert_hits_equal(hits, oracle_hits(oix, raw, off, cal, to_oracle_params(p), fresh_mapper_per_read=True), "sliced")
 
 
+def case_scheduler_rings_per_xcd(lib, oracle_lib, example, goldens, n_reads=24, slice_events=37):
+    """One pair of scheduler rings per XCD (SchedCtl): a slot stays with the wavefronts of one XCD, which park and resume its reads without
+    an L2 write-back / invalidate.  512 slots divide into eight shares of 64: the library settles on the device's XCD count (8 on the
+    MI355X; the emulator deals its workgroups to eight XCDs from XCD 3 on, so the shares in use are not the first), a mapper told
+    sched_parts=1 keeps one pair for the device, and both answer as the oracle does; a share of fewer than 64 slots falls back to one pair."""
+    dev_index = _index(lib, example)
+    off_all = goldens["sim_offsets"]
+    raw = goldens["sim_signal"][:int(off_all[n_reads])]
+    off = off_all[:n_reads + 1].copy()
+    cal = capi.make_calib(n_reads, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
+    oix = oracle_lib.Index(example["prefix"])
+    want = oracle_hits(oix, raw, off, cal, fresh_mapper_per_read=True)
+    m = capi.Mapper(dev_index, n_slots=512, n_waves=8, slice_events=slice_events, pool_chunks=256)
+    parts = m.sched_parts()
+    assert parts in (1, 8), parts               # (1: a device, or a partition mode, that shows one XCD)
+    hits = m.map_batch(raw, off, cal)
+    again = m.map_batch(raw, off, cal)
+    assert_hits_equal(hits, want, "rings per XCD")
+    m1 = capi.Mapper(dev_index, n_slots=512, n_waves=8, slice_events=slice_events, pool_chunks=256, sched_parts=1)
+    assert m1.sched_parts() == 1
+    hits1 = m1.map_batch(raw, off, cal)
+    for name in capi.RESULT_FIELDS:
+        assert np.array_equal(again[name], hits[name]) and np.array_equal(hits1[name], hits[name]), name
+    m2 = capi.Mapper(dev_index, n_slots=256, n_waves=8, slice_events=slice_events, pool_chunks=256)      # shares of 32 slots
+    assert m2.sched_parts() == 1
+    with pytest.raises(capi.UncalledHipError):
+        capi.Mapper(dev_index, n_slots=512, n_waves=8, slice_events=slice_events, pool_chunks=256, sched_parts=3)
+    return parts
+
+
 def case_cluster_pool_pressure(lib, oracle_lib, example, goldens, pool_chunks=2, n_waves=2, n_reads=12):
     """The nodes of all seed-cluster sets come from one pool.  With fewer chunks than reads in flight some reads find it
     dry; with a tiny allowance of nodes some outgrow that: both are mapped again after the batch (with fewer reads sharing

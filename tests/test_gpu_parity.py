@@ -212,6 +212,12 @@ def test_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slic
     pc.case_sliced_scheduler(hip_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves)
 
 
+def test_scheduler_rings_per_xcd(hip_lib, oracle_lib, example, goldens):
+    """On the GPU the eight wavefronts really sit on eight XCDs: every share's rings are in use, and parked reads are resumed out of an L2
+    that nobody wrote back or invalidated in between."""
+    assert pc.case_scheduler_rings_per_xcd(hip_lib, oracle_lib, example, goldens, n_reads=24) == 8
+
+
 @pytest.mark.parametrize("pool_chunks,n_waves", [(3, 2), (1, 1)])
 def test_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
     pc.case_cluster_pool_pressure(hip_lib, oracle_lib, example, goldens, pool_chunks, n_waves)

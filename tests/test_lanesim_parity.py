@@ -139,6 +139,10 @@ def test_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slic
     pc.case_sliced_scheduler(sim_lib, oracle_lib, example, goldens, max_paths, slice_events, n_slots, n_waves, n_reads=6)
 
 
+def test_scheduler_rings_per_xcd(sim_lib, oracle_lib, example, goldens):
+    assert pc.case_scheduler_rings_per_xcd(sim_lib, oracle_lib, example, goldens, n_reads=12) == 8
+
+
 @pytest.mark.parametrize("pool_chunks,n_waves", [(1, 1)])
 def test_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves):
     pc.case_cluster_pool_pressure(sim_lib, oracle_lib, example, goldens, pool_chunks, n_waves, n_reads=4)

@@ -45,6 +45,8 @@ for spec in sys.argv[2:]:
         kw["slice_events"] = int(rest[1])
     if len(rest) > 2 and int(rest[2]):
         kw["events_reads_per_wave"] = int(rest[2])
+    if len(rest) > 4 and int(rest[4]):          # pairs of scheduler rings (1 = one for the device, 0 = per XCD)
+        kw["sched_parts"] = int(rest[4])
     if len(rest) > 3 and int(rest[3]):          # wavefronts in flight (0 = what the kernel's occupancy gives)
         kw["n_waves"] = int(rest[3])
         if kw.get("n_slots") is None and rest and int(rest[0]) == 0:

@@ -32,7 +32,7 @@ class Params(C.Structure):
 
 class MapperOpts(C.Structure):
     _fields_ = [("n_slots", C.c_uint32), ("max_clusters", C.c_uint32), ("max_seed_paths", C.c_uint32),
-                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("pool_chunks", C.c_uint32), ("reserved_", C.c_uint32),
+                ("slice_events", C.c_uint32), ("n_waves", C.c_uint32), ("pool_chunks", C.c_uint32), ("sched_parts", C.c_uint32),
                 ("events_reads_per_wave", C.c_uint32)]
 
 
@@ -308,11 +308,11 @@ class Mapper:
     """Batch mapper: N x (Mapper::new_read + Mapper::map_read) on the GPU (mapper.cpp:188-207)."""
 
     def __init__(self, index, params=None, n_slots=0, max_clusters=0, max_seed_paths=0, slice_events=0, n_waves=0, pool_chunks=0,
-                 events_reads_per_wave=0):
+                 events_reads_per_wave=0, sched_parts=0):
         self.index = index
         self.L = index.L
         self.params = params or default_params(self.L)
-        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, pool_chunks, 0, events_reads_per_wave)
+        opts = MapperOpts(n_slots, max_clusters, max_seed_paths, slice_events, n_waves, pool_chunks, sched_parts, events_reads_per_wave)
         h = C.c_void_p()
         _check(self.L, self.L.unc_mapper_create(index.h, C.byref(self.params), C.byref(opts), C.byref(h)))
         self.h = h
@@ -400,6 +400,12 @@ class Mapper:
         out = np.zeros(5, dtype=np.uint32)
         self.L.unc_mapper_geometry(self.h, out.ctypes.data)
         return dict(zip(("n_waves", "n_slots", "slice_events", "pool_chunks", "max_clusters"), (int(x) for x in out)))
+
+    def sched_parts(self):
+        """Pairs of scheduler rings (one per XCD where the slots divide; 0: no time slicing)."""
+        self.L.unc_mapper_sched_parts.restype = C.c_uint32
+        self.L.unc_mapper_sched_parts.argtypes = [C.c_void_p]
+        return int(self.L.unc_mapper_sched_parts(self.h))
 
     def pool_usage(self):
         """Seed-cluster node pool: chunks (192 KB each) held now, high-water mark of chunks out at once in the last batch / ever,

@@ -1349,23 +1349,26 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             uint32_t kind = 0, tslot = 0, tread = 0;
             if (lane == 0) {
                 SchedCtl *const sc = A->sched.ctl;
-                SchedCell *const free_cells = A->sched.free_cells, *const park_cells = A->sched.park_cells;
                 const uint32_t cap_mask = A->sched.cap_mask, n_reads = A->rd.n_reads;
+                const uint32_t part = sched_part(A->sched.n_parts);
+                SchedCell *const free_cells = A->sched.free_cells + (size_t)part * (cap_mask + 1u);
+                SchedCell *const park_cells = A->sched.park_cells + (size_t)part * (cap_mask + 1u);
+                SchedQueue *const freeq = &sc->freeq[part], *const parkq = &sc->parkq[part];
                 for (int tries = 0; tries < 4096 && !kind; ++tries) {
                     const bool more = ld_rlx(&sc->next_read) < n_reads;
                     // admission control: while the pool of cluster nodes is below an eighth, reads in flight go first (they
                     // give their chunks back when they end); a new read is only started when none of them is waiting
                     const bool low = (int32_t)ld_rlx(reinterpret_cast<const uint32_t *>(&A->pool.q->avail)) < (int32_t)(A->pool.n_chunks >> 3);
                     if (more && (!low || tries >= 8)) {
-                        const uint32_t fs = sched_pop(&sc->freeq, free_cells, cap_mask);
+                        const uint32_t fs = sched_pop(freeq, free_cells, cap_mask);
                         if (fs != SCHED_EMPTY) {
                             const uint32_t t = atomicAdd(&sc->next_read, 1u);
                             if (t < n_reads) { kind = 1; tslot = fs; tread = t; }
-                            else sched_push(&sc->freeq, free_cells, cap_mask, fs);
+                            else sched_push(freeq, free_cells, cap_mask, fs);
                         }
                     }
                     if (!kind) {
-                        const uint32_t ps = sched_pop(&sc->parkq, park_cells, cap_mask);
+                        const uint32_t ps = sched_pop(parkq, park_cells, cap_mask);
                         if (ps != SCHED_EMPTY) { kind = 2; tslot = ps; }
                     }
                     // reads left but every slot is in another wavefront's hands right now: wait for one to come back
@@ -1375,7 +1378,10 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
             kind = bcast32(kind, 0); tslot = bcast32(tslot, 0); tread = bcast32(tread, 0);
             if (!kind) break;
             slot = tslot; r = tread; restore = kind == 2;
-            __threadfence();   // the slot may have been parked by a wavefront on another CU
+            // the slot was parked (or freed) by another wavefront: of this XCD when the rings are per XCD -- the L2 is theirs in common,
+            // only this CU's vector L1 may hold lines of the slot from an earlier slice --, of any XCD otherwise
+            if (A->sched.n_parts > 1u) l1_invalidate();
+            else __threadfence();
         }
 
         // everything this read owns hangs off ONE uniform pointer; regions are 32-bit byte offsets (DevScratch)
@@ -1536,11 +1542,14 @@ __global__ __launch_bounds__(64, UNC_LB) void k_map(MapArgs Aval) {
         }
         if (sliced) {
             // hand the slot back: to the free ring when the read is finished, else to the end of the parked ring
-            __threadfence();
+            // (per-XCD rings: the next wavefront to hold the slot shares this one's L2 -- the stores only have to have arrived there)
+            if (A->sched.n_parts > 1u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            else __threadfence();
             if (lane == 0) {
                 SchedCtl *const sc = A->sched.ctl;
-                if (done) sched_push(&sc->freeq, A->sched.free_cells, A->sched.cap_mask, slot);
-                else sched_push(&sc->parkq, A->sched.park_cells, A->sched.cap_mask, slot);
+                const uint32_t cap = A->sched.cap_mask + 1u, part = sched_part_of_slot(A->sched.n_slots, A->sched.n_parts, slot);
+                if (done) sched_push(&sc->freeq[part], A->sched.free_cells + (size_t)part * cap, A->sched.cap_mask, slot);
+                else sched_push(&sc->parkq[part], A->sched.park_cells + (size_t)part * cap, A->sched.cap_mask, slot);
             }
         }
         wave_sync();
@@ -2390,24 +2399,28 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
 }
 // every slot free, nothing parked, queue head at the first read
 __global__ void k_sched_init(DevSched S) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = S.cap_mask + 1u;
-    if (i < cap) {
-        SchedCell f; f.seq = i < S.n_slots ? i + 1u : i; f.val = i;
-        S.free_cells[i] = f;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, cap = S.cap_mask + 1u;
+    const uint32_t part = t / cap, i = t % cap, spp = S.n_slots / S.n_parts;       // partition p owns slots p * spp .. (p + 1) * spp - 1
+    if (part < S.n_parts) {
+        SchedCell f; f.seq = i < spp ? i + 1u : i; f.val = part * spp + i;
+        S.free_cells[t] = f;
         SchedCell p; p.seq = i; p.val = 0;
-        S.park_cells[i] = p;
+        S.park_cells[t] = p;
     }
-    if (i == 0) {
+    if (t == 0) {
         SchedCtl c;
         memset(&c, 0, sizeof c);
-        c.freeq.tail = S.n_slots;
+        for (uint32_t q = 0; q < S.n_parts; ++q) c.freeq[q].tail = spp;
         *S.ctl = c;
     }
 }
 void launch_sched_init(const DevSched &S, hipStream_t st) {
-    const uint32_t cap = S.cap_mask + 1u;
-    hipLaunchKernelGGL(k_sched_init, dim3((cap + 255) / 256), dim3(256), 0, st, S);
+    const uint32_t n = (S.cap_mask + 1u) * S.n_parts;
+    hipLaunchKernelGGL(k_sched_init, dim3((n + 255) / 256), dim3(256), 0, st, S);
 }
+// which XCD a workgroup runs on, per workgroup of a small grid: the host counts the distinct answers (unc_host.cpp: xcd_count)
+__global__ void k_xcd_probe(uint32_t *out) { if (threadIdx.x == 0) out[blockIdx.x] = xcd_id(); }
+void launch_xcd_probe(uint32_t *out, uint32_t n_blocks, hipStream_t st) { hipLaunchKernelGGL(k_xcd_probe, dim3(n_blocks), dim3(64), 0, st, out); }
 // every chunk of the node pool free
 __global__ void k_pool_init(DevPool B) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, cap = B.cap_mask + 1u;

@@ -41,6 +41,12 @@ __device__ __forceinline__ uint32_t sched_pop(SchedQueue *q, SchedCell *cells, u
     }
 }
 
+// ---- which pair of rings: the XCD this wavefront runs on (hardware register XCC_ID; workgroups are dealt to the XCDs round-robin, and
+// the register is what says whose L2 this is), the partition that owns a slot
+__device__ __forceinline__ uint32_t xcd_id() { return (uint32_t)__builtin_amdgcn_s_getreg(6164) & 0xFu; }      // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ __forceinline__ uint32_t sched_part(uint32_t n_parts) { return n_parts > 1u ? xcd_id() % n_parts : 0u; }
+__device__ __forceinline__ uint32_t sched_part_of_slot(uint32_t n_slots, uint32_t n_parts, uint32_t slot) { return n_parts > 1u ? slot / (n_slots / n_parts) : 0u; }
+
 // ---- the node pool's ring (PoolQueue, unc_dev_types.h): no loop that another wavefront's progress can restart
 __device__ __forceinline__ uint32_t pool_ring_pop(PoolQueue *q, SchedCell *cells, uint32_t mask) {
     const int32_t a = atomicAdd(&q->avail, -1);

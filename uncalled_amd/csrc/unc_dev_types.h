@@ -108,9 +108,14 @@ struct alignas(16) SlotState {
 // up on GRCh38.  The counters sit on lines of their own (128 bytes: the L2's line).
 struct alignas(8) SchedCell { uint32_t seq, val; };
 struct alignas(128) SchedQueue { uint32_t head; uint32_t pad0[31]; uint32_t tail; uint32_t pad1[31]; };
+// One pair of rings PER XCD (SCHED_MAX_PARTS; DevSched::n_parts of them in use): a slot belongs to one XCD for good -- its reads are
+// taken up, parked and resumed by wavefronts of that XCD only, whose L2 is coherent among them.  Handing a slot from one XCD to
+// another costs a write-back of the giver's whole L2 and an invalidate of the taker's (agent-scope release / acquire on this chip);
+// with one pair of rings for the whole device that was paid on every park and every resume, five to six times per read.
+constexpr uint32_t SCHED_MAX_PARTS = 8;
 struct alignas(128) SchedCtl {
     uint32_t next_read, pad0[31];
-    SchedQueue freeq, parkq;
+    SchedQueue freeq[SCHED_MAX_PARTS], parkq[SCHED_MAX_PARTS];
 };
 // The node pool of the seed-cluster grids (see ClusterKey): chunk ids travel through a ring as well, but one that is never polled by a
 // compare-and-swap loop: `avail` counts the chunks that are in the ring (published) and not yet spoken for -- a pop first takes one
@@ -134,9 +139,11 @@ struct DevPool {
 
 struct DevSched {
     SchedCtl *ctl;           // null: scheduler off (one slot per wavefront)
-    SchedCell *free_cells, *park_cells;   // [cap] each
-    uint32_t cap_mask;       // cap - 1, cap = power of two >= n_slots
+    SchedCell *free_cells, *park_cells;   // [n_parts][cap] each
+    uint32_t cap_mask;       // cap - 1, cap = power of two >= n_slots / n_parts
     uint32_t n_slots;
+    uint32_t n_parts;        // 1: one pair of rings for all wavefronts (slots cross XCDs: release / acquire around every hand-over);
+                             // the device's number of XCDs: one pair per XCD, partition p owns slots p * n_slots / n_parts ...
 };
 
 struct DevIndex {

@@ -573,6 +573,34 @@ static void free_pool(DevPool &p) {
     memset(&p, 0, sizeof p);
 }
 
+// XCDs of a device: workgroups of a small grid report the XCD they run on (hardware register), the distinct answers are counted; once
+// per device and process.  (1 on a device with one XCD -- or whose partition mode shows one --: the rings then stay one pair.)
+static uint32_t xcd_count(int device) {
+    static std::mutex mu;
+    static std::map<int, uint32_t> known;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    uint32_t n = 1;
+    uint32_t *d = nullptr;
+    constexpr uint32_t NB = 256;
+    if (hipMalloc((void **)&d, NB * sizeof(uint32_t)) == hipSuccess) {
+        uint32_t h[NB];
+        launch_xcd_probe(d, NB, nullptr);
+        if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint32_t seen = 0;
+            for (uint32_t i = 0; i < NB; ++i) seen |= 1u << (h[i] & 15u);
+            n = (uint32_t)__builtin_popcount(seen);
+            // the ids must be 0 .. n - 1 (sched_part takes the id modulo n_parts)
+            if (seen != (n >= 32 ? ~0u : (1u << n) - 1u)) n = 1;
+        }
+        (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+    known[device] = n;
+    return n;
+}
+
 static int alloc_pool(DevPool &p, uint32_t n_chunks, size_t *bytes_out) {
     memset(&p, 0, sizeof p);
     uint32_t cap = 64;
@@ -692,13 +720,20 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         if (rc2) return rc2;
     }
     if (n_slots > n_waves) {
+        // one pair of rings per XCD when every XCD's share of the slots is a fair number (SchedCtl): slots then never cross XCDs
+        uint32_t parts = (opts && opts->sched_parts) ? opts->sched_parts : xcd_count(ix->device);
+        if (parts > SCHED_MAX_PARTS || parts == 0 || n_slots % parts || n_slots / parts < 64 || (opts && opts->sched_parts > 1 && opts->sched_parts != xcd_count(ix->device))) {
+            if (opts && opts->sched_parts > 1) return fail(UNC_ERR_ARG, "sched_parts: 0, 1 or the device's number of XCDs (%u), dividing n_slots into shares of 64 or more", xcd_count(ix->device));
+            parts = 1;
+        }
+        const uint32_t spp = n_slots / parts;
         uint32_t cap = 64;
-        while (cap < n_slots) cap <<= 1;
-        m->sched.cap_mask = cap - 1; m->sched.n_slots = n_slots;
+        while (cap < spp) cap <<= 1;
+        m->sched.cap_mask = cap - 1; m->sched.n_slots = n_slots; m->sched.n_parts = parts;
         HIPCHK(hipMalloc((void **)&m->sched.ctl, sizeof(SchedCtl)));
-        HIPCHK(hipMalloc((void **)&m->sched.free_cells, (size_t)cap * sizeof(SchedCell)));
-        HIPCHK(hipMalloc((void **)&m->sched.park_cells, (size_t)cap * sizeof(SchedCell)));
-        bytes += sizeof(SchedCtl) + 2 * (size_t)cap * sizeof(SchedCell);
+        HIPCHK(hipMalloc((void **)&m->sched.free_cells, (size_t)parts * cap * sizeof(SchedCell)));
+        HIPCHK(hipMalloc((void **)&m->sched.park_cells, (size_t)parts * cap * sizeof(SchedCell)));
+        bytes += sizeof(SchedCtl) + 2 * (size_t)parts * cap * sizeof(SchedCell);
     }
     m->device_bytes = bytes;
     {
@@ -1194,6 +1229,7 @@ extern "C" int unc_mapper_last_read_cycles(const unc_mapper_t *m, uint32_t n_rea
     return UNC_OK;
 }
 
+extern "C" uint32_t unc_mapper_sched_parts(const unc_mapper_t *m) { return (m && m->sched.ctl) ? m->sched.n_parts : 0u; }
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" int unc_mapper_set_read_order(unc_mapper_t *m, int order) {
     if (!m || (order != UNC_ORDER_INDEPENDENT && order != UNC_ORDER_T1)) return fail(UNC_ERR_ARG, "unc_mapper_set_read_order: UNC_ORDER_INDEPENDENT or UNC_ORDER_T1");

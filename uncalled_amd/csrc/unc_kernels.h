@@ -14,6 +14,7 @@ void launch_map(const DevIndex &ix, const DevScratch &sc, const DevReads &rd, co
                 const DevSched *sched = nullptr, bool profile = false, const uint32_t *flags_in = nullptr, uint32_t *flags_out = nullptr,
                 uint32_t team = 1);   // chunked path only: wavefronts per channel (1, 2 or 4)
 void launch_sched_init(const DevSched &S, hipStream_t st);
+void launch_xcd_probe(uint32_t *out, uint32_t n_blocks, hipStream_t st);
 void launch_pool_init(const DevPool &B, hipStream_t st);
 uint32_t map_kernel_waves_per_cu();
 int map_kernel_attributes(bool narrow, bool profile, uint32_t *out4);   // VGPRs, scratch bytes / lane, LDS bytes, max threads

@@ -25,6 +25,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Drop this CU's vector L1: data another CU of the SAME XCD has written since (through the L2 they share) is read afresh.  The
+// agent-scope acquire does this too, and invalidates the XCD's whole L2 on top.
+#ifdef LANESIM
+__device__ __forceinline__ void l1_invalidate() {}
+#else
+__device__ __forceinline__ void l1_invalidate() { asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc0" ::: "memory"); }
+#endif
+
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) { return (uint64_t)__shfl((unsigned long long)v, src); }
 __device__ __forceinline__ float bcastf(float v, int src) { return __shfl(v, src); }
