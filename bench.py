@@ -380,7 +380,7 @@ def run_workload(a, workload, n_reads, steps, warmup, rank, world, local_rank, d
     ix = capi.Index(prefix, device=local_rank if have_gpu else 0, lib=lib)
     if have_gpu:
         torch.cuda.empty_cache()                 # blocks torch still caches from the index build: the mapper sizes its pool by what is free
-    kw = dict(pool_chunks=a.pool_chunks)
+    kw = dict(pool_chunks=a.pool_chunks, n_slots=getattr(a, "slots", 0))
     if not have_gpu:
         kw.update(n_slots=4, n_waves=2)          # lanesim plumbing test
     mapper = capi.Mapper(ix, **kw)
@@ -822,6 +822,7 @@ def main():
                     help="reads per GPU per step of the headline workload (default: 50 000 = BASELINE config 2; UNC_BENCH_READS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool-chunks", type=int, default=0, help="chunks of the seed-cluster node pool (0 = library default)")
+    ap.add_argument("--slots", type=int, default=0, help="reads in flight per mapper (0 = library default)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the extra untimed passes (PCIe-inclusive rate, phase cycle shares)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="one mapper, the steps one after the other (default: two mappers, batch k + 1 begun while batch k's tail drains)")

@@ -175,7 +175,7 @@ int unc_self_align(const unc_index_t *ix, const char *bwa_prefix, uint32_t sampl
 /* ---- mapper: replaces N x (Mapper::new_read + Mapper::map_read) (mapper.cpp:188-207), i.e. the
  * body of MapPool::MapperThread::run (map_pool.cpp:130-158), for a whole batch of reads. */
 typedef struct {
-    uint32_t n_slots;        /* reads in flight = per-read scratch slots (0 = 4 x n_waves, memory permitting) */
+    uint32_t n_slots;        /* reads in flight = per-read scratch slots (0 = 3 x n_waves, memory permitting) */
     uint32_t max_clusters;   /* a read's allowance of the shared node pool: max_clusters / 4 nodes (of 5 clusters; 0 = 2^20);
                               * reads that outgrow it are mapped again with a 16x larger allowance */
     uint32_t max_seed_paths; /* seed-valid paths per event (0 = 2 * max_paths, the bound) */

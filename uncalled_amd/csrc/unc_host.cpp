@@ -668,15 +668,18 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         if (n_slots && n_slots < n_waves) n_waves = n_slots;
     }
     if (n_slots == 0) {
-        // four times more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched);
-        // about 5 MB of scratch per slot, bounded by a third of the free HBM
+        // three times more reads in flight than wavefronts, so that the long reads of a batch are found early (DevSched); 2 - 3 MB of
+        // scratch per slot, bounded by a third of the free HBM.  (Rounds 2-5: four times.  With the rings per XCD, E. coli maps 5 - 8 %
+        // faster at 2.5 - 3 and at 4.25 - 5 reads per wavefront than at 3.5 - 4, chr20 3 % faster, GRCh38 the same, and a quarter of the
+        // slots' memory is saved: profiles/r06_ab_slots_*.log.)
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const uint32_t msp0 = (opts && opts->max_seed_paths) ? opts->max_seed_paths : 2 * p->max_paths;
         const uint32_t mcl0 = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
         const size_t per_slot = scratch_slot_bytes(*p, mcl0, msp0, ix->dev);
-        size_t want = (size_t)n_waves * 4, fit = free_b / 3 / per_slot;
+        size_t want = (size_t)n_waves * 3, fit = free_b / 3 / per_slot;
         n_slots = (uint32_t)(want < fit ? want : fit);
+        if (n_slots > 512) n_slots -= n_slots % 512;      // (whole shares of 64 slots and more for the rings of up to eight XCDs)
         if (n_slots < n_waves) n_slots = n_waves;
     }
     if (n_slots < n_waves) n_waves = n_slots;
