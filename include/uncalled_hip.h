@@ -183,7 +183,7 @@ typedef struct {
                               * next task (a new read while a slot is free, else the longest-parked read); 0 = 1024 */
     uint32_t n_waves;        /* resident wavefronts of the persistent k_map grid (0 = 16 per CU) */
     uint32_t pool_chunks;    /* the seed-cluster nodes of ALL reads in flight come from one pool, a chunk of 192 KB (768 nodes) at a
-                              * time: chunks in the pool (0 = 8 per slot, 64 per slot for references of 2^26 index rows and more, at
+                              * time: chunks in the pool (0 = 8 per slot, 24 for references of 2^26 index rows and more, 32 from 2^31 on, at
                               * most 60 % of the free HBM); k_map stops admitting reads while the pool is nearly empty, and a read
                               * that still finds it dry is mapped again after the batch */
     uint32_t sched_parts;    /* pairs of scheduler rings (free slots, parked reads): 0 = one per XCD of the device when n_slots divides

@@ -58,13 +58,16 @@ for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ
         der[k[3:].lower() + "_per_read"] = g(k) / reads
 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INST_CYCLES_VALU"):
     der["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INST_CYCLES_VALU"))
-# how busy the vector ALUs are: a wave64 VALU instruction occupies its SIMD for 4 cycles, and SQ_ACTIVE_INST_VALU counts exactly
-# those quad-cycles -- so VALU-busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clock x duration).  (Round 5: this, not the 22 % of
-# "issue slots", is the number that says how far k_map is from being ALU-bound.)
+# how busy the vector ALUs are (round 5 took a wave64 VALU instruction to occupy its SIMD for 4 cycles and read 4 x SQ_ACTIVE_INST_VALU
+# as VALU-busy: 55 - 60 %; round 6 measured two cycles -- see below)
 for name, p in passes.items():
     if "SQ_ACTIVE_INST_VALU" in p["counters"] and p["k_map_ms_under_pmc"]:
         ms = sum(p["k_map_ms_under_pmc"])
-        der["valu_pipe_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (1024 * 2.4e9 * ms * 1e-3)
+        # round 6: a wave64 VALU instruction holds its SIMD for TWO cycles (tools/dev/ubench_valu.hip); SQ_ACTIVE_INST_VALU counts
+        # quad-cycles and rounds every instruction up to one, so 4 x that counter is an upper bound (kept as valu_quad_cycle_share)
+        der["valu_quad_cycle_share"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (1024 * 2.4e9 * ms * 1e-3)
+        if g("SQ_INSTS_VALU") is not None:
+            der["valu_pipe_busy"] = 2.0 * g("SQ_INSTS_VALU") / (1024 * 2.4e9 * ms * 1e-3)
 # issue utilisation: wave-instructions / (1024 SIMDs x clock x k_map's duration in the pass that counted them); the clock is
 # the 2.4 GHz peak engine clock (MI355X_MICROARCH.md), so this is a lower bound on the share of issue slots used
 CLOCK_HZ, SIMDS = 2.4e9, 1024

@@ -709,10 +709,13 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
             const size_t chunk_bytes = POOL_CHUNK_BYTES;
-            // (per read in flight: 8 chunks on a bacterial reference, 24 from 2^26 index rows on -- chr20: eleven out at the peak --, 64 from
-            // 2^31 on -- GRCh38: 23 out at the peak, and the peak moves by a tenth from launch to launch.  Rounds 2-5 gave every reference
-            // past 2^26 rows 64: 155 GB for chr20, which left no room for a second mapper beside the first)
-            const size_t per_slot = ix->seq_len >= (1ull << 31) ? 64 : ix->seq_len >= (1ull << 26) ? 24 : 8;
+            // (per read in flight: 8 chunks on a bacterial reference, 24 from 2^26 index rows on -- chr20: eleven out at the peak --, 32 from
+            // 2^31 on (rounds 2-5 and most of round 6: 64, for every reference past 2^26 rows -- 155 GB for chr20, which left no room for a
+            // second mapper beside the first)
+            // Round 6, after the ring change: GRCh38 with 12 288 reads in flight has 287 000 chunks out at the peak, the same in every
+            // launch (23 per read in flight): 32 per slot = 393 000 chunks = 75 GB = 1.37 x the peak, where 64 (capped at 60 % of the
+            // free HBM) had grown to 131 GB once the dense SA and the slots had shrunk.
+            const size_t per_slot = ix->seq_len >= (1ull << 31) ? 32 : ix->seq_len >= (1ull << 26) ? 24 : 8;
             const size_t want = (size_t)n_slots * per_slot;
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
             m->pool_auto = true;
