@@ -5,7 +5,10 @@ around the defaults, random mapper geometry (slots, slice length, wavefronts, ti
 prints the seed that reproduces it.
 
     python tests/dev/fuzz_parity.py [n_rounds] [first_seed] [rt]        (rt: the chunked path instead of the batch path; wide: the batch path with 128-bit sort keys;
-                                                                         t1: the batch path in UNC_ORDER_T1 with path buffers small enough to leak flags)"""
+                                                                         t1: the batch path in UNC_ORDER_T1 with path buffers small enough to leak flags;
+                                                                         xcd: the batch path on a mapper whose scheduler rings are per XCD -- 512 / 1 024 slots, 16 - 64 wavefronts,
+                                                                         slices of 5 - 64 events, ~100 reads per round: every read parked and resumed dozens of times by other
+                                                                         wavefronts of its XCD.  Meant for the GPU: UNC_FUZZ_LIB=uncalled_amd/libuncalled_hip.so)"""
 import sys
 import tempfile
 import time
@@ -167,20 +170,26 @@ def main():
                 n_reads_total += n
                 print(f"seed {seed}: {n} reads ok ({what}) [{time.time() - t0:.0f} s]", flush=True)
                 continue
-            n = int(rng.integers(2, 6))
-            sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1800)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
+            xcd = len(sys.argv) > 3 and sys.argv[3] == "xcd"
+            n = int(rng.integers(2, 6)) if not xcd else int(rng.integers(*[int(x) for x in os.environ.get("UNC_FUZZ_XCD_READS", "80,141").split(",")]))
+            sim = simulate_reads(codes, lens, n, seed=seed, read_bases=int(rng.integers(300, 1800 if not xcd else 1000)), off_target=float(rng.choice([0.0, 0.3, 1.0])),
                                  dwell_mean=float(rng.uniform(6.0, 12.0)), noise_sd=float(rng.uniform(0.5, 3.0)))
             p = draw_params(rng)
             n_waves = int(rng.integers(1, 3))
             kw = dict(n_waves=n_waves, n_slots=n_waves * int(rng.integers(1, 4)), slice_events=int(rng.choice([0, 13, 64, 1024])))
-            if rng.random() < 0.3:
+            if xcd:
+                kw = dict(n_waves=int(rng.choice([16, 32, 64])), n_slots=int(rng.choice([512, 1024])), slice_events=int(rng.choice([5, 13, 29, 64])), pool_chunks=2048)
+            if rng.random() < 0.3 and not xcd:
                 kw["pool_chunks"] = int(rng.integers(1, 4))
-            if rng.random() < 0.2:
+            if rng.random() < 0.2 and not xcd:
                 kw["max_clusters"] = int(rng.choice([8, 64]))
             cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
             try:
                 tight = "pool_chunks" in kw or "max_clusters" in kw
-                hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal, allow_overflow=tight)
+                mp = capi.Mapper(dix, params=p, **kw)
+                if xcd:
+                    kw["rings"] = mp.sched_parts()
+                hits = mp.map_batch(sim["signal"], sim["offsets"], cal, allow_overflow=tight)
                 want = oracle_hits(oix, sim["signal"], sim["offsets"], cal, to_oracle_params(p), fresh_mapper_per_read=True)
                 loud = np.flatnonzero(hits["status"])
                 if loud.size:
@@ -189,7 +198,7 @@ def main():
                     ok = np.flatnonzero(hits["status"] == 0)
                     assert_hits_equal(hits[ok], want[ok], f"seed {seed}, reads beside the overflowed ones")
                     kw = {k: v for k, v in kw.items() if k not in ("pool_chunks", "max_clusters")}
-                    hits = capi.Mapper(dix, params=p, **kw).map_batch(sim["signal"], sim["offsets"], cal)
+                    hits = capi.Mapper(dix, params=p, **{k: v for k, v in kw.items() if k != "rings"}).map_batch(sim["signal"], sim["offsets"], cal)
                     kw["loud_overflows_first"] = int(loud.size)
                 assert_hits_equal(hits, want, f"seed {seed}")
             except Exception as e:
