@@ -234,6 +234,9 @@ void unc_mapper_set_profile(unc_mapper_t *m, int on);
 /* what unc_mapper_create settled on: [0] resident wavefronts, [1] reads in flight (slots), [2] events per time slice
  * (0: one read per wavefront until it is done), [3] chunks in the seed-cluster node pool, [4] max_clusters (a read's allowance x 4) */
 void unc_mapper_geometry(const unc_mapper_t *m, uint32_t *out5);
+/* diagnostics: device addresses of the mapper's large allocations: [0] slots' base, [1] bytes per slot, [2] node pool's base,
+ * [3] its bytes, [4] event means, [5] results */
+int unc_mapper_device_addresses(const unc_mapper_t *m, uint64_t *out6);
 /* pairs of scheduler rings the mapper settled on (unc_mapper_opts_t.sched_parts); 0: no time slicing (one slot per wavefront) */
 uint32_t unc_mapper_sched_parts(const unc_mapper_t *m);
 /* The seed-cluster node pool is sized by need.  The reference's SeedTracker is an unbounded std::set per Mapper

@@ -192,6 +192,35 @@ extern "C" void unc_index_free(unc_index_t *ix) {
     delete ix;
 }
 
+// WHERE in the HBM a mapper's slots and node pool lie decides which of two speeds it runs at, for the life of the allocation: the same
+// library maps the same 50 000 E. coli reads in 2 040 or in 2 250 ms (round 6, tools/dev/placement_probe.py: mapper instances created
+// and freed one after the other at the SAME virtual addresses alternate between the two; one created while 60 GB of other memory is
+// held lands on the fast one every time).  Virtual addresses say nothing; what differs is the physical memory behind them: what the
+// process -- e.g. an index build -- has used and given back is handed out again first, in pieces, and a kernel that walks tens of
+// gigabytes at random pays for the pieces in address translation.  So the big random-access allocations (the slots, the node pool;
+// the index's tables likewise) are made while a SPACER holds what was given back, up to 64 GB, and the spacer is freed right after:
+// the streaming buffers allocated later (raw signal, event means) take its place.  UNC_PLACEMENT_SPACER_GB names another size (0: none).
+struct PlacementSpacer {
+    void *p = nullptr;
+    size_t bytes = 0;
+    explicit PlacementSpacer(size_t need_after) {
+        size_t cap = 64ull << 30;
+        if (const char *e = getenv("UNC_PLACEMENT_SPACER_GB")) cap = (size_t)strtoull(e, nullptr, 10) << 30;
+        size_t free_b = 0, total_b = 0;
+        if (!cap || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+        const size_t margin = 16ull << 30;       // (left alone beside what is about to be allocated)
+        if (free_b <= need_after + margin) return;
+        const size_t want = std::min(cap, free_b - need_after - margin);
+        if (want < (2ull << 30)) return;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return; }
+        bytes = want;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    ~PlacementSpacer() { release(); }
+    PlacementSpacer(const PlacementSpacer &) = delete;
+    PlacementSpacer &operator=(const PlacementSpacer &) = delete;
+};
+
 extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, int device, unc_index_t **out) {
     if (!bwa_prefix || !out) return fail(UNC_ERR_ARG, "null argument");
     *out = nullptr;
@@ -231,6 +260,8 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
     HIPCHK(hipSetDevice(device));
     // pad the BWT to whole 64-byte blocks so that block loads of the last (partial) block stay in bounds
     const size_t bwt_bytes = ((n_words * 4 + 63) / 64 + 1) * 64;
+    // (the index's tables are read at random by every FM step: allocated behind a spacer like the mapper's slots -- PlacementSpacer)
+    PlacementSpacer spacer(bwt_bytes + n_sa * 8 + ((size_t)n_words * 16 + 2) / 2 * 12 + (size_t)n_words * 2 + (64u << 20));
     HIPCHK(hipMalloc((void **)&ix->d_bwt, bwt_bytes));
     HIPCHK(hipMemset(ix->d_bwt, 0, bwt_bytes));
     HIPCHK(hipMemcpy(ix->d_bwt, bwt.data() + 40, n_words * 4, hipMemcpyHostToDevice));
@@ -265,6 +296,7 @@ extern "C" int unc_index_load(const char *bwa_prefix, const char *idx_preset, in
         const char *env = getenv("UNC_DENSE_SA");
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
+        free_b += spacer.bytes;
         const size_t need = ((n + 2) / 2) * 12 + 16;      // rows 0 .. n in pairs (12 bytes) + the word a load reads past the last entry
         if (!(env && env[0] == '0') && need < free_b / 2) {
             HIPCHK(hipMalloc((void **)&ix->d_sa_dense, need));
@@ -694,6 +726,10 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
     // per read: the table of bucket heads of its seed-cluster grid and the list of its pool chunks; max_clusters / 4 is the number
     // of nodes a read may take from the pool below (its allowance)
     const uint32_t mcl = (opts && opts->max_clusters) ? opts->max_clusters : (1u << 20);
+    // (what the slots and the pool will take, for the spacer: see PlacementSpacer)
+    const size_t pool_per_slot = ix->seq_len >= (1ull << 31) ? 32 : ix->seq_len >= (1ull << 26) ? 24 : 8;
+    const size_t pool_want = ((opts && opts->pool_chunks) ? (size_t)opts->pool_chunks : (size_t)n_slots * pool_per_slot) * POOL_CHUNK_BYTES;
+    PlacementSpacer spacer((size_t)n_slots * scratch_slot_bytes(*p, mcl, msp, ix->dev) + pool_want);
     int rc_ = alloc_scratch(m->sc, *p, n_slots, mcl, msp, &bytes, ix->dev);
     if (rc_) return rc_;
     HIPCHK(hipMalloc((void **)&m->d_next, 64));
@@ -708,6 +744,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         if (n_chunks == 0) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            free_b += spacer.bytes;             // (held only while the pool is allocated)
             const size_t chunk_bytes = POOL_CHUNK_BYTES;
             // (per read in flight: 8 chunks on a bacterial reference, 24 from 2^26 index rows on -- chr20: eleven out at the peak --, 32 from
             // 2^31 on (rounds 2-5 and most of round 6: 64, for every reference past 2^26 rows -- 155 GB for chr20, which left no room for a
@@ -715,7 +752,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
             // Round 6, after the ring change: GRCh38 with 12 288 reads in flight has 287 000 chunks out at the peak, the same in every
             // launch (23 per read in flight): 32 per slot = 393 000 chunks = 75 GB = 1.37 x the peak, where 64 (capped at 60 % of the
             // free HBM) had grown to 131 GB once the dense SA and the slots had shrunk.
-            const size_t per_slot = ix->seq_len >= (1ull << 31) ? 32 : ix->seq_len >= (1ull << 26) ? 24 : 8;
+            const size_t per_slot = pool_per_slot;
             const size_t want = (size_t)n_slots * per_slot;
             n_chunks = (uint32_t)std::max<size_t>(16, std::min<size_t>(want, free_b / 5 * 3 / chunk_bytes));
             m->pool_auto = true;
@@ -725,6 +762,7 @@ extern "C" int unc_mapper_create(const unc_index_t *ix, const unc_params_t *p, c
         int rc2 = alloc_pool(m->pool, n_chunks, &bytes);
         if (rc2) return rc2;
     }
+    spacer.release();
     if (n_slots > n_waves) {
         // one pair of rings per XCD when every XCD's share of the slots is a fair number (SchedCtl): slots then never cross XCDs
         uint32_t parts = (opts && opts->sched_parts) ? opts->sched_parts : xcd_count(ix->device);
@@ -1235,6 +1273,16 @@ extern "C" int unc_mapper_last_read_cycles(const unc_mapper_t *m, uint32_t n_rea
     return UNC_OK;
 }
 
+// where the mapper's large allocations lie (diagnostics: the same library maps the same batch 4 - 8 % faster or slower from one mapper
+// instance to the next, tools/dev/placement_probe.py): [0] slots' base, [1] bytes per slot, [2] node pool's base, [3] its bytes,
+// [4] event means, [5] results
+extern "C" int unc_mapper_device_addresses(const unc_mapper_t *m, uint64_t *out6) {
+    if (!m || !out6) return fail(UNC_ERR_ARG, "null argument");
+    out6[0] = (uint64_t)(uintptr_t)m->sc.base; out6[1] = m->sc.slot_bytes;
+    out6[2] = (uint64_t)(uintptr_t)m->pool.nodes; out6[3] = (uint64_t)m->pool.n_chunks * POOL_CHUNK_BYTES;
+    out6[4] = (uint64_t)(uintptr_t)m->d_means; out6[5] = (uint64_t)(uintptr_t)m->d_results;
+    return UNC_OK;
+}
 extern "C" uint32_t unc_mapper_sched_parts(const unc_mapper_t *m) { return (m && m->sched.ctl) ? m->sched.n_parts : 0u; }
 extern "C" double unc_mapper_last_wave_busy(const unc_mapper_t *m) { return m ? m->wave_busy : 0.0; }
 extern "C" int unc_mapper_set_read_order(unc_mapper_t *m, int order) {
@@ -1699,6 +1747,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
     const size_t S = n_channels;
     size_t bytes = 0;
     {
+        PlacementSpacer spacer(S * scratch_slot_bytes(*p, 1u << 20, 2 * p->max_paths, ix->dev) + S * 64 * (size_t)POOL_CHUNK_BYTES);
         int rc = alloc_scratch(rt->sc, *p, S, 1u << 20, 2 * p->max_paths, &bytes, ix->dev);
         if (rc) return rc;
         HIPCHK(hipMemset(rt->sc.base, 0, bytes));
@@ -1712,6 +1761,7 @@ extern "C" int unc_rt_create(const unc_index_t *ix, const unc_params_t *p, uint3
             // the pool shrinks -- with a warning, and never below four chunks per channel -- instead of failing the whole create
             size_t free_b = 0, total_b = 0;
             HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            free_b += spacer.bytes;
             const size_t fit = free_b / 5 * 3 / POOL_CHUNK_BYTES;
             if (n_chunks > fit) {
                 const size_t floor_chunks = std::max<size_t>(64, (size_t)S * 4);
