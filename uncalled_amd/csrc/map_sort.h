@@ -361,10 +361,7 @@ static __device__ __noinline__ void sort_any64(gptr_t sb, KeyArr<6> K, uint32_t 
 // them sequentially.  Work per key: one LDS read and a dozen lane instructions, against ~60 compare-exchanges of the
 // bitonic network -- provided the inputs ARE ascending.  The caller checks the result (`verify`) and sorts the keys the
 // hard way if it is not (an event where the runs of phase E were not ascending after all).
-#ifndef UNC_MERGE_MIN
-#define UNC_MERGE_MIN 256
-#endif
-constexpr uint32_t MERGE_MIN = UNC_MERGE_MIN;     // fewer children than this go straight through the bitonic network
+constexpr uint32_t MERGE_MIN = 256;     // fewer children than this go straight through the bitonic network
 #ifndef UNC_MERGE_REPAIR
 #define UNC_MERGE_REPAIR 1              // (tests build the emulator library with 0: the runs then reach the merge unrepaired, its check
 #endif                                  //  must notice and the event must take the bitonic network instead, with the same result)
