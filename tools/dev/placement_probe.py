@@ -28,15 +28,48 @@ del codes
 cal = capi.make_calib(n, CAL_RANGE, CAL_OFFSET, CAL_DIGITISATION)
 L = ix.L
 L.unc_mapper_device_addresses.argtypes = [C.c_void_p, C.c_void_p]
+import os
+FIXED = torch.cuda.Stream(device=0) if os.environ.get("PROBE_STREAM") else None
+
+
+class _Dev:
+    """a device allocation of the library seen as a torch tensor (uint64 words), through __cuda_array_interface__"""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes) // 8,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+_idx = None
+
+
+def gather_ms(ptr, nbytes, n_idx=1 << 26):
+    """random 8-byte reads over an allocation: what address translation over it costs (ms for 2^26 reads, the best of three)"""
+    global _idx
+    t = torch.as_tensor(_Dev(ptr, nbytes), device="cuda:0")
+    if _idx is None or int(_idx.max()) >= t.numel():
+        _idx = torch.randint(0, t.numel(), (n_idx,), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        s = t[_idx].sum()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
 def run(tag, m):
     t = []
     for _ in range(2):
-        m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal)
+        # PROBE_STREAM=1: every instance launches on ONE stream of the caller's instead of the stream each mapper creates for itself
+        m.map_batch_device(sim["signal"].data_ptr(), sim["offsets"], cal, stream=(FIXED.cuda_stream if FIXED is not None else None))
         t.append(round(m.last_timing()[1], 1))
     a = np.zeros(6, dtype=np.uint64)
     L.unc_mapper_device_addresses(m.h, a.ctypes.data)
+    g_slots = gather_ms(int(a[0]), int(a[1]) * m.geometry()["n_slots"])
+    g_pool = gather_ms(int(a[2]), int(a[3]))
     free_b, _ = torch.cuda.mem_get_info(0)
-    print(f"{tag}: k_map ms {t}  wave_busy {m.last_wave_busy():.3f}  slots at {int(a[0]):#x} pool at {int(a[2]):#x} means at {int(a[4]):#x}  free {free_b / 1e9:.1f} GB", flush=True)
+    print(f"{tag}: k_map ms {t}  random 8-byte reads, 2^26 of them: over the slots {g_slots:.2f} ms, over the pool {g_pool:.2f} ms   wave_busy {m.last_wave_busy():.3f}  slots at {int(a[0]):#x} pool at {int(a[2]):#x} means at {int(a[4]):#x}  free {free_b / 1e9:.1f} GB", flush=True)
 
 
 # plan: comma-separated steps (argv[4]); plain = create, map twice, free; twice = create two, free the first, map on the second;
