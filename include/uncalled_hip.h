@@ -339,6 +339,9 @@ int unc_build_suffix_array(int device, const uint8_t *codes, uint64_t n, int64_t
  * one lane per record and four 16-byte accesses per lane -- k_map's access shape with an exactly known byte count, for
  * calibrating the HBM traffic counters of rocprofv3 (tools/dev/pmc_calib.py, profiles/r02_pmc_k_map.json) */
 int unc_calib_traffic(int device, uint64_t n_records, int reps);
+/* loaded latency of a region of device memory: `waves` (0 = 4096) single-wavefront workgroups, every lane a chain of `steps` (0 = 2000)
+ * dependent 16-byte loads over [base, base + bytes); the launch's duration in milliseconds, the best of three (diagnostics) */
+int unc_calib_chase(int device, const void *base, uint64_t bytes, uint32_t waves, uint32_t steps, float *ms_out);
 
 /* ---- stage taps (parity tests) */
 /* event detection + whole-read normalisation only (EventDetector::get_means, event_detector.cpp:133-145;

@@ -66,10 +66,14 @@ def run(tag, m):
         t.append(round(m.last_timing()[1], 1))
     a = np.zeros(6, dtype=np.uint64)
     L.unc_mapper_device_addresses(m.h, a.ctypes.data)
+    L.unc_calib_chase.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    ch = (C.c_float * 2)()
+    L.unc_calib_chase(0, int(a[0]), int(a[1]) * m.geometry()["n_slots"], 4096, 2000, C.byref(ch, 0))
+    L.unc_calib_chase(0, int(a[2]), int(a[3]), 4096, 2000, C.byref(ch, 4))
     g_slots = gather_ms(int(a[0]), int(a[1]) * m.geometry()["n_slots"])
     g_pool = gather_ms(int(a[2]), int(a[3]))
     free_b, _ = torch.cuda.mem_get_info(0)
-    print(f"{tag}: k_map ms {t}  random 8-byte reads, 2^26 of them: over the slots {g_slots:.2f} ms, over the pool {g_pool:.2f} ms   wave_busy {m.last_wave_busy():.3f}  slots at {int(a[0]):#x} pool at {int(a[2]):#x} means at {int(a[4]):#x}  free {free_b / 1e9:.1f} GB", flush=True)
+    print(f"{tag}: k_map ms {t}  dependent 16-byte loads (4 096 wavefronts x 2 000 steps): slots {ch[0]:.2f} ms, pool {ch[1]:.2f} ms;  random 8-byte reads, 2^26 of them: over the slots {g_slots:.2f} ms, over the pool {g_pool:.2f} ms   wave_busy {m.last_wave_busy():.3f}  slots at {int(a[0]):#x} pool at {int(a[2]):#x} means at {int(a[4]):#x}  free {free_b / 1e9:.1f} GB", flush=True)
 
 
 # plan: comma-separated steps (argv[4]); plain = create, map twice, free; twice = create two, free the first, map on the second;

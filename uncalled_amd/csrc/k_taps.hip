@@ -196,6 +196,23 @@ __global__ void k_calib_read(const uint4 *buf, uint64_t n_rec, uint64_t mult, ui
     }
     if (acc == 0x12345678u) *sink = acc;    // keeps the loads alive
 }
+// Dependent loads over a region, in k_map's shape: 4 096 single-wavefront workgroups, every lane its own chain of `steps` 16-byte loads, the
+// next address hashed from the last load's data (whatever the region holds) -- what a round trip into THAT memory costs while the whole
+// chip is chasing through it.  Diagnostics (unc_calib_chase, tools/dev/placement_probe.py): the two speeds of one library.
+__global__ __launch_bounds__(64, 4) void k_calib_chase(const uint4 *buf, uint64_t n16, uint32_t steps, uint32_t *sink) {
+    uint64_t x = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345ull;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < steps; ++i) {
+        const uint4 v = buf[x % n16];
+        acc += v.x ^ v.w;
+        x = (x ^ v.x ^ ((uint64_t)v.y << 32) ^ i) * 0xD6E8FEB86659FD93ull;
+        x ^= x >> 29;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;      // (keeps the loads alive)
+}
+void launch_calib_chase(const uint4 *buf, uint64_t n16, uint32_t waves, uint32_t steps, uint32_t *sink, hipStream_t st) {
+    hipLaunchKernelGGL(k_calib_chase, dim3(waves), dim3(64), 0, st, buf, n16, steps, sink);
+}
 void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStream_t st) {
     const uint64_t mult = 2654435761ull;    // odd, coprime with any power-of-two-free n_rec the host passes (n_rec is made odd)
     if (write) hipLaunchKernelGGL(k_calib_write, dim3(256 * 16), dim3(256), 0, st, buf, n_rec, mult);

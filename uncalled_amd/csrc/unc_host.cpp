@@ -1467,6 +1467,30 @@ extern "C" int unc_calib_traffic(int device, uint64_t n_records, int reps) {
     return UNC_OK;
 }
 
+// Loaded latency of a region of device memory (diagnostics): `waves` single-wavefront workgroups, every lane a chain of `steps` dependent
+// 16-byte loads over [base, base + bytes) (k_calib_chase); the launch's duration in milliseconds, the best of three.
+extern "C" int unc_calib_chase(int device, const void *base, uint64_t bytes, uint32_t waves, uint32_t steps, float *ms_out) {
+    if (!base || bytes < 16 || !ms_out) return fail(UNC_ERR_ARG, "unc_calib_chase: a region of 16 bytes or more");
+    HIPCHK(hipSetDevice(device));
+    uint32_t *sink = nullptr;
+    hipEvent_t e0, e1;
+    HIPCHK(hipMalloc((void **)&sink, 4));
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        HIPCHK(hipEventRecord(e0, nullptr));
+        launch_calib_chase((const uint4 *)base, bytes / 16, waves ? waves : 4096, steps ? steps : 2000, sink, nullptr);
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+    *ms_out = best;
+    return UNC_OK;
+}
+
 // ------------------------------------------------------------------ step-wise trace of one read
 extern "C" int unc_trace_begin(unc_mapper_t *m, const int16_t *raw, uint32_t n, const unc_calib_t *calib) {
     if (!m || !raw || !calib) return fail(UNC_ERR_ARG, "null argument");

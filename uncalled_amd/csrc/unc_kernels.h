@@ -29,6 +29,7 @@ void launch_fm32_check(const DevIndex &ix, uint32_t n, uint32_t *bad, hipStream_
 void launch_dense_sa_check(const DevIndex &ix, const uint64_t *dense, uint32_t n, uint32_t *bad, hipStream_t st);
 void launch_fm_sa(const DevIndex &ix, uint32_t n, const uint64_t *rows, uint64_t *out, hipStream_t st);
 void launch_calib(uint4 *buf, uint64_t n_rec, int write, uint32_t *sink, hipStream_t st);
+void launch_calib_chase(const uint4 *buf, uint64_t n16, uint32_t waves, uint32_t steps, uint32_t *sink, hipStream_t st);
 void launch_rsort_pass(const uint64_t *kin, const uint64_t *vin, uint64_t *kout, uint64_t *vout, uint64_t n, uint32_t shift, uint32_t iota,
                        uint32_t *counts, uint32_t *sums, hipStream_t st);      // k_sort.hip: one digit of the LSD radix sort
 uint32_t rsort_tile();
