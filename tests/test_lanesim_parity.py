@@ -24,6 +24,23 @@ def test_radix_sort_of_the_index_builders(sim_lib):
     pc.case_radix_sort(sim_lib)
 
 
+def test_calib_chase_runs_over_a_region(sim_lib, example):
+    """unc_calib_chase (diagnostics: dependent loads over a region of device memory): two wavefronts, a handful of steps over a mapper's
+    own slots -- the kernel stays inside the region whatever the region holds, and the entry refuses a region of less than one load."""
+    import ctypes as C
+    import numpy as np
+    from uncalled_amd import capi
+    ix = capi.Index(example["prefix"], lib=sim_lib)
+    m = capi.Mapper(ix, n_slots=2, n_waves=2)
+    a = np.zeros(6, dtype=np.uint64)
+    sim_lib.unc_mapper_device_addresses.argtypes = [C.c_void_p, C.c_void_p]
+    sim_lib.unc_calib_chase.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    assert sim_lib.unc_mapper_device_addresses(m.h, a.ctypes.data) == 0 and int(a[0]) and int(a[1]) and int(a[2])
+    ms = C.c_float(-1.0)
+    assert sim_lib.unc_calib_chase(0, int(a[0]), int(a[1]) * 2, 2, 16, C.byref(ms)) == 0 and ms.value >= 0.0
+    assert sim_lib.unc_calib_chase(0, int(a[0]), 8, 2, 16, C.byref(ms)) != 0
+
+
 def test_suffix_array_built_behind_the_c_abi(sim_lib):
     """unc_build_suffix_array (the suffix sort of `uncalled index` without torch: k_sort.hip's radix sort and the steps between the sorts)
     against the numpy prefix doubling, on texts with ties far deeper than the first 21-symbol key."""
