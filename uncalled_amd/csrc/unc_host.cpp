@@ -206,6 +206,9 @@ struct PlacementSpacer {
     explicit PlacementSpacer(size_t need_after) {
         size_t cap = 64ull << 30;
         if (const char *e = getenv("UNC_PLACEMENT_SPACER_GB")) cap = (size_t)strtoull(e, nullptr, 10) << 30;
+        // (a mapper of a few slots, an index of a few megabytes: what is about to be allocated sits in the caches or is walked by a
+        // handful of wavefronts -- where it lies does not matter, and 64 GB allocated and freed per creation would be all cost)
+        if (need_after < (1ull << 30)) return;
         size_t free_b = 0, total_b = 0;
         if (!cap || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
         const size_t margin = 16ull << 30;       // (left alone beside what is about to be allocated)
