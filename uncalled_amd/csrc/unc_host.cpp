@@ -195,9 +195,9 @@ extern "C" void unc_index_free(unc_index_t *ix) {
 // WHERE in the HBM a mapper's slots and node pool lie decides which of two speeds it runs at, for the life of the allocation: the same
 // library maps the same 50 000 E. coli reads in 2 040 or in 2 250 ms (round 6, tools/dev/placement_probe.py: mapper instances created
 // and freed one after the other at the SAME virtual addresses alternate between the two; one created while 60 GB of other memory is
-// held lands on the fast one every time).  Virtual addresses say nothing; what differs is the physical memory behind them: what the
+// held landed on the fast one three times out of three).  Virtual addresses say nothing; what differs is the physical memory behind them: what the
 // process -- e.g. an index build -- has used and given back is handed out again first, in pieces, and a kernel that walks tens of
-// gigabytes at random pays for the pieces in address translation.  So the big random-access allocations (the slots, the node pool;
+// gigabytes at random pays for the pieces (in latency, not in throughput: DESIGN.md section 5).  So the big random-access allocations (the slots, the node pool;
 // the index's tables likewise) are made while a SPACER holds what was given back, up to 64 GB, and the spacer is freed right after:
 // the streaming buffers allocated later (raw signal, event means) take its place.  UNC_PLACEMENT_SPACER_GB names another size (0: none).
 struct PlacementSpacer {
